@@ -1,0 +1,203 @@
+/*
+ * oasisx_hip.h -- C ABI of the MI355X (gfx950) implementation of the per-time-step
+ * IPCS hot path of oasisx's FractionalStep_AB_CN.
+ *
+ * The reference (ComputationalPhysiology/oasisx, pure Python) has no FFI of its
+ * own: on this path it calls DOLFINx (assembly, set_bc) and PETSc (Mat/Vec/KSP).
+ * Every entry point below replaces one such call site; the file:line cited is
+ * the reference call it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (text via ox_last_error());
+ *   - all pointers marked "device" are HIP device pointers owned by the caller
+ *     (the Python host allocates them with torch); the library owns no field data;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     stream-ordered and only ox_ksp_solve blocks (it returns host-visible results);
+ *   - all floating point data is float64, all indices int32, offsets int64;
+ *   - multi-component vectors are interleaved: v[row*ncomp + comp].
+ *
+ * Matrix layout: SELL-64 ("sliced ELLPACK", one slice = the 64 rows one CDNA
+ * wavefront owns, lane = row).  Inside slice s with width w_s (multiple of OX_KV)
+ * entry k of lane l sits at
+ *      slice_ptr[s] + (k / OX_KV) * 64 * OX_KV + l * OX_KV + (k % OX_KV)
+ * so that a wave reads 64 * 16 B of values with one dwordx4 load per lane.
+ * The dof numbering of a function space IS the SELL row order (rows are grouped
+ * by length inside windows at setup), so no row permutation is applied.
+ */
+#ifndef OASISX_HIP_H
+#define OASISX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OX_KV 2          /* entries of one row stored contiguously (16-B value loads) */
+#define OX_SLICE 64      /* rows per slice = wavefront width */
+
+/* KSPConvergedReason values the step functions return (reference ksp.py:78,
+ * fracstep.py:681,684 assert > 0). */
+#define OX_CONVERGED_RTOL 2
+#define OX_CONVERGED_ATOL 3
+#define OX_CONVERGED_ITS 4
+#define OX_DIVERGED_ITS (-3)
+#define OX_DIVERGED_DTOL (-4)
+#define OX_DIVERGED_BREAKDOWN (-5)
+#define OX_DIVERGED_NANORINF (-9)
+
+#define OX_KSP_CG 1      /* PETSc "cg"   */
+#define OX_KSP_BCGS 2    /* PETSc "bcgs" */
+
+/* SELL-64 matrix: pattern + one value array (PETSc Mat on this path). */
+typedef struct {
+  int64_t n_rows;            /* rows owned by this rank                                  */
+  int64_t n_cols;            /* local columns (owned + ghost)                            */
+  int32_t n_slices;          /* ceil(n_rows / 64)                                        */
+  int32_t reserved;
+  const int64_t *slice_ptr;  /* device [n_slices+1], entry offsets, multiples of 64*OX_KV */
+  const int32_t *cols;       /* device [slice_ptr[n_slices]] (padding: own row, value 0) */
+  double *vals;              /* device [slice_ptr[n_slices]]                             */
+} ox_sell;
+
+/* Cells of the mesh as the element kernels read them. */
+typedef struct {
+  int32_t gdim;              /* 2 (triangles) or 3 (tetrahedra)                          */
+  int32_t reserved;
+  int64_t n_cells;
+  const double *geom;        /* device [n_cells][gs]: grad(lambda_1..d) row-major, |detJ|;
+                                gs = 6 (2-D, one pad) or 10 (3-D)                        */
+} ox_cells;
+
+/* dof -> cell adjacency of one row space in the same SELL-64 row order:
+ * pair (t, lane) of slice s sits at adj_ptr[s] + t*64 + lane. */
+typedef struct {
+  int32_t n_slices;
+  int32_t nd;                /* dofs per cell of the ROW space                           */
+  const int64_t *adj_ptr;    /* device [n_slices+1]                                      */
+  const int32_t *adj_cell;   /* device [pairs], -1 = padding                             */
+  const uint8_t *adj_loc;    /* device [pairs], local index of the row dof in the cell   */
+} ox_adj;
+
+/* Halo plan + communicator for mesh-partitioned runs (NULL = single GPU). */
+typedef struct ox_dist ox_dist;
+
+typedef struct {
+  int32_t reason[4];         /* per component, KSPConvergedReason                        */
+  int32_t its[4];            /* per component, iterations taken                          */
+  double rnorm[4];           /* per component, final preconditioned residual norm        */
+  double bnorm[4];           /* per component, preconditioned norm of b                  */
+} ox_ksp_result;
+
+/* ---- library -------------------------------------------------------------------- */
+int ox_version(void);
+const char *ox_last_error(void);
+int ox_sell_kv(void);
+/* device of the current context: compute units and name (diagnostics for bench.py) */
+int ox_device_info(int *n_cu, char *name, int name_len);
+
+/* ---- S1/S2: Mat.mult (reference fracstep.py:452,501,541,615,638,642) -------------- */
+/* y[row*ncomp+c] = sum_k A[row,k] * x[col_k*ncomp+c]; ncomp in 1..3. */
+int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp, const ox_dist *dist,
+            void *stream);
+
+/* ---- V1: Vec axpy/copy/scale on .x.array (fracstep.py:432-434,456-458,506,604,622,690-693) */
+/* z = a*x + b*y elementwise over n doubles (x, y, z may alias). */
+int ox_axpby(int64_t n, double a, const double *x, double b, const double *y, double *z,
+             void *stream);
+/* V1: out[c] = sum_i x[i*ncomp+c]*y[i*ncomp+c] (Vec.norm/dot, fracstep.py:524); host result. */
+int ox_dot(int64_t n_rows, int ncomp, const double *x, const double *y, double *out_host,
+           const ox_dist *dist, void *stream);
+
+/* ---- V2: set_bc(vec,[bc]) (reference bcs.py:135-139, fracstep.py:518,550) ---------- */
+/* b[dofs[k]*ncomp+comp] = g[k]. */
+int ox_set_bc(double *b, const int32_t *dofs, const double *g, int64_t n, int ncomp, int comp,
+              void *stream);
+
+/* ---- S4: Mat.zeroRowsLocal(rows, diag) (fracstep.py:471-472); keeps columns -------- */
+int ox_zero_rows(const ox_sell *A, const int32_t *rows, int64_t n, double diag, void *stream);
+/* DOLFINx assemble_matrix(..., bcs) on the pressure Laplacian (fracstep.py:379):
+ * rows AND columns flagged in is_bc[] -> identity. */
+int ox_zero_rows_cols(const ox_sell *A, const uint8_t *is_bc, double diag, void *stream);
+
+/* ---- A1/A2/A3: one-off assemble_matrix of mass / stiffness (fracstep.py:373-380) ---- */
+/* kind 0: u*v*dx, kind 1: inner(grad u, grad v)*dx.  Square Lagrange space of `degree`
+ * on `cells`; cell_dofs [n_cells][nd]; adj_pos [pairs][pw] gives, per (row, cell) pair,
+ * the in-row index k of every cell dof.  Overwrites A->vals.  Slices are launched per width
+ * bin: bin b covers bin_slices[bin_ptr_host[b] .. bin_ptr_host[b+1]) (device list) whose rows
+ * are at most bin_width_host[b] entries wide (sizes the per-wave LDS accumulator). */
+int ox_assemble_matrix(int kind, int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                       const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                       int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
+                       const int32_t *bin_width_host, void *stream);
+/* w[row] = int phi_row dx (body-force vector for constant f: fracstep.py:387-390, and
+ * the weights of assemble_scalar(phi*dx): fracstep.py:585-590). */
+int ox_assemble_weights(int degree, const ox_cells *cells, const ox_adj *adj, int64_t n_rows,
+                        double *w, void *stream);
+
+/* ---- A4 + S3 + S1, fused: assemble_first (fracstep.py:432-469) ---------------------- */
+/* With uab = 1.5*u1 - 0.5*u2 already formed (ox_axpby), for every row:
+ *   C   = assemble_matrix(inner(dot(uab, nabla_grad(u)), v)*dx)            (:435-437)
+ *   Ar  = -0.5*C + (1/dt)*M - 0.5*nu*K                                     (:438-442)
+ *   b_first[:, i] = Ar @ u1[:, i] + b0[:, i]                               (:449-458)
+ *   A   = -Ar + (2/dt)*M                                                   (:468-469)
+ * M, K, A share one SELL pattern (fracstep.py:293-294).  Slices are launched per
+ * width bin (bin_ptr/bin_slices/bin_width from the host) so each launch sizes its
+ * LDS accumulator for the widest row of the bin. */
+int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                      const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                      const double *Mvals, const double *Kvals, const double *uab,
+                      const double *u1, const double *b0, double *b_first, double dt, double nu,
+                      int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
+                      const int32_t *bin_width_host, void *stream);
+
+/* ---- A6 / A8: assemble_vector(p * v.dx(i) * dx) and (dp.dx(i) * v * dx), all i at once
+ *      (fracstep.py:487-497 and :618).  kind 0: out[r][i] = base[r][i] + scale * int p d_i(phi_r)
+ *      kind 1: out[r][i] = base[r][i] + scale * int d_i(p) phi_r.  base may be NULL (=0). */
+int ox_assemble_grad_vector(int kind, int row_degree, int p_degree, const ox_cells *cells,
+                            const int32_t *cell_pdofs, const ox_adj *adj, int64_t n_rows,
+                            const double *p, const double *base, double scale, double *out,
+                            void *stream);
+/* ---- A7: assemble_vector(div(u) * q * dx) scaled (fracstep.py:538,546):
+ *      out[r] = scale * int div(u) psi_r,  u interleaved [n_u][gdim]. */
+int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cells *cells,
+                           const int32_t *cell_udofs, const ox_adj *adj, int64_t n_rows,
+                           const double *u, double scale, double *out, void *stream);
+
+/* ---- Jacobi preconditioner setup: dinv[row] = 1 / A[row,row] (PCJACOBI) ------------- */
+int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream);
+
+/* ---- K1/K2/K3: KSP.solve (reference ksp.py:71-78; fracstep.py:521,578,634) ---------- */
+/* Left-Jacobi-preconditioned CG or BiCGStab on `ncomp` right-hand sides that share A
+ * (the velocity components share one matrix, fracstep.py:274,521), run in lockstep with
+ * per-component scalars; PETSc conventions: zero initial guess unless nonzero_guess,
+ * convergence on ||D^-1 r|| <= max(rtol*||D^-1 b||, atol).  Scalars stay on the device;
+ * the host reads the state back every `check_every` iterations. */
+size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type);
+int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
+                 int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
+                 int check_every, void *work, size_t work_bytes, ox_ksp_result *result,
+                 const ox_dist *dist, void *stream);
+
+/* ---- V3 + A10: nullspace.remove and mean shift (fracstep.py:573-574, 579-591) -------- */
+/* x[i] -= (sum_i w[i]*x[i]) / wsum ;  w == NULL -> arithmetic mean (wsum = n). */
+int ox_remove_mean(int64_t n, double *x, const double *w, double wsum, const ox_dist *dist,
+                   void *stream);
+
+/* ---- H1 + collectives: mesh-partitioned runs (one process per GPU, RCCL) -------------- */
+int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 */
+/* send_idx: device, owned rows to pack; per-peer counts; ghosts arrive contiguously per peer
+ * at x[n_owned + recv_off[p] ...]. */
+int ox_dist_create(const char *id128, int rank, int nranks, int n_peers, const int32_t *peers,
+                   const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
+                   int64_t n_owned, int64_t n_ghost, ox_dist **out);
+int ox_dist_destroy(ox_dist *d);
+/* scatter_forward (owner -> ghost) of an interleaved vector (fracstep.py:453,...). */
+int ox_halo_forward(const ox_dist *d, double *x, int ncomp, void *stream);
+int ox_allreduce_sum(const ox_dist *d, double *buf_dev, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

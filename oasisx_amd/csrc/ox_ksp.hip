@@ -1,0 +1,519 @@
+// Jacobi-preconditioned CG and BiCGStab on up to 3 right-hand sides that share one
+// SELL-64 matrix (reference ksp.py:71-78 -> PETSc KSPSolve; fracstep.py:521,578,634).
+//
+// All scalars (alpha, beta, omega, rho, norms, convergence flags) live in a device-side
+// state block; the host only enqueues kernels and reads the state back every
+// `check_every` iterations.  Once every component has converged the state's `done` flag
+// turns the remaining queued kernels into no-ops, so the result is exactly the one an
+// every-iteration check would give.  Reductions are two-stage and ordered (no float
+// atomics): results are bit-reproducible run to run.
+#include "ox_kernels.h"
+
+struct KspState {
+  double rz[OX_MAXC], alpha[OX_MAXC], beta[OX_MAXC], omega[OX_MAXC], rho[OX_MAXC];
+  double bn[OX_MAXC], rn[OX_MAXC];
+  int active[OX_MAXC], reason[OX_MAXC], its[OX_MAXC];
+  int done;  // all components finished
+  int pad[2];
+};
+
+struct KspParams {
+  double rtol, atol;
+  int max_it, nc;
+};
+
+enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3 };
+
+__device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P) {
+  if (!(rn == rn) || isinf(rn)) return OX_DIVERGED_NANORINF;
+  if (rn <= P.atol) return OX_CONVERGED_ATOL;
+  if (rn <= P.rtol * bn) return OX_CONVERGED_RTOL;
+  return 0;
+}
+
+// Scalar logic of one synchronisation point, run by thread c for component c.
+// `s` holds the globally reduced sums of that point.
+template <int PH>
+__device__ __forceinline__ void ksp_logic(KspState *S, const double *s, int c, const KspParams &P) {
+  const int NC = P.nc;
+  if (PH == PH_CG_INIT) {  // s = {r.z, z.z, (Db).(Db)}
+    S->rz[c] = s[c];
+    S->rn[c] = sqrt(s[NC + c]);
+    S->bn[c] = sqrt(s[2 * NC + c]);
+    S->its[c] = 0;
+    S->alpha[c] = 0.0;
+    S->beta[c] = 0.0;
+    const int r = ksp_test(S->rn[c], S->bn[c], P);
+    S->reason[c] = r;
+    S->active[c] = (r == 0);
+  } else if (PH == PH_CG_A) {  // s = {p.q}
+    if (S->active[c]) {
+      const double pq = s[c];
+      if (pq == 0.0 || !(pq == pq)) {
+        S->reason[c] = (pq == pq) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
+        S->active[c] = 0;
+        S->alpha[c] = 0.0;
+      } else {
+        S->alpha[c] = S->rz[c] / pq;
+      }
+    } else {
+      S->alpha[c] = 0.0;
+    }
+  } else if (PH == PH_CG_B) {  // s = {r.z (new), z.z}
+    if (S->active[c]) {
+      S->its[c] += 1;
+      S->rn[c] = sqrt(s[NC + c]);
+      int r = ksp_test(S->rn[c], S->bn[c], P);
+      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
+      if (r) {
+        S->reason[c] = r;
+        S->active[c] = 0;
+        S->beta[c] = 0.0;
+      } else {
+        S->beta[c] = s[c] / S->rz[c];
+        S->rz[c] = s[c];
+      }
+    } else {
+      S->beta[c] = 0.0;
+    }
+  } else if (PH == PH_BCGS_INIT) {  // s = {r.r, (Db).(Db)}  (r already preconditioned)
+    S->rn[c] = sqrt(s[c]);
+    S->bn[c] = sqrt(s[NC + c]);
+    S->its[c] = 0;
+    S->alpha[c] = 1.0;
+    S->omega[c] = 1.0;
+    const int r = ksp_test(S->rn[c], S->bn[c], P);
+    S->reason[c] = r;
+    S->active[c] = (r == 0);
+    // first iteration: rho_new = rhat.r = r.r, beta = (rho_new/1)*(1/1); p = v = 0
+    S->rho[c] = s[c];
+    S->beta[c] = S->active[c] ? s[c] : 0.0;
+    if (S->active[c] && s[c] == 0.0) {
+      S->reason[c] = OX_DIVERGED_BREAKDOWN;
+      S->active[c] = 0;
+    }
+  } else if (PH == PH_BCGS_1) {  // s = {rhat.v}
+    if (S->active[c]) {
+      const double rv = s[c];
+      if (rv == 0.0 || !(rv == rv)) {
+        S->reason[c] = (rv == rv) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
+        S->active[c] = 0;
+        S->alpha[c] = 0.0;
+      } else {
+        S->alpha[c] = S->rho[c] / rv;
+      }
+    } else {
+      S->alpha[c] = 0.0;
+    }
+  } else if (PH == PH_BCGS_2) {  // s = {t.t, t.s}
+    if (S->active[c]) {
+      const double tt = s[c];
+      S->omega[c] = (tt != 0.0) ? s[NC + c] / tt : 0.0;
+    } else {
+      S->omega[c] = 0.0;
+    }
+  } else if (PH == PH_BCGS_3) {  // s = {r.r, rhat.r}
+    if (S->active[c]) {
+      S->its[c] += 1;
+      S->rn[c] = sqrt(s[c]);
+      int r = ksp_test(S->rn[c], S->bn[c], P);
+      if (r == 0 && (S->omega[c] == 0.0 || s[NC + c] == 0.0)) r = OX_DIVERGED_BREAKDOWN;
+      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
+      if (r) {
+        S->reason[c] = r;
+        S->active[c] = 0;
+        S->beta[c] = 0.0;
+      } else {
+        S->beta[c] = (s[NC + c] / S->rho[c]) * (S->alpha[c] / S->omega[c]);
+        S->rho[c] = s[NC + c];
+      }
+    } else {
+      S->beta[c] = 0.0;
+    }
+  }
+}
+
+__device__ __forceinline__ void ksp_finish(KspState *S, int nc) {
+  int any = 0;
+  for (int c = 0; c < nc; ++c) any |= S->active[c];
+  S->done = !any;
+}
+
+// Fused: reduce per-block partials (fixed order) + scalar logic.  One 256-thread block.
+template <int PH>
+__global__ __launch_bounds__(256) void k_ksp_scalar(KspState *S, const double *__restrict__ partial,
+                                                    int nparts, int nv, KspParams P) {
+  __shared__ double red[4];
+  __shared__ double sums[4 * OX_MAXC];
+  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  for (int i = 0; i < nv; ++i) {
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * nv + i];
+    double v[1] = {s};
+    ox_block_sum_256<1>(v, red);
+    if (threadIdx.x == 0) sums[i] = v[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, sums, c, P);
+    ksp_finish(S, P.nc);
+  }
+}
+
+// Logic only (distributed runs: the sums were all-reduced over the ranks first).
+template <int PH>
+__global__ void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspParams P) {
+  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, sums, c, P);
+    ksp_finish(S, P.nc);
+  }
+}
+
+// ------------------------------- vector kernels ------------------------------------------
+// thread = row, NC interleaved components per row (24-B contiguous per lane for NC = 3).
+#define OX_ROW_LOOP                                 \
+  const int64_t stride_ = (int64_t)gridDim.x * 256; \
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride_)
+
+template <int NV>
+__device__ __forceinline__ void ksp_store_partial(double (&s)[NV], double *red, double *partial) {
+  ox_block_sum_256<NV>(s, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+  }
+}
+
+// CG init: r = b - q (q = A x0) or r = b, x = 0;  z = D^-1 r;  p = z
+// partial = {r.z, z.z, (D^-1 b).(D^-1 b)}
+template <int NC>
+__global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__restrict__ b, double *x,
+                                                 const double *q, const double *__restrict__ dinv,
+                                                 double *vr, double *vz, double *vp, int guess,
+                                                 double *partial) {
+  __shared__ double red[4 * 3 * NC];
+  double s[3 * NC];
+#pragma unroll
+  for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
+  OX_ROW_LOOP {
+    const double d = dinv[row];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      const double bi = b[i];
+      double ri = bi;
+      if (guess) ri -= q[i];
+      else x[i] = 0.0;
+      const double zi = d * ri, db = d * bi;
+      vr[i] = ri;
+      vz[i] = zi;
+      vp[i] = zi;
+      s[c] = fma(ri, zi, s[c]);
+      s[NC + c] = fma(zi, zi, s[NC + c]);
+      s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
+    }
+  }
+  ksp_store_partial<3 * NC>(s, red, partial);
+}
+
+// CG: x += alpha p; r -= alpha q; z = D^-1 r; partial = {r.z, z.z}
+template <int NC>
+__global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, double *x,
+                                                    double *vr, double *vz,
+                                                    const double *__restrict__ vp,
+                                                    const double *__restrict__ vq,
+                                                    const double *__restrict__ dinv,
+                                                    double *partial) {
+  __shared__ double red[4 * 2 * NC];
+  if (S->done) return;
+  double alpha[NC], s[2 * NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c];
+#pragma unroll
+  for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
+  OX_ROW_LOOP {
+    const double d = dinv[row];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      x[i] = fma(alpha[c], vp[i], x[i]);
+      const double ri = fma(-alpha[c], vq[i], vr[i]);
+      const double zi = d * ri;
+      vr[i] = ri;
+      vz[i] = zi;
+      s[c] = fma(ri, zi, s[c]);
+      s[NC + c] = fma(zi, zi, s[NC + c]);
+    }
+  }
+  ksp_store_partial<2 * NC>(s, red, partial);
+}
+
+// CG: p = z + beta p
+template <int NC>
+__global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S,
+                                                    const double *__restrict__ vz, double *vp) {
+  if (S->done) return;
+  double beta[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) beta[c] = S->beta[c];
+  OX_ROW_LOOP {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      vp[i] = fma(beta[c], vp[i], vz[i]);
+    }
+  }
+}
+
+// BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = v = 0
+// partial = {r.r, (D^-1 b).(D^-1 b)}
+template <int NC>
+__global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__restrict__ b,
+                                                   double *x, const double *q,
+                                                   const double *__restrict__ dinv, double *vr,
+                                                   double *vrhat, double *vp, double *vv, int guess,
+                                                   double *partial) {
+  __shared__ double red[4 * 2 * NC];
+  double s[2 * NC];
+#pragma unroll
+  for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
+  OX_ROW_LOOP {
+    const double d = dinv[row];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      const double bi = b[i];
+      double ri = bi;
+      if (guess) ri -= q[i];
+      else x[i] = 0.0;
+      ri *= d;
+      const double db = d * bi;
+      vr[i] = ri;
+      vrhat[i] = ri;
+      vp[i] = 0.0;
+      vv[i] = 0.0;
+      s[c] = fma(ri, ri, s[c]);
+      s[NC + c] = fma(db, db, s[NC + c]);
+    }
+  }
+  ksp_store_partial<2 * NC>(s, red, partial);
+}
+
+// BiCGStab: p = r + beta (p - omega v)
+template <int NC>
+__global__ __launch_bounds__(256) void k_bcgs_p(int64_t n, const KspState *S,
+                                                const double *__restrict__ vr, double *vp,
+                                                const double *__restrict__ vv) {
+  if (S->done) return;
+  double beta[NC], omega[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    beta[c] = S->beta[c];
+    omega[c] = S->omega[c];
+  }
+  OX_ROW_LOOP {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      vp[i] = fma(beta[c], fma(-omega[c], vv[i], vp[i]), vr[i]);
+    }
+  }
+}
+
+// BiCGStab: s = r - alpha v
+template <int NC>
+__global__ __launch_bounds__(256) void k_bcgs_s(int64_t n, const KspState *S,
+                                                const double *__restrict__ vr,
+                                                const double *__restrict__ vv, double *vs) {
+  if (S->done) return;
+  double alpha[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c];
+  OX_ROW_LOOP {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      vs[i] = fma(-alpha[c], vv[i], vr[i]);
+    }
+  }
+}
+
+// BiCGStab: x += alpha p + omega s; r = s - omega t; partial = {r.r, rhat.r}
+template <int NC>
+__global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, double *x, double *vr,
+                                                const double *__restrict__ vrhat,
+                                                const double *__restrict__ vp,
+                                                const double *__restrict__ vs,
+                                                const double *__restrict__ vt, double *partial) {
+  __shared__ double red[4 * 2 * NC];
+  if (S->done) return;
+  double alpha[NC], omega[NC], s[2 * NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    alpha[c] = S->alpha[c];
+    omega[c] = S->omega[c];
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
+  OX_ROW_LOOP {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      const double si = vs[i];
+      x[i] = fma(omega[c], si, fma(alpha[c], vp[i], x[i]));
+      const double ri = fma(-omega[c], vt[i], si);
+      vr[i] = ri;
+      s[c] = fma(ri, ri, s[c]);
+      s[NC + c] = fma(vrhat[i], ri, s[NC + c]);
+    }
+  }
+  ksp_store_partial<2 * NC>(s, red, partial);
+}
+
+// ------------------------------- host driver ---------------------------------------------
+static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct KspLayout {
+  size_t state, sums, partial, vec0, vec_stride, total;
+  int nvec, nparts_max;
+};
+
+static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type) {
+  KspLayout L;
+  const int n_slices = (int)((n_rows + 63) / 64);
+  const int nblk_spmv = (n_slices + 3) / 4;
+  L.nparts_max = nblk_spmv > OX_VEC_MAX_BLOCKS ? nblk_spmv : OX_VEC_MAX_BLOCKS;
+  L.nvec = ksp_type == OX_KSP_CG ? 4 : 6;
+  L.state = 0;
+  L.sums = ox_align(sizeof(KspState));
+  L.partial = L.sums + ox_align(sizeof(double) * 4 * OX_MAXC);
+  L.vec0 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
+  L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
+  L.total = L.vec0 + L.vec_stride * L.nvec;
+  return L;
+}
+
+extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type) {
+  return ksp_layout(n_rows, n_cols, ncomp, ksp_type).total;
+}
+
+static KspState *g_state_host = nullptr;
+
+template <int PH>
+static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
+                          const KspParams &P, const ox_dist *dist, hipStream_t st) {
+  if (!dist) {
+    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(256), 0, st, S, partial, nparts, nv, P);
+    OX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (ox_reduce_partials(partial, nparts, nv, sums, st)) return -1;
+  if (ox_allreduce_impl(dist, sums, nv, st)) return -1;
+  hipLaunchKernelGGL((k_ksp_logic<PH>), dim3(1), dim3(64), 0, st, S, sums, P);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NC>
+static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
+                   const KspParams &P, int guess, int check_every, char *work,
+                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st) {
+  const int64_t n = A->n_rows;
+  const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type);
+  KspState *S = reinterpret_cast<KspState *>(work + L.state);
+  double *sums = reinterpret_cast<double *>(work + L.sums);
+  double *partial = reinterpret_cast<double *>(work + L.partial);
+  double *vec[6];
+  for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
+  const int nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
+  const int nbs = ox_spmv_blocks(A);
+  const int *done = &S->done;
+  if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, sizeof(KspState)));
+
+  if (ksp_type == OX_KSP_CG) {
+    double *vr = vec[0], *vz = vec[1], *vp = vec[2], *vq = vec[3];
+    if (guess) {
+      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
+      if (ox_spmv_launch(A, x, vq, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+    }
+    hipLaunchKernelGGL((k_cg_init<NC>), dim3(nb), dim3(256), 0, st, n, b, x, vq, dinv, vr, vz, vp, guess, partial);
+    OX_LAUNCH_CHECK();
+    if (ksp_sync_point<PH_CG_INIT>(S, partial, nb, 3 * NC, sums, P, dist, st)) return -1;
+    for (int it = 0; it <= P.max_it;) {
+      for (int k = 0; k < check_every; ++k, ++it) {
+        if (dist && ox_halo_forward_impl(dist, vp, NC, st)) return -1;
+        if (ox_spmv_launch(A, vp, vq, NC, OX_EPI_DOT, nullptr, nullptr, partial, done, st)) return -1;
+        if (ksp_sync_point<PH_CG_A>(S, partial, nbs, NC, sums, P, dist, st)) return -1;
+        hipLaunchKernelGGL((k_cg_update1<NC>), dim3(nb), dim3(256), 0, st, n, S, x, vr, vz, vp, vq, dinv, partial);
+        OX_LAUNCH_CHECK();
+        if (ksp_sync_point<PH_CG_B>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
+        hipLaunchKernelGGL((k_cg_update2<NC>), dim3(nb), dim3(256), 0, st, n, S, vz, vp);
+        OX_LAUNCH_CHECK();
+      }
+      OX_HIP(hipMemcpyAsync(g_state_host, S, sizeof(KspState), hipMemcpyDeviceToHost, st));
+      OX_HIP(hipStreamSynchronize(st));
+      if (g_state_host->done) break;
+    }
+  } else {
+    double *vr = vec[0], *vrhat = vec[1], *vp = vec[2], *vv = vec[3], *vs = vec[4], *vt = vec[5];
+    if (guess) {
+      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
+      if (ox_spmv_launch(A, x, vt, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+    }
+    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(nb), dim3(256), 0, st, n, b, x, vt, dinv, vr, vrhat, vp, vv, guess, partial);
+    OX_LAUNCH_CHECK();
+    if (ksp_sync_point<PH_BCGS_INIT>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
+    for (int it = 0; it <= P.max_it;) {
+      for (int k = 0; k < check_every; ++k, ++it) {
+        hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(nb), dim3(256), 0, st, n, S, vr, vp, vv);
+        OX_LAUNCH_CHECK();
+        if (dist && ox_halo_forward_impl(dist, vp, NC, st)) return -1;
+        if (ox_spmv_launch(A, vp, vv, NC, OX_EPI_BCGS_V, dinv, vrhat, partial, done, st)) return -1;
+        if (ksp_sync_point<PH_BCGS_1>(S, partial, nbs, NC, sums, P, dist, st)) return -1;
+        hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(nb), dim3(256), 0, st, n, S, vr, vv, vs);
+        OX_LAUNCH_CHECK();
+        if (dist && ox_halo_forward_impl(dist, vs, NC, st)) return -1;
+        if (ox_spmv_launch(A, vs, vt, NC, OX_EPI_BCGS_T, dinv, nullptr, partial, done, st)) return -1;
+        if (ksp_sync_point<PH_BCGS_2>(S, partial, nbs, 2 * NC, sums, P, dist, st)) return -1;
+        hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(nb), dim3(256), 0, st, n, S, x, vr, vrhat, vp, vs, vt, partial);
+        OX_LAUNCH_CHECK();
+        if (ksp_sync_point<PH_BCGS_3>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
+      }
+      OX_HIP(hipMemcpyAsync(g_state_host, S, sizeof(KspState), hipMemcpyDeviceToHost, st));
+      OX_HIP(hipStreamSynchronize(st));
+      if (g_state_host->done) break;
+    }
+  }
+  if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
+  for (int c = 0; c < NC; ++c) {
+    result->reason[c] = g_state_host->reason[c];
+    result->its[c] = g_state_host->its[c];
+    result->rnorm[c] = g_state_host->rn[c];
+    result->bnorm[c] = g_state_host->bn[c];
+  }
+  return 0;
+}
+
+extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
+                            double *x, int ncomp, double rtol, double atol, int max_it,
+                            int nonzero_guess, int check_every, void *work, size_t work_bytes,
+                            ox_ksp_result *result, const ox_dist *dist, void *stream) {
+  if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
+  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS) OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
+  if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
+  if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))
+    OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes,
+            ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type));
+  if (max_it < 1) max_it = 1;
+  if (check_every < 1) check_every = 1;
+  memset(result, 0, sizeof(*result));
+  KspParams P{rtol, atol, max_it, ncomp};
+  hipStream_t st = ox_stream(stream);
+  char *w = static_cast<char *>(work);
+  switch (ncomp) {
+    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
+    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
+    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
+  }
+}

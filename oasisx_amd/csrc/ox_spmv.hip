@@ -1,0 +1,394 @@
+// SELL-64 SpMV / multi-vector SpMM, BLAS-1, set_bc, zero-rows, Jacobi setup.
+// Memory-bound float64 kernels for gfx950: lane = row, 16-B value loads, XCD-aware
+// slice mapping.  No MFMA: the path is sparse and HBM-bound.
+#include "ox_common.h"
+#include "ox_kernels.h"
+
+thread_local char ox_err_buf[512] = "";
+
+extern "C" int ox_version(void) { return 100; }
+extern "C" const char *ox_last_error(void) { return ox_err_buf; }
+extern "C" int ox_sell_kv(void) { return OX_KV; }
+
+extern "C" int ox_device_info(int *n_cu, char *name, int name_len) {
+  int dev = 0;
+  OX_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  OX_HIP(hipGetDeviceProperties(&p, dev));
+  if (n_cu) *n_cu = p.multiProcessorCount;
+  if (name && name_len > 0) {
+    strncpy(name, p.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// SpMV.  One wave per slice (lane = row), 4 slices per 256-thread block.  Per k-pair a lane
+// loads 16 B of values + 8 B of columns (coalesced over the wave: 1 KiB + 512 B) and gathers
+// NC doubles of x per entry.  EPI selects the fused epilogue the Krylov loops need.
+// ---------------------------------------------------------------------------------------
+template <int NC, int EPI>
+__global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restrict__ x,
+                                              double *__restrict__ y,
+                                              const double *__restrict__ dinv,
+                                              const double *__restrict__ aux,
+                                              double *__restrict__ partial,
+                                              const int *__restrict__ done_flag) {
+  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
+  __shared__ double red[4 * NV];
+  if (done_flag && *done_flag) return;
+  const int nblk = gridDim.x;
+  const int b = ox_xcd_remap(blockIdx.x, nblk);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slice = b * 4 + wave;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  if (slice < A.n_slices) {
+    const int64_t base = A.slice_ptr[slice];
+    const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);  // width / OX_KV
+    const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
+    const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+#pragma unroll 4
+    for (int k = 0; k < npair; ++k) {
+      const double2 v = vp[(size_t)k * 64];
+      const int2 c = cp[(size_t)k * 64];
+      const double *x0 = x + (size_t)c.x * NC;
+      const double *x1 = x + (size_t)c.y * NC;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.x, x0[cc], acc[cc]);
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
+    }
+  }
+  const bool live = slice < A.n_slices && row < A.n_rows;
+  if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] *= dinv[row];  // one matrix, one diagonal
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) y[row * NC + c] = acc[c];
+  }
+  if (EPI != OX_EPI_NONE) {
+    double s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.0;
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (EPI == OX_EPI_DOT) s[c] = x[row * NC + c] * acc[c];
+        if (EPI == OX_EPI_BCGS_V) s[c] = aux[row * NC + c] * acc[c];
+        if (EPI == OX_EPI_BCGS_T) {
+          s[c] = acc[c] * acc[c];
+          s[NC + c] = acc[c] * x[row * NC + c];
+        }
+      }
+    }
+    ox_block_sum_256<NV>(s, red);
+    if (threadIdx.x == 0) {
+      // partial slot = ORIGINAL block index: the order of the final sum is fixed
+#pragma unroll
+      for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+    }
+  }
+}
+
+int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
+                   const double *dinv, const double *aux, double *partial, const int *done,
+                   hipStream_t st) {
+  const int nblk = ox_spmv_blocks(A);
+  if (nblk == 0) return 0;
+#define OX_SPMV_CASE(NC, E)                                                                     \
+  if (ncomp == NC && epi == E) {                                                                \
+    hipLaunchKernelGGL((k_spmv<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, \
+                       done);                                                                   \
+    OX_LAUNCH_CHECK();                                                                          \
+    return 0;                                                                                   \
+  }
+#define OX_SPMV_NC(NC)               \
+  OX_SPMV_CASE(NC, OX_EPI_NONE)      \
+  OX_SPMV_CASE(NC, OX_EPI_DOT)       \
+  OX_SPMV_CASE(NC, OX_EPI_BCGS_V)    \
+  OX_SPMV_CASE(NC, OX_EPI_BCGS_T)
+  OX_SPMV_NC(1) OX_SPMV_NC(2) OX_SPMV_NC(3)
+#undef OX_SPMV_NC
+#undef OX_SPMV_CASE
+  OX_FAIL("ox_spmv: unsupported ncomp=%d epi=%d", ncomp, epi);
+}
+
+extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
+                       const ox_dist *dist, void *stream) {
+  if (!A || !x || !y) OX_FAIL("ox_spmv: null argument");
+  if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_spmv: ncomp=%d out of range", ncomp);
+  hipStream_t st = ox_stream(stream);
+  if (dist) {
+    int rc = ox_halo_forward_impl(dist, const_cast<double *>(x), ncomp, st);
+    if (rc) return rc;
+  }
+  return ox_spmv_launch(A, x, y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Deterministic final reduction of per-block partials: sums[i] = sum_p partial[p*nv+i],
+// always in the same order (no float atomics anywhere on the path).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial,
+                                                         int nparts, int nv,
+                                                         double *__restrict__ sums) {
+  __shared__ double red[4];
+  for (int i = 0; i < nv; ++i) {
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * nv + i];
+    double v[1] = {s};
+    ox_block_sum_256<1>(v, red);
+    if (threadIdx.x == 0) sums[i] = v[0];
+    __syncthreads();
+  }
+}
+
+int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, nparts, nv, sums);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// BLAS-1
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double *x, double b,
+                                               const double *y, double *z) {
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+    double2 r;
+    if (b != 0.0) {
+      const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+      const double2 yv = reinterpret_cast<const double2 *>(y)[i];
+      r.x = a * xv.x + b * yv.x;
+      r.y = a * xv.y + b * yv.y;
+    } else {
+      const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+      r.x = a * xv.x;
+      r.y = a * xv.y;
+    }
+    reinterpret_cast<double2 *>(z)[i] = r;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    z[i] = (b != 0.0) ? a * x[i] + b * y[i] : a * x[i];
+  }
+}
+
+extern "C" int ox_axpby(int64_t n, double a, const double *x, double b, const double *y, double *z,
+                        void *stream) {
+  if (n <= 0) return 0;
+  if (!x || !z || (b != 0.0 && !y)) OX_FAIL("ox_axpby: null argument");
+  const int nblk = ox_vec_blocks(n);
+  hipLaunchKernelGGL(k_axpby, dim3(nblk), dim3(256), 0, ox_stream(stream), n, a, x, b, y, z);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_dot(int64_t n_rows, const double *__restrict__ x,
+                                             const double *__restrict__ y,
+                                             double *__restrict__ partial) {
+  __shared__ double red[4 * NC];
+  double s[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s[c] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += stride) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s[c] = fma(x[r * NC + c], y[r * NC + c], s[c]);
+  }
+  ox_block_sum_256<NC>(s, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) partial[(size_t)blockIdx.x * NC + c] = s[c];
+  }
+}
+
+static double *g_scratch = nullptr;       // device scratch for ox_dot / ox_remove_mean
+static double *g_scratch_host = nullptr;  // pinned
+static int ox_scratch_init() {
+  if (!g_scratch) {
+    OX_HIP(hipMalloc(&g_scratch, sizeof(double) * (OX_VEC_MAX_BLOCKS * 4 + 16)));
+    OX_HIP(hipHostMalloc(&g_scratch_host, sizeof(double) * 16));
+  }
+  return 0;
+}
+
+extern "C" int ox_dot(int64_t n_rows, int ncomp, const double *x, const double *y, double *out_host,
+                      const ox_dist *dist, void *stream) {
+  if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_dot: ncomp=%d", ncomp);
+  if (ox_scratch_init()) return -1;
+  hipStream_t st = ox_stream(stream);
+  const int nblk = ox_vec_blocks(n_rows > 0 ? n_rows : 1);
+  double *partial = g_scratch, *sums = g_scratch + OX_VEC_MAX_BLOCKS * 4;
+  switch (ncomp) {
+    case 1: hipLaunchKernelGGL(k_dot<1>, dim3(nblk), dim3(256), 0, st, n_rows, x, y, partial); break;
+    case 2: hipLaunchKernelGGL(k_dot<2>, dim3(nblk), dim3(256), 0, st, n_rows, x, y, partial); break;
+    default: hipLaunchKernelGGL(k_dot<3>, dim3(nblk), dim3(256), 0, st, n_rows, x, y, partial); break;
+  }
+  OX_LAUNCH_CHECK();
+  if (ox_reduce_partials(partial, nblk, ncomp, sums, st)) return -1;
+  if (dist && ox_allreduce_impl(dist, sums, ncomp, st)) return -1;
+  OX_HIP(hipMemcpyAsync(g_scratch_host, sums, sizeof(double) * ncomp, hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  for (int c = 0; c < ncomp; ++c) out_host[c] = g_scratch_host[c];
+  return 0;
+}
+
+// x -= (sum w*x)/wsum   (w == NULL: plain sum)
+__global__ __launch_bounds__(256) void k_wsum(int64_t n, const double *__restrict__ x,
+                                              const double *__restrict__ w,
+                                              double *__restrict__ partial) {
+  __shared__ double red[4];
+  double s[1] = {0.0};
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    s[0] += w ? w[i] * x[i] : x[i];
+  ox_block_sum_256<1>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(256) void k_shift(int64_t n, double *x, const double *sum,
+                                               double inv_wsum) {
+  const double m = sum[0] * inv_wsum;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] -= m;
+}
+
+extern "C" int ox_remove_mean(int64_t n, double *x, const double *w, double wsum,
+                              const ox_dist *dist, void *stream) {
+  if (n <= 0) return 0;
+  if (ox_scratch_init()) return -1;
+  if (wsum == 0.0) OX_FAIL("ox_remove_mean: wsum == 0");
+  hipStream_t st = ox_stream(stream);
+  const int nblk = ox_vec_blocks(n);
+  double *partial = g_scratch, *sums = g_scratch + OX_VEC_MAX_BLOCKS * 4;
+  hipLaunchKernelGGL(k_wsum, dim3(nblk), dim3(256), 0, st, n, x, w, partial);
+  OX_LAUNCH_CHECK();
+  if (ox_reduce_partials(partial, nblk, 1, sums, st)) return -1;
+  if (dist && ox_allreduce_impl(dist, sums, 1, st)) return -1;
+  hipLaunchKernelGGL(k_shift, dim3(nblk), dim3(256), 0, st, n, x, sums, 1.0 / wsum);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Boundary conditions
+// ---------------------------------------------------------------------------------------
+__global__ void k_set_bc(double *b, const int32_t *dofs, const double *g, int64_t n, int ncomp,
+                         int comp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[(int64_t)dofs[i] * ncomp + comp] = g[i];
+}
+
+extern "C" int ox_set_bc(double *b, const int32_t *dofs, const double *g, int64_t n, int ncomp,
+                         int comp, void *stream) {
+  if (n <= 0) return 0;
+  if (!b || !dofs || !g) OX_FAIL("ox_set_bc: null argument");
+  if (comp < 0 || comp >= ncomp) OX_FAIL("ox_set_bc: comp=%d ncomp=%d", comp, ncomp);
+  hipLaunchKernelGGL(k_set_bc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ox_stream(stream),
+                     b, dofs, g, n, ncomp, comp);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+__device__ __forceinline__ int64_t ox_entry(const int64_t base, int k, int lane) {
+  return base + (int64_t)(k / OX_KV) * (64 * OX_KV) + lane * OX_KV + (k % OX_KV);
+}
+
+__global__ void k_zero_rows(ox_sell A, const int32_t *rows, int64_t n, double diag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = rows[i];
+  const int slice = row >> 6, lane = row & 63;
+  const int64_t base = A.slice_ptr[slice];
+  const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
+  bool placed = false;
+  for (int k = 0; k < width; ++k) {
+    const int64_t e = ox_entry(base, k, lane);
+    const bool isd = (A.cols[e] == row) && !placed;  // first match = the real diagonal entry
+    A.vals[e] = isd ? diag : 0.0;
+    placed = placed || isd;
+  }
+}
+
+extern "C" int ox_zero_rows(const ox_sell *A, const int32_t *rows, int64_t n, double diag,
+                            void *stream) {
+  if (n <= 0) return 0;
+  if (!A || !rows) OX_FAIL("ox_zero_rows: null argument");
+  hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ox_stream(stream),
+                     *A, rows, n, diag);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_zero_rows_cols(ox_sell A, const uint8_t *is_bc,
+                                                        double diag) {
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= A.n_slices) return;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  if (row >= A.n_rows) return;
+  const int64_t base = A.slice_ptr[slice];
+  const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
+  const bool rbc = is_bc[row];
+  bool placed = false;
+  for (int k = 0; k < width; ++k) {
+    const int64_t e = ox_entry(base, k, lane);
+    const int c = A.cols[e];
+    if (rbc || is_bc[c]) {
+      const bool isd = rbc && c == row && !placed;
+      A.vals[e] = isd ? diag : 0.0;
+      placed = placed || isd;
+    }
+  }
+}
+
+extern "C" int ox_zero_rows_cols(const ox_sell *A, const uint8_t *is_bc, double diag,
+                                 void *stream) {
+  if (!A || !is_bc) OX_FAIL("ox_zero_rows_cols: null argument");
+  if (A->n_slices == 0) return 0;
+  hipLaunchKernelGGL(k_zero_rows_cols, dim3((A->n_slices + 3) / 4), dim3(256), 0,
+                     ox_stream(stream), *A, is_bc, diag);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+// dinv[row] = 1 / A[row,row]; the diagonal is the first entry whose column equals the row
+// (padding entries repeat the row index with value 0 and always come later).
+__global__ __launch_bounds__(256) void k_jacobi(ox_sell A, double *dinv) {
+  const int b = ox_xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = b * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= A.n_slices) return;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const int64_t base = A.slice_ptr[slice];
+  const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
+  const int2 *cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+  int kd = -1;
+  for (int k = 0; k < npair; ++k) {
+    const int2 c = cp[(size_t)k * 64];
+    if (kd < 0 && c.x == row) kd = 2 * k;
+    if (kd < 0 && c.y == row) kd = 2 * k + 1;
+  }
+  if (row < A.n_rows) {
+    const double d = kd >= 0 ? A.vals[ox_entry(base, kd, lane)] : 0.0;
+    dinv[row] = d != 0.0 ? 1.0 / d : 1.0;
+  }
+}
+
+extern "C" int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream) {
+  if (!A || !dinv) OX_FAIL("ox_jacobi_setup: null argument");
+  const int nblk = ox_spmv_blocks(A);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(k_jacobi, dim3(nblk), dim3(256), 0, ox_stream(stream), *A, dinv);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
