@@ -1,0 +1,144 @@
+"""ctypes binding of ``liboasisx_hip.so`` (declared in ``include/oasisx_hip.h``).
+
+The HIP library IS the compute path: there is no CPU fallback.  ``load()`` raises
+if the shared object is missing, and every wrapper raises ``OasisxHipError`` with the
+library's message when a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboasisx_hip.so")
+
+KSP_CG, KSP_BCGS = 1, 2
+CONVERGED_RTOL, CONVERGED_ATOL, CONVERGED_ITS = 2, 3, 4
+DIVERGED_ITS, DIVERGED_DTOL, DIVERGED_BREAKDOWN, DIVERGED_NANORINF = -3, -4, -5, -9
+
+
+class OasisxHipError(RuntimeError):
+    pass
+
+
+class ox_sell(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64),
+        ("n_cols", C.c_int64),
+        ("n_slices", C.c_int32),
+        ("reserved", C.c_int32),
+        ("slice_ptr", C.c_void_p),
+        ("cols", C.c_void_p),
+        ("vals", C.c_void_p),
+    ]
+
+
+class ox_cells(C.Structure):
+    _fields_ = [
+        ("gdim", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_cells", C.c_int64),
+        ("geom", C.c_void_p),
+    ]
+
+
+class ox_adj(C.Structure):
+    _fields_ = [
+        ("n_slices", C.c_int32),
+        ("nd", C.c_int32),
+        ("adj_ptr", C.c_void_p),
+        ("adj_cell", C.c_void_p),
+        ("adj_loc", C.c_void_p),
+    ]
+
+
+class ox_ksp_result(C.Structure):
+    _fields_ = [
+        ("reason", C.c_int32 * 4),
+        ("its", C.c_int32 * 4),
+        ("rnorm", C.c_double * 4),
+        ("bnorm", C.c_double * 4),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_D = C.c_double
+
+# name -> (restype, argtypes); the complete export list of include/oasisx_hip.h
+SIGNATURES = {
+    "ox_version": (_I, []),
+    "ox_last_error": (C.c_char_p, []),
+    "ox_sell_kv": (_I, []),
+    "ox_device_info": (_I, [C.POINTER(_I), C.c_char_p, _I]),
+    "ox_spmv": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
+    "ox_axpby": (_I, [_L, _D, _P, _D, _P, _P, _P]),
+    "ox_dot": (_I, [_L, _I, _P, _P, C.POINTER(_D), _P, _P]),
+    "ox_set_bc": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "ox_zero_rows": (_I, [C.POINTER(ox_sell), _P, _L, _D, _P]),
+    "ox_zero_rows_cols": (_I, [C.POINTER(ox_sell), _P, _D, _P]),
+    "ox_assemble_matrix": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
+                                C.POINTER(ox_sell), _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
+    "ox_assemble_weights": (_I, [_I, C.POINTER(ox_cells), C.POINTER(ox_adj), _L, _P, _P]),
+    "ox_assemble_first": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
+                               C.POINTER(ox_sell), _P, _P, _P, _P, _P, _P, _D, _D, _I,
+                               C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
+    "ox_assemble_grad_vector": (_I, [_I, _I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P,
+                                     _P, _D, _P, _P]),
+    "ox_assemble_div_vector": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P, _D,
+                                    _P, _P]),
+    "ox_jacobi_setup": (_I, [C.POINTER(ox_sell), _P, _P]),
+    "ox_ksp_work_bytes": (C.c_size_t, [_L, _L, _I, _I]),
+    "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _P,
+                          C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
+    "ox_remove_mean": (_I, [_L, _P, _P, _D, _P, _P]),
+    "ox_comm_unique_id": (_I, [C.c_char_p]),
+    "ox_dist_create": (_I, [C.c_char_p, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
+                            C.POINTER(_L), _L, _L, C.POINTER(_P)]),
+    "ox_dist_destroy": (_I, [_P]),
+    "ox_halo_forward": (_I, [_P, _P, _I, _P]),
+    "ox_allreduce_sum": (_I, [_P, _P, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OasisxHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  oasisx_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ox_last_error().decode(errors="replace")
+        raise OasisxHipError(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    """hipStream_t of torch's current stream on the current device (0 on CPU)."""
+    import torch
+
+    if torch.cuda.is_available():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(0)

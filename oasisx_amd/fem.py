@@ -1,0 +1,491 @@
+"""Lagrange P1/P2 function spaces, fields and the device data layout of the IPCS path.
+
+A ``FunctionSpace`` owns, as torch tensors on the setup device:
+
+* the cell->dof table in the FINAL dof numbering.  Dofs are first ordered lexicographically
+  by coordinate (z, y, x) for gather locality and then, inside windows of ``window`` rows,
+  stably by decreasing row length: the numbering itself is the SELL-64 row order, so a
+  wave's 64 rows have (nearly) equal length and equal cell counts -- no padding waste, no
+  divergence, no row permutation at run time;
+* the SELL-64 sparsity pattern of the square operator on the space (see include/oasisx_hip.h);
+* the dof->cell adjacency in the same slice order, with per-(row, cell) position bytes that
+  tell the row-centric assembly kernels where each cell dof sits inside the row.
+
+The DOLFINx-shaped surface (``Function.x.array``, ``interpolate``, ``Constant``,
+``locate_dofs_*``) is what the oasisx callers touch (reference bcs.py:103-139,
+demo/taylor_green.py:142-182, fracstep.py:187-216,698-705).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+
+import numpy as np
+import torch
+
+from . import _lib
+from .mesh import Mesh
+
+KV = 2
+SLICE = 64
+default_scalar_type = np.float64
+
+
+def local_edges(gdim: int):
+    return [(1, 2), (0, 2), (0, 1)] if gdim == 2 else [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+
+
+def cell_geometry(mesh: Mesh) -> torch.Tensor:
+    """[n_cells][gs] rows of grad(lambda_1..d) then |detJ| (gs = 6 in 2-D, 10 in 3-D)."""
+    d = mesh.gdim
+    x = mesh.coords[mesh.cells]  # (nc, d+1, d)
+    J = (x[:, 1:, :] - x[:, :1, :]).transpose(1, 2).contiguous()  # columns = edge vectors
+    det = torch.linalg.det(J)
+    Jinv = torch.linalg.inv(J)  # rows = grad lambda_a, a = 1..d
+    gs = 6 if d == 2 else 10
+    geom = torch.zeros((mesh.num_cells, gs), dtype=torch.float64, device=mesh.device)
+    geom[:, : d * d] = Jinv.reshape(mesh.num_cells, d * d)
+    geom[:, d * d] = det.abs()
+    return geom
+
+
+class SellPattern:
+    """SELL-64 sparsity pattern shared by every matrix on one (row space, col space)."""
+
+    def __init__(self, n_rows, n_cols, slice_ptr, cols, row_len, widths):
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.slice_ptr = slice_ptr  # int64 [n_slices+1] device
+        self.cols = cols  # int32 device
+        self.row_len = row_len  # int32 [n_rows] device
+        self.widths = widths  # int32 [n_slices] host numpy
+        self.n_slices = int(widths.shape[0])
+        self.size = int(cols.shape[0])
+        self.nnz = int(row_len.sum().item())
+        self.device = cols.device
+        # width bins for the LDS-accumulating row kernels
+        w = torch.from_numpy(widths.astype(np.int64))
+        order = torch.argsort(w, stable=True)
+        ws = w[order]
+        uw, counts = torch.unique_consecutive(ws, return_counts=True)
+        self.bin_width = uw.numpy().astype(np.int32)
+        self.bin_ptr = np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64)
+        self.bin_slices = order.to(torch.int32).to(self.device)
+
+    def new_values(self) -> torch.Tensor:
+        return torch.zeros(self.size, dtype=torch.float64, device=self.device)
+
+    def struct(self, vals: torch.Tensor) -> _lib.ox_sell:
+        assert vals.shape[0] == self.size and vals.dtype == torch.float64
+        return _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
+                            self.cols.data_ptr(), vals.data_ptr())
+
+    def bins_args(self):
+        return (int(self.bin_width.shape[0]), self.bin_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                _lib.ptr(self.bin_slices), self.bin_width.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    # ---- host-side conversions (tests / diagnostics, small sizes) ----------------------
+    def slot_rows_k(self):
+        """For every storage slot: (row, k) -- host numpy."""
+        sp = self.slice_ptr.cpu().numpy()
+        o = np.arange(self.size, dtype=np.int64)
+        s = np.searchsorted(sp, o, side="right") - 1
+        loc = o - sp[s]
+        k = (loc // (SLICE * KV)) * KV + loc % KV
+        lane = (loc % (SLICE * KV)) // KV
+        return s * SLICE + lane, k
+
+    def to_csr(self, vals: torch.Tensor):
+        import scipy.sparse as sp
+
+        rows, k = self.slot_rows_k()
+        rl = np.zeros(self.n_slices * SLICE, dtype=np.int64)
+        rl[: self.n_rows] = self.row_len.cpu().numpy()
+        ok = k < rl[rows]
+        A = sp.coo_matrix((vals.cpu().numpy()[ok], (rows[ok], self.cols.cpu().numpy()[ok])),
+                          shape=(self.n_rows, self.n_cols)).tocsr()
+        A.sort_indices()
+        return A
+
+    def values_from_csr(self, A) -> torch.Tensor:
+        """SELL value array holding the entries of scipy CSR ``A`` (same pattern or a subset)."""
+        rows, k = self.slot_rows_k()
+        cols = self.cols.cpu().numpy()
+        rl = np.zeros(self.n_slices * SLICE, dtype=np.int64)
+        rl[: self.n_rows] = self.row_len.cpu().numpy()
+        ok = k < rl[rows]
+        out = np.zeros(self.size)
+        A = A.tocsr()
+        out[ok] = np.asarray(A[rows[ok], cols[ok]]).ravel()
+        return torch.from_numpy(out).to(self.device)
+
+
+class AdjTable:
+    """dof -> cell adjacency in slice order (+ in-row positions of the cell dofs)."""
+
+    def __init__(self, n_slices, nd, adj_ptr, adj_cell, adj_loc, adj_pos, pw):
+        self.n_slices, self.nd = n_slices, nd
+        self.adj_ptr, self.adj_cell, self.adj_loc = adj_ptr, adj_cell, adj_loc
+        self.adj_pos, self.pw = adj_pos, pw
+
+    def struct(self) -> _lib.ox_adj:
+        return _lib.ox_adj(self.n_slices, self.nd, self.adj_ptr.data_ptr(), self.adj_cell.data_ptr(),
+                           self.adj_loc.data_ptr())
+
+
+class _Element:
+    def __init__(self, degree, gdim):
+        self.degree = degree
+        self.family = "Lagrange"
+        self.gdim = gdim
+
+
+class _DofMap:
+    def __init__(self, V):
+        self._V = V
+        self.index_map = type("IndexMap", (), {"size_local": V.num_dofs, "num_ghosts": 0,
+                                               "size_global": V.num_dofs})()
+        self.index_map_bs = 1
+
+    def cell_dofs(self, c):
+        return self._V.cell_dofs[c].cpu().numpy()
+
+
+class FunctionSpace:
+    """Scalar Lagrange space of degree 1 or 2 on a simplicial mesh."""
+
+    def __init__(self, mesh: Mesh, degree: int, window: int = 4096, build_operator: bool = True,
+                 chunk_cells: int = 1 << 21):
+        if degree not in (1, 2):
+            raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
+        self.mesh = mesh
+        self.degree = degree
+        self.element = _Element(degree, mesh.gdim)
+        self.num_sub_spaces = 0
+        dev = mesh.device
+        d = mesh.gdim
+        nverts = mesh.num_vertices
+        cells = mesh.cells
+        nc = mesh.num_cells
+        # ---- 1. initial dofs: vertices, then edges --------------------------------------
+        if degree == 1:
+            cd0 = cells
+            ndofs = nverts
+            x0 = mesh.coords
+            self._edge_keys = None
+        else:
+            ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)
+            eb = torch.tensor([e[1] for e in local_edges(d)], device=dev)
+            a, b = cells[:, ea], cells[:, eb]
+            key = torch.minimum(a, b) * nverts + torch.maximum(a, b)
+            uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)
+            cd0 = torch.cat([cells, nverts + inv.reshape(nc, -1)], dim=1)
+            ndofs = nverts + int(uniq.shape[0])
+            x0 = torch.cat([mesh.coords, 0.5 * (mesh.coords[uniq // nverts] + mesh.coords[uniq % nverts])])
+            self._edge_keys = uniq
+            del a, b, key, inv
+        nd = int(cd0.shape[1])
+        self.nd = nd
+        self.num_dofs = ndofs
+        # ---- 2. spatial (z, y, x) ordering ---------------------------------------------
+        lo = x0.min(dim=0).values
+        span = (x0.max(dim=0).values - lo).clamp_min(1e-300)
+        q = torch.round((x0 - lo) / span * float(1 << 20)).to(torch.int64)
+        skey = q[:, d - 1]
+        for k in range(d - 2, -1, -1):
+            skey = skey * (1 << 21) + q[:, k]
+        perm1 = torch.argsort(skey, stable=True)
+        rank1 = torch.empty_like(perm1)
+        rank1[perm1] = torch.arange(ndofs, device=dev)
+        del skey, q
+        cd1 = rank1[cd0]
+        # ---- 3. pattern in that numbering (chunked unique of row*n+col keys) -------------
+        keys = None
+        for c0 in range(0, nc, chunk_cells):
+            blk = cd1[c0:c0 + chunk_cells]
+            kk = torch.unique((blk.unsqueeze(2) * ndofs + blk.unsqueeze(1)).reshape(-1))
+            keys = kk if keys is None else torch.unique(torch.cat([keys, kk]))
+        row1 = torch.div(keys, ndofs, rounding_mode="floor")
+        len1 = torch.bincount(row1, minlength=ndofs)
+        # ---- 4. window sort by decreasing row length (stable) -----------------------------
+        lmax = int(len1.max().item())
+        wkey = (torch.arange(ndofs, device=dev) // window) * (lmax + 1) + (lmax - len1)
+        perm2 = torch.argsort(wkey, stable=True)
+        rank2 = torch.empty_like(perm2)
+        rank2[perm2] = torch.arange(ndofs, device=dev)
+        del wkey
+        rank = rank2[rank1]  # initial dof -> final dof
+        self._rank_initial = rank
+        self.cell_dofs = rank[cd0].to(torch.int32).contiguous()
+        xf = torch.empty_like(x0)
+        xf[rank] = x0
+        self.x = xf  # (ndofs, gdim) dof coordinates
+        self._x3 = None
+        self.vertex_dofs = rank[:nverts]
+        self.dofmap = _DofMap(self)
+        self.pattern = None
+        self.adj = None
+        if not build_operator:
+            del keys
+            self._build_adjacency(None, None)
+            return
+        # ---- 5. final pattern: relabel + sort ---------------------------------------------
+        keys2 = torch.sort(rank2[row1] * ndofs + rank2[keys - row1 * ndofs]).values
+        del keys, row1
+        rowf = torch.div(keys2, ndofs, rounding_mode="floor")
+        colf = (keys2 - rowf * ndofs).to(torch.int32)
+        row_len = torch.bincount(rowf, minlength=ndofs)
+        row_ptr = torch.zeros(ndofs + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:] = torch.cumsum(row_len, 0)
+        self.pattern = build_sell(ndofs, ndofs, rowf, colf, row_len, row_ptr)
+        self._build_adjacency(keys2, row_ptr)
+        del keys2
+
+    # ---------------------------------------------------------------------------------
+    def _build_adjacency(self, keys_sorted, row_ptr, chunk_pairs: int = 1 << 24):
+        dev = self.mesh.device
+        nd, ndofs, nc = self.nd, self.num_dofs, self.mesh.num_cells
+        n_slices = (ndofs + SLICE - 1) // SLICE
+        dof = self.cell_dofs.reshape(-1).to(torch.int64)
+        order = torch.argsort(dof, stable=True)  # pairs grouped by dof, cells ascending
+        dof_s = dof[order]
+        cell_s = torch.div(order, nd, rounding_mode="floor")
+        loc_s = order - cell_s * nd
+        cnt = torch.bincount(dof_s, minlength=ndofs)
+        start = torch.zeros(ndofs + 1, dtype=torch.int64, device=dev)
+        start[1:] = torch.cumsum(cnt, 0)
+        t = torch.arange(dof_s.shape[0], device=dev) - start[dof_s]
+        cpad = torch.zeros(n_slices * SLICE, dtype=torch.int64, device=dev)
+        cpad[:ndofs] = cnt
+        T = cpad.reshape(n_slices, SLICE).max(dim=1).values
+        adj_ptr = torch.zeros(n_slices + 1, dtype=torch.int64, device=dev)
+        adj_ptr[1:] = torch.cumsum(T * SLICE, 0)
+        npairs = int(adj_ptr[-1].item())
+        off = adj_ptr[dof_s // SLICE] + t * SLICE + (dof_s % SLICE)
+        adj_cell = torch.full((npairs,), -1, dtype=torch.int32, device=dev)
+        adj_cell[off] = cell_s.to(torch.int32)
+        adj_loc = torch.zeros(npairs, dtype=torch.uint8, device=dev)
+        adj_loc[off] = loc_s.to(torch.uint8)
+        adj_pos, pw = None, 0
+        if keys_sorted is not None:
+            pw = 4 if nd <= 4 else (8 if nd <= 8 else 16)
+            if int(self.pattern.widths.max()) > 255:
+                raise ValueError("row longer than 255 entries: position bytes overflow")
+            adj_pos = torch.zeros((npairs, pw), dtype=torch.uint8, device=dev)
+            P = dof_s.shape[0]
+            for p0 in range(0, P, chunk_pairs):
+                sl = slice(p0, min(P, p0 + chunk_pairs))
+                r = dof_s[sl]
+                cd = self.cell_dofs[cell_s[sl]].to(torch.int64)  # (m, nd)
+                g = torch.searchsorted(keys_sorted, (r.unsqueeze(1) * ndofs + cd).reshape(-1))
+                k = g.reshape(-1, nd) - row_ptr[r].unsqueeze(1)
+                adj_pos[off[sl], :nd] = k.to(torch.uint8)
+        self.adj = AdjTable(n_slices, nd, adj_ptr, adj_cell, adj_loc, adj_pos, pw)
+        self.adj_count = cnt
+
+    # ---- DOLFINx-shaped helpers -------------------------------------------------------
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        if self._x3 is None:
+            x = np.zeros((self.num_dofs, 3))
+            x[:, : self.mesh.gdim] = self.x.cpu().numpy()
+            self._x3 = x
+        return self._x3
+
+    def entity_dofs(self, dim: int, entities) -> np.ndarray:
+        """Dofs on the closure of mesh entities (vertices + edges for P2)."""
+        mesh = self.mesh
+        ev, _ = mesh._entities(dim)
+        verts = ev[np.asarray(entities, dtype=np.int64)].reshape(len(entities), -1)
+        vd = self.vertex_dofs.cpu().numpy()
+        dofs = [vd[verts.ravel()]]
+        if self.degree == 2 and verts.shape[1] >= 2:
+            ek = self._edge_keys.cpu().numpy()
+            rank = self._rank_initial.cpu().numpy()
+            nv = mesh.num_vertices
+            for a, b in itertools.combinations(range(verts.shape[1]), 2):
+                lo = np.minimum(verts[:, a], verts[:, b])
+                hi = np.maximum(verts[:, a], verts[:, b])
+                idx = np.searchsorted(ek, lo * np.int64(nv) + hi)
+                dofs.append(rank[nv + idx])
+        return np.unique(np.concatenate(dofs)).astype(np.int32)
+
+
+def build_sell(n_rows, n_cols, rowf, colf, row_len, row_ptr) -> SellPattern:
+    """SELL-64 layout from a row-sorted COO/CSR pattern (device tensors)."""
+    dev = colf.device
+    n_slices = (n_rows + SLICE - 1) // SLICE
+    lpad = torch.zeros(n_slices * SLICE, dtype=torch.int64, device=dev)
+    lpad[:n_rows] = row_len
+    width = lpad.reshape(n_slices, SLICE).max(dim=1).values
+    width = ((width + KV - 1) // KV) * KV
+    width = torch.clamp(width, min=KV)
+    slice_ptr = torch.zeros(n_slices + 1, dtype=torch.int64, device=dev)
+    slice_ptr[1:] = torch.cumsum(width * SLICE, 0)
+    size = int(slice_ptr[-1].item())
+    # padding slots repeat the row's own index (value 0); rows past n_rows point at column 0
+    o = torch.arange(size, device=dev)
+    s = torch.searchsorted(slice_ptr, o, right=True) - 1
+    lane = ((o - slice_ptr[s]) % (SLICE * KV)) // KV
+    own = s * SLICE + lane
+    cols = torch.where(own < min(n_rows, n_cols), own, torch.zeros_like(own)).to(torch.int32)
+    del o, s, lane, own
+    k = torch.arange(rowf.shape[0], device=dev) - row_ptr[rowf]
+    off = slice_ptr[rowf // SLICE] + (k // KV) * (SLICE * KV) + (rowf % SLICE) * KV + (k % KV)
+    cols[off] = colf
+    return SellPattern(n_rows, n_cols, slice_ptr, cols, row_len.to(torch.int32),
+                       width.cpu().numpy().astype(np.int32))
+
+
+def functionspace(mesh: Mesh, element, **kwargs):
+    """``dolfinx.fem.functionspace(mesh, ("Lagrange", k))`` (also with a shape tuple)."""
+    if isinstance(element, FunctionSpace):
+        return element
+    family, degree = element[0], int(element[1])
+    if str(family).lower() not in ("lagrange", "p", "cg"):
+        raise ValueError(f"unsupported element family {family!r}")
+    V = FunctionSpace(mesh, degree, **kwargs)
+    if len(element) > 2 and element[2]:
+        return VectorFunctionSpace(V, int(element[2][0]))
+    return V
+
+
+class VectorFunctionSpace:
+    """Blocked space (bs = dim) over a scalar space: dof (i, c) at index i*dim + c."""
+
+    def __init__(self, Vi: FunctionSpace, dim: int):
+        self.scalar = Vi
+        self.mesh = Vi.mesh
+        self.dim = dim
+        self.num_sub_spaces = dim
+        self.num_dofs = Vi.num_dofs
+        self.element = Vi.element
+
+    def sub(self, i):
+        return _SubSpace(self, i)
+
+    def tabulate_dof_coordinates(self):
+        return self.scalar.tabulate_dof_coordinates()
+
+
+class _SubSpace:
+    def __init__(self, V, i):
+        self._V, self._i = V, i
+
+    def collapse(self):
+        n, dim = self._V.num_dofs, self._V.dim
+        return self._V.scalar, (np.arange(n, dtype=np.int32) * dim + self._i)
+
+
+# ---- fields ----------------------------------------------------------------------------------
+
+
+class FieldStorage:
+    """(n_alloc, nc) float64 block on the device with a lazily synchronised host mirror.
+
+    The device copy is authoritative.  ``host()`` checks the block out: it is copied to the
+    host and the returned numpy array may be read and written; the next device use copies
+    it back.  (On a CPU-only machine both views share memory.)"""
+
+    def __init__(self, n: int, nc: int, device, n_alloc: int | None = None):
+        self.n, self.nc = int(n), int(nc)
+        self.n_alloc = int(n if n_alloc is None else n_alloc)
+        self._dev = torch.zeros((self.n_alloc, self.nc), dtype=torch.float64, device=device)
+        self._shared = self._dev.device.type == "cpu"
+        self._host = self._dev.numpy()[: self.n] if self._shared else None
+        self._out = False
+
+    def host(self) -> np.ndarray:
+        if self._shared:
+            return self._host
+        if not self._out:
+            if self._host is None:
+                self._host = np.empty((self.n, self.nc))
+            self._host[...] = self._dev[: self.n].cpu().numpy()
+            self._out = True
+        return self._host
+
+    def dev(self) -> torch.Tensor:
+        if self._out:
+            self._dev[: self.n].copy_(torch.from_numpy(self._host))
+            self._out = False
+        return self._dev
+
+    def ptr(self):
+        return C.c_void_p(self.dev().data_ptr())
+
+
+class Vector:
+    """``dolfinx.la.Vector`` / PETSc Vec stand-in over one column (or all) of a FieldStorage."""
+
+    def __init__(self, storage: FieldStorage, comp: int | None):
+        self._s, self._c = storage, comp
+
+    @property
+    def array(self) -> np.ndarray:
+        h = self._s.host()
+        return h.reshape(-1) if self._c is None else h[:, self._c]
+
+    @property
+    def petsc_vec(self):
+        return self
+
+    def scatter_forward(self):
+        pass
+
+    def scatter_reverse(self, mode=None):
+        pass
+
+
+class Constant:
+    """``dolfinx.fem.Constant``: a mutable value shared by reference."""
+
+    def __init__(self, mesh, value):
+        self.mesh = mesh
+        self._v = np.asarray(value, dtype=np.float64).copy()
+
+    @property
+    def value(self):
+        return self._v
+
+    @value.setter
+    def value(self, v):
+        self._v[...] = np.asarray(v, dtype=np.float64)
+
+    def __float__(self):
+        return float(self._v)
+
+
+class Function:
+    """Field on a scalar space (one column of a shared block) or on a blocked space."""
+
+    def __init__(self, V, name: str = "f", storage: FieldStorage | None = None, comp: int | None = None):
+        self.function_space = V
+        self.name = name
+        if storage is None:
+            if isinstance(V, VectorFunctionSpace):
+                storage, comp = FieldStorage(V.num_dofs, V.dim, V.mesh.device), None
+            else:
+                storage, comp = FieldStorage(V.num_dofs, 1, V.mesh.device), 0
+        self._storage, self._comp = storage, comp
+        self.x = Vector(storage, comp)
+
+    def interpolate(self, f):
+        """Nodal interpolation of ``f(x)``, x of shape (3, npts) (reference bcs.py:125,133)."""
+        X = self.function_space.tabulate_dof_coordinates().T
+        if isinstance(f, Function):
+            self.x.array[:] = f.x.array
+            return
+        vals = np.asarray(f(X), dtype=np.float64)
+        if self._comp is None:
+            dim = self._storage.nc
+            self._storage.host()[:, :] = vals.reshape(dim, -1).T
+        else:
+            self.x.array[:] = vals.reshape(-1)
+
+
+def locate_dofs_geometrical(V, marker) -> np.ndarray:
+    X = V.tabulate_dof_coordinates().T
+    return np.nonzero(np.asarray(marker(X), dtype=bool))[0].astype(np.int32)
+
+
+def locate_dofs_topological(V, entity_dim: int, entities) -> np.ndarray:
+    return V.entity_dofs(entity_dim, np.asarray(entities))

@@ -1,0 +1,313 @@
+"""``FractionalStep_AB_CN`` -- the IPCS fractional-step solver (Adams-Bashforth convection,
+Crank-Nicolson diffusion) with the Python surface of reference src/oasisx/fracstep.py:29-705,
+running on hand-written HIP kernels (liboasisx_hip.so) instead of DOLFINx assembly + PETSc.
+
+Data layout on the device
+  * velocity-like fields are (n_u, gdim) interleaved blocks, so the gdim component systems,
+    which share one matrix (reference fracstep.py:274,521,634), are multiplied and solved
+    together: one pass over the matrix per SpMV instead of gdim;
+  * M, K, A share one SELL-64 pattern (reference fracstep.py:293-294), Ap has its own;
+  * the p*-, div(u)- and grad(phi)-terms are always evaluated matrix-free (the reference's
+    ``low_memory_version=True`` path, fracstep.py:485-497,537-538,612-634); the option is
+    accepted and both settings give the same numbers (they differ in the reference only by
+    round-off, too).
+
+Deviations from the reference, by necessity of the platform:
+  * ``preonly``+``lu`` is mapped to a tightly converged Krylov solve (ksp.py);
+  * without pressure BCs the reference overrides the pressure solver with MUMPS
+    (fracstep.py:562-576); here the configured solver (CG + Jacobi) runs on the mean-free
+    right-hand side -- the mass-weighted shift that follows makes the result unique.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib
+from .bcs import DirichletBC, PressureBC
+from .fem import (FieldStorage, Function, FunctionSpace, VectorFunctionSpace, cell_geometry,
+                  functionspace)
+from .ksp import KSPSolver
+from .la import SellMatrix
+
+__all__ = ["FractionalStep_AB_CN"]
+
+
+def _degree(element):
+    if isinstance(element, FunctionSpace):
+        return element.degree
+    fam = str(element[0]).lower()
+    if fam not in ("lagrange", "p", "cg"):
+        raise ValueError(f"unsupported element family {element[0]!r}")
+    return int(element[1])
+
+
+class FractionalStep_AB_CN:
+    """
+    Create the fractional step solver with Adam-Bashforth linearization
+    of the convective term, and Crank-Nicholson time discretization.
+
+    Args:
+        mesh: The computational domain
+        u_element: ``("Lagrange", k)`` for each velocity component (k = 1, 2)
+        p_element: ``("Lagrange", 1)`` for the pressure
+        bcs_u: list of Dirichlet BCs for each component of the velocity
+        bcs_p: list of pressure BCs
+        rotational: rotational pressure update (not implemented on the HIP path yet)
+        solver_options: dict with keys ``'tentative'``, ``'pressure'``, ``'scalar'`` leading
+            to PETSc-style option dicts (see :mod:`oasisx_amd.ksp`)
+        jit_options: accepted for compatibility, ignored (nothing is JIT compiled)
+        options: ``"low_memory_version"`` accepted (see module docstring)
+        body_force: constant force per direction
+    """
+
+    def __init__(self, mesh, u_element, p_element, bcs_u, bcs_p, rotational: bool = False,
+                 solver_options: dict | None = None, jit_options: dict | None = None,
+                 body_force=None, options: dict | None = None):
+        self._lib = _lib.load()  # fails loudly when the HIP library is missing
+        self._mesh = mesh
+        gdim = mesh.geometry.dim
+        self._gdim = gdim
+        dev = mesh.device
+        u_deg, p_deg = _degree(u_element), _degree(p_element)
+        if p_deg != 1:
+            raise NotImplementedError("pressure space must be Lagrange degree 1")
+        if rotational:
+            raise NotImplementedError("rotational pressure update is not implemented on the HIP path yet")
+        if len(bcs_p) > 0:
+            raise NotImplementedError("PressureBC (open boundaries) is not implemented on the HIP path yet")
+        window = int((options or {}).get("sell_window", 4096))
+
+        # ---- spaces (reference fracstep.py:186-216) ----------------------------------------
+        Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window)
+        if isinstance(p_element, FunctionSpace):
+            Q = p_element
+        else:
+            Q = Vi if u_deg == p_deg else FunctionSpace(mesh, p_deg, window=window)
+        self._V = VectorFunctionSpace(Vi, gdim)
+        self._Vi = [self._V.sub(i).collapse() for i in range(gdim)]
+        self._Q = Q
+        nu_, nq_ = Vi.num_dofs, Q.num_dofs
+        self._n_u, self._n_q = nu_, nq_
+
+        def block():
+            return FieldStorage(nu_, gdim, dev)
+
+        self._U, self._U1, self._U2, self._UAB = block(), block(), block(), block()
+        self._RHS1, self._B0, self._BFIRST, self._WRK = block(), block(), block(), block()
+        self._B3 = block()
+        comp = range(gdim)
+        self._sol_u = Function(self._V, "u", storage=self._U, comp=None)
+        self._u = [Function(Vi, f"u{i}", self._U, i) for i in comp]
+        self._u1 = [Function(Vi, f"u_{i}1", self._U1, i) for i in comp]
+        self._u2 = [Function(Vi, f"u_{i}2", self._U2, i) for i in comp]
+        self._uab = [Function(Vi, f"u_{i}ab", self._UAB, i) for i in comp]
+        self._rhs1 = [Function(Vi, f"rhs1_{i}", self._RHS1, i) for i in comp]
+        self._b0 = [Function(Vi, f"b0_{i}", self._B0, i) for i in comp]
+        self._b_first = [Function(Vi, f"b_first_{i}", self._BFIRST, i) for i in comp]
+        self._wrk_vel = [Function(Vi, f"wrk_{i}", self._WRK, i) for i in comp]
+
+        self._PS, self._P, self._DP, self._B2 = (FieldStorage(nq_, 1, dev) for _ in range(4))
+        self._ps = Function(Q, "ps", self._PS, 0)
+        self._p = Function(Q, "p", self._P, 0)
+        self._dp = Function(Q, "dp", self._DP, 0)
+        self._b2 = Function(Q, "b2", self._B2, 0)
+
+        # ---- boundary conditions (reference fracstep.py:196-200,218-227) ---------------------
+        self._bcs_u = bcs_u
+        for bc_i in self._bcs_u:
+            for bc in bc_i:
+                bc.create_bc(Vi)
+        self._bcs_p = bcs_p
+
+        # ---- solvers (reference fracstep.py:229-255) -------------------------------------
+        solver_options = {} if solver_options is None else solver_options
+        self._solver_u = KSPSolver(mesh.comm, solver_options.get("tentative"), prefix="tentative_velocity")
+        self._solver_p = KSPSolver(mesh.comm, solver_options.get("pressure"), prefix="pressure_correction")
+        self._solver_c = KSPSolver(mesh.comm, solver_options.get("scalar"), prefix="velocity_update")
+        self._projector_p = None
+
+        if options is None:
+            options = {}
+        self._low_memory = options.get("low_memory_version", True)
+        if body_force is None:
+            body_force = (0.0,) * gdim
+        self._body_force = [float(f) for f in body_force]
+
+        self._compile_and_allocate_forms()
+        self._preassemble()
+
+        # reference fracstep.py:270-275
+        self._solver_p.setOperators(self._Ap)
+        self._solver_p.setOptions(self._Ap)
+        self._solver_c.setOperators(self._M)
+        self._solver_u.setOperators(self._A)
+        self._solver_u.setOptions(self._A)
+        self.timings = {}
+
+    # ------------------------------------------------------------------------------------
+    def _compile_and_allocate_forms(self):
+        """Device mesh data and matrix allocation (reference fracstep.py:277-358: nothing is
+        compiled here -- the element kernels are the templated HIP kernels of ox_assemble.hip)."""
+        mesh = self._mesh
+        Vi, Q = self._Vi[0][0], self._Q
+        self._geom = cell_geometry(mesh)
+        self._cells = _lib.ox_cells(mesh.gdim, 0, mesh.num_cells, self._geom.data_ptr())
+        self._adj_u = Vi.adj.struct()
+        self._adj_q = Q.adj.struct()
+        self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
+        self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")
+        self._A = SellMatrix(Vi.pattern, symmetric=False, name="A")
+        self._Ap = SellMatrix(Q.pattern, symmetric=True, name="Ap")
+
+    def _assemble_matrix(self, kind, V: FunctionSpace, adj_struct, Mat: SellMatrix):
+        nb, bptr, bsl, bw = V.pattern.bins_args()
+        _lib.check(self._lib.ox_assemble_matrix(kind, V.degree, C.byref(self._cells), _lib.ptr(V.cell_dofs),
+                                                C.byref(adj_struct), _lib.ptr(V.adj.adj_pos), V.adj.pw,
+                                                Mat.ref(), nb, bptr, bsl, bw, _lib.current_stream()),
+                   "ox_assemble_matrix")
+        Mat.version += 1
+
+    def _preassemble(self):
+        """Time-independent operators (reference fracstep.py:360-409)."""
+        lib, st = self._lib, _lib.current_stream()
+        Vi, Q = self._Vi[0][0], self._Q
+        dev = self._mesh.device
+        self._assemble_matrix(0, Vi, self._adj_u, self._M)  # mass        (:373)
+        self._assemble_matrix(1, Vi, self._adj_u, self._K)  # stiffness   (:375)
+        self._assemble_matrix(1, Q, self._adj_q, self._Ap)  # pressure Laplacian (:379)
+        # int phi_r dx on both spaces: body force vector (:387-390), mean of phi (:585-590)
+        self._wV = torch.empty(Vi.num_dofs, dtype=torch.float64, device=dev)
+        self._wQ = torch.empty(Q.num_dofs, dtype=torch.float64, device=dev)
+        _lib.check(lib.ox_assemble_weights(Vi.degree, C.byref(self._cells), C.byref(self._adj_u), Vi.num_dofs,
+                                           _lib.ptr(self._wV), st), "ox_assemble_weights")
+        _lib.check(lib.ox_assemble_weights(Q.degree, C.byref(self._cells), C.byref(self._adj_q), Q.num_dofs,
+                                           _lib.ptr(self._wQ), st), "ox_assemble_weights")
+        f = torch.tensor(self._body_force, dtype=torch.float64, device=dev)
+        self._B0.dev()[: Vi.num_dofs] = self._wV.unsqueeze(1) * f.unsqueeze(0)
+        self._vol = float(self._wQ.sum().item())  # assemble_scalar(1*dx) (:581-584)
+
+    # ------------------------------------------------------------------------------------
+    def assemble_first(self, dt: float, nu: float):
+        """Reference fracstep.py:411-472: A = M/dt + C/2 + nu K/2 and the part of the RHS that
+        depends on the previous time step, b_k = (M/dt - C/2 - nu K/2) u_k^{n-1} + b0_k."""
+        lib, st = self._lib, _lib.current_stream()
+        n = self._n_u * self._gdim
+        # u_ab = 1.5 u_1 - 0.5 u_2 (:432-434)
+        _lib.check(lib.ox_axpby(n, 1.5, self._U1.ptr(), -0.5, self._U2.ptr(), self._UAB.ptr(), st), "ox_axpby")
+        Vi = self._Vi[0][0]
+        nb, bptr, bsl, bw = Vi.pattern.bins_args()
+        _lib.check(lib.ox_assemble_first(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
+                                         C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
+                                         self._A.ref(), _lib.ptr(self._M.vals), _lib.ptr(self._K.vals),
+                                         self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
+                                         float(dt), float(nu), nb, bptr, bsl, bw, st), "ox_assemble_first")
+        self._A.version += 1
+        # NOTE (reference :470): rows of the FIRST component's BCs only
+        for bcu in self._bcs_u[0]:
+            self._A.zero_rows(bcu._dofs_dev, 1.0)
+
+    def velocity_tentative_assemble(self):
+        """rhs1_k = b_first_k + int p* dv/dx_k (reference fracstep.py:474-506)."""
+        Vi, Q = self._Vi[0][0], self._Q
+        _lib.check(self._lib.ox_assemble_grad_vector(0, Vi.degree, Q.degree, C.byref(self._cells),
+                                                     _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.num_dofs,
+                                                     self._PS.ptr(), self._BFIRST.ptr(), 1.0, self._RHS1.ptr(),
+                                                     _lib.current_stream()), "ox_assemble_grad_vector")
+
+    def velocity_tentative_solve(self):
+        """Apply the Dirichlet values to the RHS and solve the gdim tentative-velocity systems
+        (reference fracstep.py:508-525).  Returns (diff, errors)."""
+        lib, st = self._lib, _lib.current_stream()
+        gdim = self._gdim
+        for i in range(gdim):
+            for bc in self._bcs_u[i]:
+                bc.apply(self._rhs1[i].x)
+        n = self._n_u * gdim
+        _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._WRK.ptr(), st), "ox_axpby")
+        errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U), dtype=np.int32)
+        # diff = sum_i || u_i^old - u_i ||_2 (:523-524)
+        _lib.check(lib.ox_axpby(n, 1.0, self._WRK.ptr(), -1.0, self._U.ptr(), self._WRK.ptr(), st), "ox_axpby")
+        out = (C.c_double * 4)()
+        _lib.check(lib.ox_dot(self._n_u, gdim, self._WRK.ptr(), self._WRK.ptr(), out, None, st), "ox_dot")
+        diff = float(sum(np.sqrt(out[i]) for i in range(gdim)))
+        return diff, errors
+
+    def pressure_assemble(self, dt: float):
+        """b2 = -(1/dt) int div(u) q (reference fracstep.py:527-551)."""
+        Vi, Q = self._Vi[0][0], self._Q
+        _lib.check(self._lib.ox_assemble_div_vector(Q.degree, Vi.degree, C.byref(self._cells),
+                                                    _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.num_dofs,
+                                                    self._U.ptr(), -1.0 / float(dt), self._B2.ptr(),
+                                                    _lib.current_stream()), "ox_assemble_div_vector")
+
+    def pressure_solve(self, nu: float | None = None, rotational: bool = False):
+        """Solve the pressure-correction problem (reference fracstep.py:553-605)."""
+        lib, st = self._lib, _lib.current_stream()
+        logger = logging.getLogger("oasisx")
+        nq = self._n_q
+        if len(self._bcs_p) == 0:
+            # nullspace.remove(b2): subtract the arithmetic mean (:573-574)
+            _lib.check(lib.ox_remove_mean(nq, self._B2.ptr(), None, float(nq), None, st), "ox_remove_mean")
+        converged = self._solver_p.solve_block(self._B2, self._DP)[0]
+        if len(self._bcs_p) == 0:
+            logger.debug("Making sure that mean of phi is 0 with lack of pressure conditions")
+            # dp -= (int dp dx) / (int 1 dx) (:579-591)
+            _lib.check(lib.ox_remove_mean(nq, self._DP.ptr(), _lib.ptr(self._wQ), self._vol, None, st),
+                       "ox_remove_mean")
+        # ps = p + dp (:604)
+        _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 1.0, self._DP.ptr(), self._PS.ptr(), st), "ox_axpby")
+        return converged
+
+    def velocity_update(self, dt) -> np.ndarray:
+        """M u_k = M u*_k - dt int dphi/dx_k v (reference fracstep.py:607-658; un-BC'd mass
+        matrix, no Dirichlet re-imposition, exactly as the reference)."""
+        lib, st = self._lib, _lib.current_stream()
+        Vi, Q = self._Vi[0][0], self._Q
+        gdim = self._gdim
+        self._M.mult(self._U.dev(), self._B3.dev(), gdim)
+        _lib.check(lib.ox_assemble_grad_vector(1, Vi.degree, Q.degree, C.byref(self._cells),
+                                               _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.num_dofs,
+                                               self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr(), st),
+                   "ox_assemble_grad_vector")
+        return np.asarray(self._solver_c.solve_block(self._B3, self._U), dtype=np.int32)
+
+    def solve(self, dt: float, nu: float, max_error: float = 1e-12, max_iter: int = 10):
+        """Propagate the splitting scheme one time step (reference fracstep.py:660-696)."""
+        lib, st = self._lib, _lib.current_stream()
+        inner_it = 0
+        diff = 1e8
+        nq, n = self._n_q, self._n_u * self._gdim
+        _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 0.0, None, self._PS.ptr(), st), "ox_axpby")
+        for bcu in self._bcs_u:
+            for bc in bcu:
+                bc.update_bc()
+        self.assemble_first(dt, nu)
+        while inner_it < max_iter and diff > max_error:
+            inner_it += 1
+            self.velocity_tentative_assemble()
+            diff, errors = self.velocity_tentative_solve()
+            assert (errors > 0).all(), f"tentative velocity solve failed: {errors}"
+            self.pressure_assemble(dt)
+            error_p = self.pressure_solve(nu=nu)
+            assert int(error_p) > 0, f"pressure solve failed: {error_p}"
+        errors_c = self.velocity_update(dt)
+        self._last_errors = (errors, error_p, errors_c)
+        # u2 <- u1, u1 <- u, p <- ps (:689-693)
+        _lib.check(lib.ox_axpby(n, 1.0, self._U1.ptr(), 0.0, None, self._U2.ptr(), st), "ox_axpby")
+        _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._U1.ptr(), st), "ox_axpby")
+        _lib.check(lib.ox_axpby(nq, 1.0, self._PS.ptr(), 0.0, None, self._P.ptr(), st), "ox_axpby")
+        return diff
+
+    @property
+    def u(self):
+        """The velocity as a blocked vector function (reference fracstep.py:698-705); it shares
+        storage with the component functions ``_u[i]``."""
+        return self._sol_u
+
+    def iteration_counts(self):
+        return {"tentative": self._solver_u.iterations, "pressure": self._solver_p.iterations,
+                "update": self._solver_c.iterations}

@@ -1,0 +1,130 @@
+"""``KSPSolver``: the reference's thin PETSc-KSP wrapper (reference src/oasisx/ksp.py:14-91),
+backed by the device-resident Jacobi-CG / Jacobi-BiCGStab of ``liboasisx_hip.so``.
+
+Option mapping (PETSc string keys, as the reference passes them):
+  ksp_type  cg -> CG;  bcgs -> BiCGStab;  gmres/other/unset -> CG if the operator is flagged
+            symmetric else BiCGStab;  preonly (+ pc_type lu/cholesky) -> the same Krylov
+            method run to ``direct_rtol`` (there is no sparse LU on the device; the converged
+            reason reported is KSP_CONVERGED_ITS = 4 as PETSc's preonly does)
+  pc_type   jacobi (also what lu/ilu/none/unset map to: the only preconditioner on the device)
+  ksp_rtol, ksp_atol, ksp_max_it, ksp_initial_guess_nonzero: as in PETSc (defaults 1e-5,
+            1e-50, 10000, false -> the solution vector is zeroed before the solve)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import typing
+
+import torch
+
+from . import _lib
+from .fem import FieldStorage, Function, Vector
+from .la import SellMatrix
+
+__all__ = ["KSPSolver"]
+
+DIRECT_RTOL = 1e-12
+
+
+class KSPSolver:
+    def __init__(self, comm=None, petsc_options: typing.Optional[dict] = None, prefix="oasis_solver"):
+        self._comm = comm
+        self._prefix = prefix
+        self._options: dict = {}
+        self._A: SellMatrix | None = None
+        self._dinv = None
+        self._dinv_version = -1
+        self._work = None
+        self._dist = None
+        self.last_result = None
+        self.check_every = None
+        self.updateOptions({} if petsc_options is None else petsc_options)
+
+    # -- reference surface --------------------------------------------------------------
+    def updateOptions(self, options: dict):
+        """Update options (reference ksp.py:38-53)."""
+        self._options.update({str(k): v for k, v in options.items()})
+
+    def setOptions(self, op):
+        """Reference ksp.py:55-59 gives the operator the solver's options prefix; nothing to
+        do here -- matrix options do not exist on this path."""
+        return None
+
+    def setOperators(self, A: SellMatrix, P: typing.Optional[SellMatrix] = None):
+        self._A = A
+        self._dinv_version = -1
+
+    def set_dist(self, dist):
+        self._dist = dist
+
+    def solve(self, b, x: Function) -> int:
+        """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
+        KSPConvergedReason.  ``b`` is a Vector (``Function.x.petsc_vec``) or a Function."""
+        bvec = b.x if isinstance(b, Function) else b
+        bs, bc = bvec._s, bvec._c
+        xs, xc = x._storage, x._comp
+        if bs.nc == 1 and xs.nc == 1:
+            return int(self.solve_block(bs, xs)[0])
+        # one column of an interleaved block: gather, solve, scatter back
+        n = xs.n
+        tb = FieldStorage(n, 1, xs.dev().device, n_alloc=xs.n_alloc)
+        tx = FieldStorage(n, 1, xs.dev().device, n_alloc=xs.n_alloc)
+        tb.dev()[:, 0].copy_(bs.dev()[:, 0 if bc is None else bc])
+        tx.dev()[:, 0].copy_(xs.dev()[:, xc])
+        reason = self.solve_block(tb, tx)[0]
+        xs.dev()[:, xc].copy_(tx.dev()[:, 0])
+        return int(reason)
+
+    # -- block interface used by FractionalStep_AB_CN -------------------------------------
+    def _method(self):
+        o = self._options
+        kt = str(o.get("ksp_type", "")).lower()
+        direct = kt == "preonly"
+        if kt == "cg":
+            meth = _lib.KSP_CG
+        elif kt in ("bcgs", "bicgstab"):
+            meth = _lib.KSP_BCGS
+        else:
+            meth = _lib.KSP_CG if (self._A is not None and self._A.symmetric) else _lib.KSP_BCGS
+        if direct:
+            return meth, DIRECT_RTOL, 1e-50, 20000, True
+        return (meth, float(o.get("ksp_rtol", 1e-5)), float(o.get("ksp_atol", 1e-50)),
+                int(o.get("ksp_max_it", 10000)), False)
+
+    def solve_block(self, B: FieldStorage, X: FieldStorage):
+        """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
+        Returns the list of per-component converged reasons."""
+        if self._A is None:
+            raise RuntimeError("KSPSolver.solve called before setOperators")
+        lib = _lib.load()
+        A = self._A
+        nc = X.nc
+        meth, rtol, atol, max_it, direct = self._method()
+        guess = bool(self._options.get("ksp_initial_guess_nonzero", False)) and not direct
+        st = _lib.current_stream()
+        dev = X.dev().device
+        if self._dinv is None or self._dinv.shape[0] != A.pattern.n_rows:
+            self._dinv = torch.empty(A.pattern.n_rows, dtype=torch.float64, device=dev)
+            self._dinv_version = -1
+        if self._dinv_version != A.version:
+            _lib.check(lib.ox_jacobi_setup(A.ref(), _lib.ptr(self._dinv), st), "ox_jacobi_setup")
+            self._dinv_version = A.version
+        need = lib.ox_ksp_work_bytes(A.pattern.n_rows, A.pattern.n_cols, nc, meth)
+        if self._work is None or self._work.shape[0] < need:
+            self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        res = _lib.ox_ksp_result()
+        every = self.check_every or (16 if meth == _lib.KSP_CG else 4)
+        _lib.check(lib.ox_ksp_solve(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
+                                    max_it, int(guess), int(every), _lib.ptr(self._work),
+                                    int(self._work.shape[0]), C.byref(res), self._dist, st),
+                   "ox_ksp_solve")
+        self.last_result = res
+        reasons = [int(res.reason[c]) for c in range(nc)]
+        if direct:
+            reasons = [_lib.CONVERGED_ITS if r > 0 else r for r in reasons]
+        return reasons
+
+    @property
+    def iterations(self):
+        r = self.last_result
+        return [] if r is None else [int(v) for v in r.its]

@@ -1,0 +1,48 @@
+"""Device matrices of the IPCS path: a SELL-64 pattern plus a float64 value array."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .fem import SellPattern
+
+
+class SellMatrix:
+    """What stands in for a PETSc ``Mat`` on this path (reference fracstep.py:293-300,324)."""
+
+    def __init__(self, pattern: SellPattern, symmetric: bool = False, name: str = "A"):
+        self.pattern = pattern
+        self.vals = pattern.new_values()
+        self.symmetric = symmetric
+        self.name = name
+        self.version = 0  # bumped whenever the values change (Jacobi setup is cached on it)
+        self._struct = pattern.struct(self.vals)
+
+    @property
+    def struct(self) -> _lib.ox_sell:
+        return self._struct
+
+    def ref(self):
+        return C.byref(self._struct)
+
+    def getSize(self):
+        return (self.pattern.n_rows, self.pattern.n_cols)
+
+    def to_scipy(self):
+        """Host copy as scipy CSR (tests / diagnostics)."""
+        return self.pattern.to_csr(self.vals)
+
+    def mult(self, x: torch.Tensor, y: torch.Tensor, ncomp: int = 1, dist=None):
+        """y = A x on interleaved (n, ncomp) device blocks (PETSc Mat.mult)."""
+        lib = _lib.load()
+        _lib.check(lib.ox_spmv(self.ref(), _lib.ptr(x), _lib.ptr(y), ncomp, dist, _lib.current_stream()),
+                   "ox_spmv")
+
+    def zero_rows(self, rows_dev: torch.Tensor, diag: float = 1.0):
+        """Mat.zeroRowsLocal(rows, diag): keeps the columns (reference fracstep.py:471-472)."""
+        lib = _lib.load()
+        _lib.check(lib.ox_zero_rows(self.ref(), _lib.ptr(rows_dev), int(rows_dev.shape[0]), float(diag),
+                                    _lib.current_stream()), "ox_zero_rows")
+        self.version += 1

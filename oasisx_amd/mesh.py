@@ -1,0 +1,266 @@
+"""Simplicial meshes with the small DOLFINx-shaped surface the oasisx callers touch
+(reference demo/taylor_green.py:126-139, test/test_tentative_velocity.py:90-128,
+bcs.py:99-100,245-250): generators, facet/edge tables, ``meshtags``, entity location.
+
+Mesh arrays live as torch tensors on the setup device (the GPU when there is one) so
+that 128^3 x 6 tetrahedra are generated and indexed there; numpy views are made on
+demand for the host-side callers.
+"""
+from __future__ import annotations
+
+import enum
+import itertools
+
+import numpy as np
+import torch
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+        else torch.device("cpu")
+
+
+class CellType(enum.Enum):
+    triangle = 2
+    tetrahedron = 3
+
+
+class _Comm:
+    """Stand-in for the MPI communicator attribute callers pass around; the data path
+    uses RCCL (see oasisx_amd.parallel), not MPI."""
+
+    def __init__(self, rank=0, size=1):
+        self.rank, self.size = rank, size
+
+    def allreduce(self, v, op=None):
+        return v
+
+    def Barrier(self):
+        pass
+
+
+COMM_WORLD = _Comm()
+
+
+class _UflCell:
+    def __init__(self, name):
+        self.cellname = name
+
+
+class _IndexMap:
+    def __init__(self, n):
+        self.size_local = int(n)
+        self.num_ghosts = 0
+        self.size_global = int(n)
+
+
+class Geometry:
+    def __init__(self, mesh):
+        self._mesh = mesh
+        self.dim = mesh.gdim
+
+    @property
+    def x(self) -> np.ndarray:
+        """(n_vertices, 3) vertex coordinates (zero padded), as in DOLFINx."""
+        m = self._mesh
+        if m._x3 is None:
+            x = np.zeros((m.num_vertices, 3))
+            x[:, : m.gdim] = m.coords.cpu().numpy()
+            m._x3 = x
+        return m._x3
+
+
+class Topology:
+    def __init__(self, mesh):
+        self._mesh = mesh
+        self.dim = mesh.gdim
+
+    def create_connectivity(self, d0, d1):
+        self._mesh._entities(d0)
+        self._mesh._entities(d1)
+
+    def create_entities(self, dim):
+        self._mesh._entities(dim)
+
+    def index_map(self, dim):
+        m = self._mesh
+        if dim == m.gdim:
+            return _IndexMap(m.num_cells)
+        if dim == 0:
+            return _IndexMap(m.num_vertices)
+        return _IndexMap(m._entities(dim)[0].shape[0])
+
+    def cell_name(self):
+        return self._mesh.cellname
+
+    @property
+    def _cpp_object(self):
+        return self
+
+
+class Mesh:
+    """coords: (nv, gdim) float64, cells: (nc, gdim+1) int64 vertex ids."""
+
+    def __init__(self, coords: torch.Tensor, cells: torch.Tensor, comm=COMM_WORLD):
+        self.coords = coords.to(torch.float64).contiguous()
+        self.cells = cells.to(torch.int64).contiguous()
+        self.device = self.coords.device
+        self.gdim = int(coords.shape[1])
+        assert cells.shape[1] == self.gdim + 1, "simplicial cells only"
+        self.num_vertices = int(coords.shape[0])
+        self.num_cells = int(cells.shape[0])
+        self.cellname = "triangle" if self.gdim == 2 else "tetrahedron"
+        self.comm = comm
+        self._x3 = None
+        self._ent = {}
+        self.geometry = Geometry(self)
+        self.topology = Topology(self)
+
+    def ufl_cell(self):
+        return _UflCell(self.cellname)
+
+    # ---- entity tables (host, lazy; not used on the hot path) -------------------------
+    def _entities(self, dim):
+        """(entity_vertices (ne, dim+1) sorted rows, cell_entities (nc, nloc))."""
+        if dim in self._ent:
+            return self._ent[dim]
+        cells = self.cells.cpu().numpy()
+        nvl = self.gdim + 1
+        if dim == self.gdim:
+            res = (np.sort(cells, axis=1), np.arange(self.num_cells)[:, None])
+        elif dim == 0:
+            res = (np.arange(self.num_vertices)[:, None], cells)
+        else:
+            combos = list(itertools.combinations(range(nvl), dim + 1))
+            sub = np.stack([np.sort(cells[:, list(c)], axis=1) for c in combos], axis=1)
+            flat = sub.reshape(-1, dim + 1)
+            key = np.zeros(flat.shape[0], dtype=np.int64)
+            for k in range(dim + 1):
+                key = key * np.int64(self.num_vertices) + flat[:, k]
+            uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+            res = (flat[first], inv.reshape(self.num_cells, len(combos)))
+        self._ent[dim] = res
+        return res
+
+    def exterior_facets(self) -> np.ndarray:
+        _, cf = self._entities(self.gdim - 1)
+        counts = np.bincount(cf.ravel())
+        return np.nonzero(counts == 1)[0].astype(np.int32)
+
+    def h(self, dim, entities) -> np.ndarray:
+        """Largest vertex distance of each cell (dolfinx.mesh.Mesh.h for cells)."""
+        assert dim == self.gdim
+        x = self.coords.cpu().numpy()
+        c = self.cells.cpu().numpy()[np.asarray(entities)]
+        hmax = np.zeros(c.shape[0])
+        for a, b in itertools.combinations(range(self.gdim + 1), 2):
+            hmax = np.maximum(hmax, np.linalg.norm(x[c[:, a]] - x[c[:, b]], axis=1))
+        return hmax
+
+
+# ---- generators (DOLFINx layouts) --------------------------------------------------------
+
+
+def create_rectangle(comm, points, n, cell_type=CellType.triangle, device=None, **kwargs) -> Mesh:
+    """dolfinx.mesh.create_rectangle, triangles, DiagonalType.right: each quad
+    (v0 v1 / v2 v3) is cut into [v0, v1, v3] and [v0, v2, v3]."""
+    assert cell_type == CellType.triangle
+    dev = default_device() if device is None else torch.device(device)
+    nx, ny = int(n[0]), int(n[1])
+    p0, p1 = points
+    xs = torch.linspace(float(p0[0]), float(p1[0]), nx + 1, dtype=torch.float64, device=dev)
+    ys = torch.linspace(float(p0[1]), float(p1[1]), ny + 1, dtype=torch.float64, device=dev)
+    Y, X = torch.meshgrid(ys, xs, indexing="ij")
+    coords = torch.stack([X.reshape(-1), Y.reshape(-1)], dim=1)
+    iy, ix = torch.meshgrid(torch.arange(ny, device=dev), torch.arange(nx, device=dev), indexing="ij")
+    v0 = (iy * (nx + 1) + ix).reshape(-1)
+    v1, v2, v3 = v0 + 1, v0 + nx + 1, v0 + nx + 2
+    cells = torch.stack([torch.stack([v0, v1, v3], 1), torch.stack([v0, v2, v3], 1)], dim=1)
+    return Mesh(coords, cells.reshape(-1, 3), comm if comm is not None else COMM_WORLD)
+
+
+def create_unit_square(comm, nx, ny, cell_type=CellType.triangle, device=None, **kwargs) -> Mesh:
+    return create_rectangle(comm, [[0.0, 0.0], [1.0, 1.0]], [nx, ny], cell_type, device=device)
+
+
+def create_box(comm, points, n, cell_type=CellType.tetrahedron, device=None, **kwargs) -> Mesh:
+    """dolfinx.mesh.create_box, tetrahedra: every hexahedron is cut into the 6 tetrahedra
+    that share its main diagonal v0-v7."""
+    assert cell_type == CellType.tetrahedron
+    dev = default_device() if device is None else torch.device(device)
+    nx, ny, nz = (int(v) for v in n)
+    p0, p1 = points
+    ax = [torch.linspace(float(p0[k]), float(p1[k]), m + 1, dtype=torch.float64, device=dev)
+          for k, m in enumerate((nx, ny, nz))]
+    Z, Y, X = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    coords = torch.stack([X.reshape(-1), Y.reshape(-1), Z.reshape(-1)], dim=1)
+    iz, iy, ix = torch.meshgrid(torch.arange(nz, device=dev), torch.arange(ny, device=dev),
+                                torch.arange(nx, device=dev), indexing="ij")
+    sy, sz = nx + 1, (nx + 1) * (ny + 1)
+    v0 = (iz * sz + iy * sy + ix).reshape(-1)
+    v1, v2, v3 = v0 + 1, v0 + sy, v0 + 1 + sy
+    v4, v5, v6, v7 = v0 + sz, v0 + sz + 1, v0 + sz + sy, v0 + sz + sy + 1
+    tets = [(v0, v1, v3, v7), (v0, v1, v7, v5), (v0, v5, v7, v4),
+            (v0, v3, v2, v7), (v0, v6, v4, v7), (v0, v2, v6, v7)]
+    cells = torch.stack([torch.stack(t, 1) for t in tets], dim=1)
+    return Mesh(coords, cells.reshape(-1, 4), comm if comm is not None else COMM_WORLD)
+
+
+def create_unit_cube(comm, nx, ny, nz, cell_type=CellType.tetrahedron, device=None, **kwargs) -> Mesh:
+    return create_box(comm, [[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]], [nx, ny, nz], cell_type, device=device)
+
+
+# ---- entity location and tags ------------------------------------------------------------
+
+
+def exterior_facet_indices(topology) -> np.ndarray:
+    return topology._mesh.exterior_facets()
+
+
+def _marked_entities(mesh: Mesh, dim: int, marker, candidates=None) -> np.ndarray:
+    ev, _ = mesh._entities(dim)
+    x = mesh.geometry.x.T  # (3, nv)
+    on = np.asarray(marker(x), dtype=bool)
+    hit = on[ev].all(axis=1)
+    if candidates is not None:
+        mask = np.zeros(ev.shape[0], dtype=bool)
+        mask[candidates] = True
+        hit &= mask
+    return np.nonzero(hit)[0].astype(np.int32)
+
+
+def locate_entities(mesh: Mesh, dim: int, marker) -> np.ndarray:
+    """Entities all of whose vertices satisfy ``marker(x)``, x of shape (3, nverts)."""
+    return _marked_entities(mesh, dim, marker)
+
+
+def locate_entities_boundary(mesh: Mesh, dim: int, marker) -> np.ndarray:
+    ext = mesh.exterior_facets()
+    if dim == mesh.gdim - 1:
+        return _marked_entities(mesh, dim, marker, candidates=ext)
+    # sub-entities of exterior facets
+    fv, _ = mesh._entities(mesh.gdim - 1)
+    ev, _ = mesh._entities(dim)
+    bverts = np.zeros(mesh.num_vertices, dtype=bool)
+    bverts[fv[ext].ravel()] = True
+    cand = np.nonzero(bverts[ev].all(axis=1))[0]
+    return _marked_entities(mesh, dim, marker, candidates=cand)
+
+
+class MeshTags:
+    def __init__(self, mesh, dim, indices, values):
+        self.mesh = mesh
+        self.dim = int(dim)
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.values = np.asarray(values)
+        self.topology = mesh.topology
+
+    def find(self, value) -> np.ndarray:
+        return self.indices[self.values == value]
+
+
+def meshtags(mesh: Mesh, dim: int, entities, values) -> MeshTags:
+    entities = np.asarray(entities)
+    if entities.size > 1 and not (np.diff(entities) > 0).all():
+        raise RuntimeError("meshtags: entities must be sorted and unique")
+    return MeshTags(mesh, dim, entities, values)
