@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- time-steps/sec and pressure-CG SpMV GB/s of the IPCS hot path on MI355X.
+
+Workload (BASELINE.json configs[2]): 3-D Taylor-Green on [-1,1]^3, N^3 x 6 tetrahedra
+(N = 128 by default), P2-P1 Taylor-Hood, z-extruded analytic Taylor-Green field with exact
+Dirichlet data on every face, nu = 0.01, dt = 0.005*32/N, max_iter = 1, BiCGStab+Jacobi
+tentative velocity, CG+Jacobi pressure and velocity update, rtol 1e-8 / atol 1e-14.
+A "step" is one FractionalStep_AB_CN.solve().  Synthetic data, float64 throughout.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def spmv_bytes(nnz, n_rows, n_cols):
+    """Algorithmic bytes of one CSR SpMV, f64 values + int32 columns."""
+    return 12 * nnz + 4 * (n_rows + 1) + 8 * n_cols + 8 * n_rows
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("-N", type=int, default=128, help="cubes per direction")
+    ap.add_argument("--udeg", type=int, default=2)
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import oasisx_amd as ox
+    from oasisx_amd import _lib
+    from oasisx_amd import mesh as M
+
+    lib = _lib.load()
+    N, nu = args.N, 0.01
+    dt = 0.005 * 32.0 / N
+    clock = {"t": 0.0}
+
+    def log(*a):
+        if args.verbose and rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    def tg_u(x, t):
+        return -np.cos(np.pi * x[0]) * np.sin(np.pi * x[1]) * np.exp(-2.0 * nu * np.pi ** 2 * t)
+
+    def tg_v(x, t):
+        return np.cos(np.pi * x[1]) * np.sin(np.pi * x[0]) * np.exp(-2.0 * nu * np.pi ** 2 * t)
+
+    def tg_w(x, t):
+        return np.zeros_like(x[0])
+
+    def tg_p(x, t):
+        return -0.25 * (np.cos(2 * np.pi * x[0]) + np.cos(2 * np.pi * x[1])) * np.exp(-4.0 * nu * np.pi ** 2 * t)
+
+    def on_boundary(x):
+        return (np.isclose(np.abs(x[0]), 1.0) | np.isclose(np.abs(x[1]), 1.0) | np.isclose(np.abs(x[2]), 1.0))
+
+    t_setup = time.perf_counter()
+    mesh = M.create_box(None, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N])
+    fns = [tg_u, tg_v, tg_w]
+    bcs_u = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"]), ox.LocatorMethod.GEOMETRICAL, on_boundary)]
+             for f in fns]
+    ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000}
+    solver_options = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"),
+                      "scalar": dict(ksp, ksp_type="cg")}
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", args.udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
+                                solver_options=solver_options)
+    for i, f in enumerate(fns):
+        S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
+        S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
+    S._p.interpolate(lambda x: tg_p(x, -dt / 2.0))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    log(f"setup {t_setup:.1f} s; n_u={S._n_u} n_p={S._n_q} nnz_u={S._M.pattern.nnz} nnz_p={S._Ap.pattern.nnz}; "
+        f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+    def step():
+        clock["t"] += dt
+        return S.solve(dt, nu, max_iter=1)
+
+    for _ in range(args.warmup):
+        step()
+        log("warmup step", S.iteration_counts())
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    _lib.check(lib.ox_profile_begin(200000), "ox_profile_begin")
+    t0 = time.perf_counter()
+    its = []
+    for _ in range(args.steps):
+        step()
+        its.append(S.iteration_counts())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.ox_profile_end(), "ox_profile_end")
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    def prof(tag):
+        cnt, ms = C.c_longlong(0), C.c_double(0.0)
+        _lib.check(lib.ox_profile_get(tag, C.byref(cnt), C.byref(ms)), "ox_profile_get")
+        return int(cnt.value), float(ms.value)
+
+    gd = mesh.gdim
+    Pp, Pu = S._Ap.pattern, S._M.pattern
+    b_p = spmv_bytes(Pp.nnz, Pp.n_rows, Pp.n_cols)
+    # velocity SpMM on gd interleaved vectors: matrix read once, gd x/y vectors
+    b_u = 12 * Pu.nnz + 4 * (Pu.n_rows + 1) + gd * 8 * (Pu.n_cols + Pu.n_rows)
+    kernels = {}
+    for name, tag, nbytes in (("pressure_cg_spmv", 11, b_p), ("velocity_bcgs_spmv_v", 10 * gd + 2, b_u),
+                              ("velocity_bcgs_spmv_t", 10 * gd + 3, b_u), ("mass_cg_spmv", 10 * gd + 1, b_u),
+                              ("mass_spmv", 10 * gd + 0, b_u), ("assemble_first", 100, None),
+                              ("grad_vector_p", 110, None), ("grad_vector_dp", 111, None),
+                              ("div_vector", 120, None)):
+        cnt, ms = prof(tag)
+        if cnt:
+            k = {"launches": cnt, "avg_us": 1e3 * ms / cnt, "total_ms": ms}
+            if nbytes:
+                k["algorithmic_bytes"] = nbytes
+                k["gbs"] = nbytes / (1e6 * ms / cnt)
+            kernels[name] = k
+    cg = kernels.get("pressure_cg_spmv")
+    roofline = None
+    if cg:
+        roofline = {"kernel": "k_spmv<1,OX_EPI_DOT> (pressure-Poisson CG SpMV, SELL-64, f64)", "bound": "hbm",
+                    "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": cg["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": b_p, "avg_launch_us": cg["avg_us"],
+                    "launches": cg["launches"]}
+
+    if rank == 0:
+        mean_its = {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
+        out = {
+            "metric": "time-steps/sec, 3D Taylor-Green %d^3 P2-P1 (with pressure-CG SpMV GB/s in roofline)" % N
+            if args.udeg == 2 else "time-steps/sec, 3D Taylor-Green %d^3 P%d-P1" % (N, args.udeg),
+            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D Taylor-Green {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
+                                   f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g}, max_iter=1",
+                       "cells": mesh.num_cells, "n_u_per_component": S._n_u, "n_p": S._n_q,
+                       "nnz_velocity": Pu.nnz, "nnz_pressure": Pp.nnz, "parallelism": f"mesh-partition x{world}"},
+            "roofline": roofline,
+            "krylov_iterations_per_step": mean_its,
+            "kernels": kernels,
+            "setup_s": t_setup,
+            "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }
+        if not args.no_cpu:
+            try:
+                from oracle.cpu_baseline import run_cpu_baseline
+
+                out["cpu_baseline"] = run_cpu_baseline(N, args.udeg, nu, dt, args.rtol, args.cpu_seconds)
+            except Exception as e:  # the baseline is a reported figure, never the product path
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

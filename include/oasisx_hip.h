@@ -185,6 +185,13 @@ int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const doubl
 int ox_remove_mean(int64_t n, double *x, const double *w, double wsum, const ox_dist *dist,
                    void *stream);
 
+/* ---- measurement: per-kernel HIP-event timing on the launching stream (bench.py) ------- */
+/* tags: 10*ncomp+epi for SpMV (epi 0 plain, 1 CG p.q, 2/3 BiCGStab), 100 assemble_first,
+ * 110/111 grad vectors, 120 div vector. */
+int ox_profile_begin(int max_records);
+int ox_profile_end(void);
+int ox_profile_get(int tag, long long *count, double *total_ms);
+
 /* ---- H1 + collectives: mesh-partitioned runs (one process per GPU, RCCL) -------------- */
 int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 */
 /* send_idx: device, owned rows to pack; per-peer counts; ghosts arrive contiguously per peer

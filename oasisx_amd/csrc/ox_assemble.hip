@@ -307,8 +307,11 @@ extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_
     OX_FAIL("ox_assemble_first: null argument");
   if (!(dt > 0.0)) OX_FAIL("ox_assemble_first: dt=%g", dt);
   FirstArgs F{Mvals, Kvals, uab, u1, b0, b_first, 1.0 / dt, nu};
-  return launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
-                                   bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
+  if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
+  const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
+                                           bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
+  if (ox_prof_on) ox_prof_stop(ox_stream(stream));
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -429,8 +432,10 @@ extern "C" int ox_assemble_grad_vector(int kind, int row_degree, int p_degree, c
   const int g = cells->gdim;
 #define OX_GV_CASE(GD, RD, PD, KD)                                                             \
   if (g == GD && row_degree == RD && p_degree == PD && kind == KD) {                           \
+    if (ox_prof_on) ox_prof_start(OX_TAG_GRAD_VECTOR + KD, st);                                \
     hipLaunchKernelGGL((k_grad_vector<GD, RD, PD, KD>), dim3(nblk), dim3(256), 0, st, *cells,  \
                        cell_pdofs, *adj, n_rows, p, base, scale, out);                         \
+    if (ox_prof_on) ox_prof_stop(st);                                                          \
     OX_LAUNCH_CHECK();                                                                         \
     return 0;                                                                                  \
   }
@@ -499,8 +504,10 @@ extern "C" int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cel
   const int g = cells->gdim;
 #define OX_DV_CASE(GD, RD, UD)                                                                     \
   if (g == GD && row_degree == RD && u_degree == UD) {                                             \
+    if (ox_prof_on) ox_prof_start(OX_TAG_DIV_VECTOR, st);                                          \
     hipLaunchKernelGGL((k_div_vector<GD, RD, UD>), dim3(nblk), dim3(256), 0, st, *cells, cell_udofs, \
                        *adj, n_rows, u, scale, out);                                               \
+    if (ox_prof_on) ox_prof_stop(st);                                                              \
     OX_LAUNCH_CHECK();                                                                             \
     return 0;                                                                                      \
   }

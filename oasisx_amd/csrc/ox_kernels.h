@@ -21,3 +21,14 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
                    const double *dinv, const double *aux, double *partial, const int *done,
                    hipStream_t st);
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st);
+
+// ---- optional per-kernel HIP-event timing (bench.py: roofline.achieved is measured live, on the
+// stream the kernel runs on) --------------------------------------------------------------------
+#define OX_TAG_SPMV(nc, epi) (10 * (nc) + (epi))
+#define OX_TAG_ASSEMBLE_FIRST 100
+#define OX_TAG_GRAD_VECTOR 110
+#define OX_TAG_DIV_VECTOR 120
+#define OX_TAG_ASSEMBLE_MATRIX 130
+extern bool ox_prof_on;
+void ox_prof_start(int tag, hipStream_t st);
+void ox_prof_stop(hipStream_t st);

@@ -105,8 +105,10 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   if (nblk == 0) return 0;
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
+    if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st);                                      \
     hipLaunchKernelGGL((k_spmv<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, \
                        done);                                                                   \
+    if (ox_prof_on) ox_prof_stop(st);                                                           \
     OX_LAUNCH_CHECK();                                                                          \
     return 0;                                                                                   \
   }
@@ -390,5 +392,68 @@ extern "C" int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream) {
   if (nblk == 0) return 0;
   hipLaunchKernelGGL(k_jacobi, dim3(nblk), dim3(256), 0, ox_stream(stream), *A, dinv);
   OX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-kernel timing with HIP events (enabled by bench.py around its timed region).
+// ---------------------------------------------------------------------------------------
+#include <vector>
+bool ox_prof_on = false;
+namespace {
+struct ProfRec { int tag; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+bool g_prof_open = false;
+constexpr int OX_PROF_NTAG = 256;
+double g_prof_ms[OX_PROF_NTAG];
+long long g_prof_cnt[OX_PROF_NTAG];
+}  // namespace
+
+void ox_prof_start(int tag, hipStream_t st) {
+  g_prof_open = false;
+  if (g_prof_used >= g_prof.size()) return;
+  ProfRec &r = g_prof[g_prof_used];
+  r.tag = tag;
+  if (hipEventRecord(r.a, st) == hipSuccess) g_prof_open = true;
+}
+void ox_prof_stop(hipStream_t st) {
+  if (!g_prof_open) return;
+  (void)hipEventRecord(g_prof[g_prof_used].b, st);
+  ++g_prof_used;
+  g_prof_open = false;
+}
+
+extern "C" int ox_profile_begin(int max_records) {
+  if (max_records < 1) max_records = 1;
+  while ((int)g_prof.size() < max_records) {
+    ProfRec r{};
+    OX_HIP(hipEventCreate(&r.a));
+    OX_HIP(hipEventCreate(&r.b));
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  for (int i = 0; i < OX_PROF_NTAG; ++i) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
+  ox_prof_on = true;
+  return 0;
+}
+
+extern "C" int ox_profile_end(void) {
+  ox_prof_on = false;
+  OX_HIP(hipDeviceSynchronize());
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) == hipSuccess) {
+      const int t = g_prof[i].tag;
+      if (t >= 0 && t < OX_PROF_NTAG) { g_prof_ms[t] += ms; g_prof_cnt[t] += 1; }
+    }
+  }
+  return 0;
+}
+
+extern "C" int ox_profile_get(int tag, long long *count, double *total_ms) {
+  if (tag < 0 || tag >= OX_PROF_NTAG) OX_FAIL("ox_profile_get: tag=%d", tag);
+  if (count) *count = g_prof_cnt[tag];
+  if (total_ms) *total_ms = g_prof_ms[tag];
   return 0;
 }
