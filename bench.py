@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("-N", type=int, default=128, help="cubes per direction")
     ap.add_argument("--udeg", type=int, default=2)
     ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--zero-guess", action="store_true",
+                    help="PETSc default: zero the solution before every Krylov solve "
+                         "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--verbose", action="store_true")
@@ -94,7 +97,8 @@ def main():
     fns = [tg_u, tg_v, tg_w]
     bcs_u = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"]), ox.LocatorMethod.GEOMETRICAL, on_boundary)]
              for f in fns]
-    ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000}
+    ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
+           "ksp_initial_guess_nonzero": not args.zero_guess}
     solver_options = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"),
                       "scalar": dict(ksp, ksp_type="cg")}
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", args.udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
@@ -181,7 +185,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Taylor-Green {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
-                                   f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g}, max_iter=1",
+                                   f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
+                                   f"initial_guess_nonzero={not args.zero_guess}, max_iter=1",
                        "cells": mesh.num_cells, "n_u_per_component": S._n_u, "n_p": S._n_q,
                        "nnz_velocity": Pu.nnz, "nnz_pressure": Pp.nnz, "parallelism": f"mesh-partition x{world}"},
             "roofline": roofline,

@@ -10,11 +10,70 @@
 
 #define OX_VEC_MAX_BLOCKS 2048  // grid cap of the BLAS-1 kernels (256 CUs x 8 blocks)
 
-static inline int ox_spmv_blocks(const ox_sell *A) { return (A->n_slices + 3) / 4; }
+#define OX_SPMV_MAX_BLOCKS (1 << 22)  // one slice group per block (a cap of 2048 = persistent grid
+                                      // measured 10 % slower: r01 notes in DESIGN.md)
+#define OX_MAX_NV 9             // most sums reduced at one synchronisation point (3 * OX_MAXC)
+
+static inline int ox_spmv_blocks(const ox_sell *A) {
+  const int ngroups = (A->n_slices + 3) / 4;
+  if (ngroups == 0) return 0;
+  const int g8 = (ngroups + 7) & ~7;
+  return g8 > OX_SPMV_MAX_BLOCKS ? OX_SPMV_MAX_BLOCKS : g8;
+}
+
 static inline int ox_vec_blocks(int64_t n) {
   int64_t b = (n / 2 + 255) / 256;
   if (b < 1) b = 1;
   return (int)(b > OX_VEC_MAX_BLOCKS ? OX_VEC_MAX_BLOCKS : b);
+}
+
+#define OX_RED_THREADS 1024  // final reductions: one wide block, independent loads in flight
+
+// Per-thread slice of the ordered final reduction: v[i] = sum over this thread's partials
+// (4 partial rows in flight per thread).
+__device__ __forceinline__ void ox_gather_partials(const double *__restrict__ partial, int nparts,
+                                                   int nv, double (&v)[OX_MAX_NV]) {
+#pragma unroll
+  for (int i = 0; i < OX_MAX_NV; ++i) v[i] = 0.0;
+  int p = threadIdx.x;
+  for (; p + 3 * OX_RED_THREADS < nparts; p += 4 * OX_RED_THREADS) {
+    double t[4][OX_MAX_NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < OX_MAX_NV; ++i)
+        t[u][i] = (i < nv) ? partial[(size_t)(p + u * OX_RED_THREADS) * nv + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < OX_MAX_NV; ++i) v[i] += t[u][i];
+  }
+  for (; p < nparts; p += OX_RED_THREADS) {
+#pragma unroll
+    for (int i = 0; i < OX_MAX_NV; ++i)
+      if (i < nv) v[i] += partial[(size_t)p * nv + i];
+  }
+}
+
+// Sum NV per-thread values over a OX_RED_THREADS-thread block; result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void ox_block_sum_wide(double (&v)[NV], double *lds /* [16*NV] */) {
+  constexpr int NW = OX_RED_THREADS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = ox_wave_sum(v[i]);
+    if (lane == 0) lds[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double s = 0.0;
+      for (int w = 0; w < NW; ++w) s += lds[w * NV + i];
+      v[i] = s;
+    }
+  }
 }
 
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,

@@ -141,21 +141,16 @@ __device__ __forceinline__ void ksp_finish(KspState *S, int nc) {
 
 // Fused: reduce per-block partials (fixed order) + scalar logic.  One 256-thread block.
 template <int PH>
-__global__ __launch_bounds__(256) void k_ksp_scalar(KspState *S, const double *__restrict__ partial,
-                                                    int nparts, int nv, KspParams P) {
-  __shared__ double red[4];
-  __shared__ double sums[4 * OX_MAXC];
+__global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
+                                                               const double *__restrict__ partial,
+                                                               int nparts, int nv, KspParams P) {
+  __shared__ double red[(OX_RED_THREADS / 64) * OX_MAX_NV];
   if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
-  for (int i = 0; i < nv; ++i) {
-    double s = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * nv + i];
-    double v[1] = {s};
-    ox_block_sum_256<1>(v, red);
-    if (threadIdx.x == 0) sums[i] = v[0];
-    __syncthreads();
-  }
+  double v[OX_MAX_NV];
+  ox_gather_partials(partial, nparts, nv, v);
+  ox_block_sum_wide<OX_MAX_NV>(v, red);
   if (threadIdx.x == 0) {
-    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, sums, c, P);
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, v, c, P);
     ksp_finish(S, P.nc);
   }
 }
@@ -383,7 +378,8 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   KspLayout L;
   const int n_slices = (int)((n_rows + 63) / 64);
   const int nblk_spmv = (n_slices + 3) / 4;
-  L.nparts_max = nblk_spmv > OX_VEC_MAX_BLOCKS ? nblk_spmv : OX_VEC_MAX_BLOCKS;
+  const int nb8 = (nblk_spmv + 7) & ~7;
+  L.nparts_max = nb8 > OX_VEC_MAX_BLOCKS ? nb8 : OX_VEC_MAX_BLOCKS;
   L.nvec = ksp_type == OX_KSP_CG ? 4 : 6;
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
@@ -404,7 +400,7 @@ template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
                           const KspParams &P, const ox_dist *dist, hipStream_t st) {
   if (!dist) {
-    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(256), 0, st, S, partial, nparts, nv, P);
+    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(OX_RED_THREADS), 0, st, S, partial, nparts, nv, P);
     OX_LAUNCH_CHECK();
     return 0;
   }

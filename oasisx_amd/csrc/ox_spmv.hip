@@ -38,15 +38,26 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
   __shared__ double red[4 * NV];
   if (done_flag && *done_flag) return;
-  const int nblk = gridDim.x;
-  const int b = ox_xcd_remap(blockIdx.x, nblk);
+  // Persistent grid (<= OX_SPMV_MAX_BLOCKS blocks, a multiple of 8): the blocks that share an XCD
+  // (equal blockIdx % 8) stride together over ONE contiguous eighth of the slice groups, so
+  // at any time an XCD's L2 serves a compact window of rows and of x.
+  const int ngroups = (A.n_slices + 3) >> 2;
+  const int per = gridDim.x >> 3;
+  const int chunk = (ngroups + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int g_begin = xcd * chunk;
+  const int g_end = min(ngroups, g_begin + chunk);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slice = b * 4 + wave;
-  const int64_t row = (int64_t)slice * 64 + lane;
-  double acc[NC];
+  double s[NV];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-  if (slice < A.n_slices) {
+  for (int i = 0; i < NV; ++i) s[i] = 0.0;
+  for (int g = g_begin + (blockIdx.x >> 3); g < g_end; g += per) {
+    const int slice = g * 4 + wave;
+    if (slice >= A.n_slices) continue;
+    const int64_t row = (int64_t)slice * 64 + lane;
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
     const int64_t base = A.slice_ptr[slice];
     const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);  // width / OX_KV
     const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
@@ -62,36 +73,28 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
     }
-  }
-  const bool live = slice < A.n_slices && row < A.n_rows;
-  if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
-    if (live) {
+    if (row < A.n_rows) {
+      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
+        const double d = dinv[row];  // one matrix, one diagonal
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] *= dinv[row];  // one matrix, one diagonal
-    }
-  }
-  if (live) {
+        for (int c = 0; c < NC; ++c) acc[c] *= d;
+      }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) y[row * NC + c] = acc[c];
-  }
-  if (EPI != OX_EPI_NONE) {
-    double s[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) s[i] = 0.0;
-    if (live) {
+      for (int c = 0; c < NC; ++c) y[row * NC + c] = acc[c];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (EPI == OX_EPI_DOT) s[c] = x[row * NC + c] * acc[c];
-        if (EPI == OX_EPI_BCGS_V) s[c] = aux[row * NC + c] * acc[c];
+        if (EPI == OX_EPI_DOT) s[c] = fma(x[row * NC + c], acc[c], s[c]);
+        if (EPI == OX_EPI_BCGS_V) s[c] = fma(aux[row * NC + c], acc[c], s[c]);
         if (EPI == OX_EPI_BCGS_T) {
-          s[c] = acc[c] * acc[c];
-          s[NC + c] = acc[c] * x[row * NC + c];
+          s[c] = fma(acc[c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], x[row * NC + c], s[NC + c]);
         }
       }
     }
+  }
+  if (EPI != OX_EPI_NONE) {
     ox_block_sum_256<NV>(s, red);
     if (threadIdx.x == 0) {
-      // partial slot = ORIGINAL block index: the order of the final sum is fixed
 #pragma unroll
       for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
     }
@@ -139,22 +142,18 @@ extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
 // Deterministic final reduction of per-block partials: sums[i] = sum_p partial[p*nv+i],
 // always in the same order (no float atomics anywhere on the path).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial,
-                                                         int nparts, int nv,
-                                                         double *__restrict__ sums) {
-  __shared__ double red[4];
-  for (int i = 0; i < nv; ++i) {
-    double s = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * nv + i];
-    double v[1] = {s};
-    ox_block_sum_256<1>(v, red);
-    if (threadIdx.x == 0) sums[i] = v[0];
-    __syncthreads();
-  }
+__global__ __launch_bounds__(OX_RED_THREADS) void k_reduce_partials(
+    const double *__restrict__ partial, int nparts, int nv, double *__restrict__ sums) {
+  __shared__ double red[(OX_RED_THREADS / 64) * OX_MAX_NV];
+  double v[OX_MAX_NV];
+  ox_gather_partials(partial, nparts, nv, v);
+  ox_block_sum_wide<OX_MAX_NV>(v, red);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nv; ++i) sums[i] = v[i];
 }
 
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, nparts, nv, sums);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(OX_RED_THREADS), 0, st, partial, nparts, nv, sums);
   OX_LAUNCH_CHECK();
   return 0;
 }
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(256) void k_jacobi(ox_sell A, double *dinv) {
 
 extern "C" int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream) {
   if (!A || !dinv) OX_FAIL("ox_jacobi_setup: null argument");
-  const int nblk = ox_spmv_blocks(A);
+  const int nblk = (A->n_slices + 3) / 4;  // one slice group per block (not the persistent grid)
   if (nblk == 0) return 0;
   hipLaunchKernelGGL(k_jacobi, dim3(nblk), dim3(256), 0, ox_stream(stream), *A, dinv);
   OX_LAUNCH_CHECK();
