@@ -48,8 +48,21 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may actually use (affinity mask, capped by the cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     args = parse()
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))  # cpu_baseline leg (oracle/ipcs_cpu.c)
     import numpy as np
     import torch
 
@@ -199,7 +212,11 @@ def main():
             try:
                 from oracle.cpu_baseline import run_cpu_baseline
 
-                out["cpu_baseline"] = run_cpu_baseline(N, args.udeg, nu, dt, args.rtol, args.cpu_seconds)
+                bc0 = S._bcs_u[0][0]
+                ksp_cpu = {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess}
+                out["cpu_baseline"] = run_cpu_baseline(
+                    S, clock, dt, nu, ksp_cpu, lambda t: np.stack([f(bc0._xbc, t) for f in fns]), gpu_step=step)
+                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -1,0 +1,182 @@
+"""CPU: host logic of the product (mesh, spaces, SELL layout, BC location) and the C ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oasisx_amd import fem
+from oasisx_amd import mesh as M
+from oracle import ipcs_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every function include/oasisx_hip.h declares
+    (no compute calls: there is no GPU here)."""
+    from oasisx_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "oasisx_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ox_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.load()
+    assert L.ox_version() >= 100 and L.ox_sell_kv() == fem.KV
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: a compute call on a machine without a GPU raises, it does not emulate."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from oasisx_amd import _lib
+    from oasisx_amd.la import SellMatrix
+
+    m = M.create_unit_square(None, 3, 3, device="cpu")
+    V = fem.FunctionSpace(m, 1, window=64)
+    A = SellMatrix(V.pattern)
+    x = torch.zeros(V.num_dofs, dtype=torch.float64)
+    with pytest.raises(_lib.OasisxHipError):
+        A.mult(x, x.clone(), 1)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_mesh_generators_match_oracle_layout(dim):
+    if dim == 2:
+        m = M.create_rectangle(None, [[-1, -1], [1, 1]], [5, 4], device="cpu")
+        c, cl = O.create_rectangle_mesh([-1, -1], [1, 1], [5, 4])
+    else:
+        m = M.create_box(None, [[-1, -1, -1], [1, 1, 1]], [3, 4, 2], device="cpu")
+        c, cl = O.create_box_mesh([-1, -1, -1], [1, 1, 1], [3, 4, 2])
+    assert np.abs(m.coords.numpy() - c).max() < 1e-15
+    assert (m.cells.numpy() == cl).all()
+    assert m.geometry.x.shape == (c.shape[0], 3)
+
+
+@pytest.mark.parametrize("dim,N,deg", [(2, 7, 1), (2, 6, 2), (3, 4, 1), (3, 3, 2)])
+def test_function_space_layout(dim, N, deg):
+    m = (M.create_rectangle(None, [[-1, -1], [1, 1]], [N, N], device="cpu") if dim == 2
+         else M.create_box(None, [[-1, -1, -1], [1, 1, 1]], [N, N, N], device="cpu"))
+    V = fem.FunctionSpace(m, deg, window=128)
+    P = V.pattern
+    n = V.num_dofs
+    # the numbering is a permutation and cell_dofs is consistent with the dof coordinates
+    assert sorted(V._rank_initial.tolist()) == list(range(n))
+    x = V.x.numpy()
+    cd = V.cell_dofs.numpy()
+    vx = m.coords.numpy()[m.cells.numpy()]
+    assert np.abs(x[cd[:, : dim + 1]] - vx).max() < 1e-15
+    if deg == 2:
+        for e, (a, b) in enumerate(fem.local_edges(dim)):
+            assert np.abs(x[cd[:, dim + 1 + e]] - 0.5 * (vx[:, a] + vx[:, b])).max() < 1e-15
+    # the pattern equals the oracle's on the same numbering
+    F = O.Forms(m.coords.numpy(), m.cells.numpy(), deg, 1, vd=cd, qd=m.cells.numpy(), nv_dofs=n,
+                nq_dofs=m.num_vertices)
+    Mo = F.mass_v()
+    assert P.nnz == Mo.nnz
+    vals = P.values_from_csr(Mo)
+    assert abs(P.to_csr(vals) - Mo).max() == 0.0
+    # rows are sorted by decreasing length inside each window; slice widths cover their rows
+    rl = P.row_len.numpy()
+    for w0 in range(0, n, 128):
+        seg = rl[w0:w0 + 128]
+        assert (np.diff(seg) <= 0).all()
+    for s in range(P.n_slices):
+        assert P.widths[s] >= rl[s * 64:(s + 1) * 64].max() and P.widths[s] % fem.KV == 0
+    # padding slots point at the row itself (value 0 keeps SpMV exact)
+    rows, k = P.slot_rows_k()
+    pad = (rows < n) & (k >= np.concatenate([rl, np.zeros(P.n_slices * 64 - n, int)])[rows])
+    assert (P.cols.numpy()[pad] == rows[pad]).all()
+    # adjacency: every (dof, cell) pair once, positions point at the right columns
+    A = V.adj
+    cell = A.adj_cell.numpy()
+    assert (cell >= 0).sum() == cd.size
+    ap = A.adj_ptr.numpy()
+    sp_ = P.slice_ptr.numpy()
+    cols = P.cols.numpy()
+    pos = A.adj_pos.numpy()
+    loc = A.adj_loc.numpy()
+    pidx = np.nonzero(cell >= 0)[0]
+    s = np.searchsorted(ap, pidx, side="right") - 1
+    lane = (pidx - ap[s]) % 64
+    r = s * 64 + lane
+    assert (cd[cell[pidx], loc[pidx]] == r).all()
+    for j in range(V.nd):
+        kk = pos[pidx, j].astype(np.int64)
+        off = sp_[s] + (kk // 2) * 128 + lane * 2 + kk % 2
+        assert (cols[off] == cd[cell[pidx], j]).all()
+
+
+def test_locate_dofs_and_meshtags():
+    m = M.create_rectangle(None, [[-1, -1], [1, 1]], [6, 6], device="cpu")
+    V = fem.FunctionSpace(m, 2, window=64)
+    dim = m.topology.dim - 1
+    m.topology.create_connectivity(dim, dim + 1)
+    facets = M.exterior_facet_indices(m.topology)
+    assert facets.shape[0] == 4 * 6
+    tags = M.meshtags(m, dim, np.sort(facets), np.full(facets.shape, 3, dtype=np.int32))
+    assert (tags.find(3) == np.sort(facets)).all() and tags.dim == dim
+    topo = fem.locate_dofs_topological(V, dim, tags.find(3))
+    geo = fem.locate_dofs_geometrical(V, lambda x: np.isclose(np.abs(x[0]), 1) | np.isclose(np.abs(x[1]), 1))
+    assert (np.sort(topo) == np.sort(geo)).all() and topo.shape[0] == 4 * 12
+    left = M.locate_entities_boundary(m, dim, lambda x: np.isclose(x[0], -1))
+    assert left.shape[0] == 6
+    with pytest.raises(RuntimeError):
+        M.meshtags(m, dim, facets[::-1].copy(), np.zeros(facets.shape, dtype=np.int32))
+    # 3-D: boundary faces of a box
+    b = M.create_box(None, [[0, 0, 0], [1, 1, 1]], [2, 2, 2], device="cpu")
+    assert M.exterior_facet_indices(b.topology).shape[0] == 6 * 2 * 2 * 2
+
+
+def test_dirichlet_bc_host_side():
+    """reference test/test_bcs.py restated for the parts that do not need the device: the dofs and
+    values a DirichletBC will impose (geometrical / topological, float / Constant / callable)."""
+    from oasisx_amd import DirichletBC, LocatorMethod
+
+    m = M.create_unit_square(None, 5, 5, device="cpu")
+    for P in (1, 2):
+        V = fem.FunctionSpace(m, P, window=64)
+        X = V.tabulate_dof_coordinates()
+        clock = {"t": 0.1}
+        f = lambda x: x[0] + 2 * x[1] ** 2 + clock["t"]  # noqa: E731
+        bc = DirichletBC(f, LocatorMethod.GEOMETRICAL, lambda x: np.isclose(x[0], 0))
+        bc.create_bc(V)
+        exp_dofs = np.nonzero(np.isclose(X[:, 0], 0))[0]
+        assert (np.sort(bc._dofs) == exp_dofs).all()
+        for t in (0.1, 0.2, 0.3):
+            clock["t"] = t
+            bc.update_bc()
+            assert np.allclose(bc.values_host(), f(X[bc._dofs].T))
+        c = fem.Constant(m, 3.0)
+        bcc = DirichletBC(c, LocatorMethod.GEOMETRICAL, lambda x: np.isclose(x[1], 1))
+        bcc.create_bc(V)
+        assert np.allclose(bcc.values_host(), 3.0)
+        c.value = 5.0  # tracked by reference (test_bcs.py:100-125)
+        assert np.allclose(bcc.values_host(), 5.0)
+        dim = m.topology.dim - 1
+        facets = M.locate_entities_boundary(m, dim, lambda x: np.isclose(x[0], 1))
+        tags = M.meshtags(m, dim, facets, np.full(facets.shape, 2, dtype=np.int32))
+        bct = DirichletBC(1.5, LocatorMethod.TOPOLOGICAL, (tags, 2))
+        bct.create_bc(V)
+        assert (np.sort(bct._dofs) == np.nonzero(np.isclose(X[:, 0], 1))[0]).all()
+        assert bct._bc._cpp_object.dof_indices()[1] == bct._dofs.shape[0]
+
+
+def test_field_storage_and_function_views():
+    m = M.create_unit_square(None, 3, 3, device="cpu")
+    V = fem.FunctionSpace(m, 2, window=64)
+    W = fem.VectorFunctionSpace(V, 2)
+    S = fem.FieldStorage(V.num_dofs, 2, "cpu")
+    u0, u1 = fem.Function(V, "a", S, 0), fem.Function(V, "b", S, 1)
+    u0.interpolate(lambda x: x[0])
+    u1.x.array[:] = 7.0
+    w = fem.Function(W, "w", S, None)
+    assert w.x.array.shape[0] == 2 * V.num_dofs
+    assert np.allclose(w.x.array[1::2], 7.0) and np.allclose(w.x.array[0::2], V.tabulate_dof_coordinates()[:, 0])
+    Vs, idx = W.sub(1).collapse()
+    assert Vs is V and (idx == np.arange(V.num_dofs) * 2 + 1).all()

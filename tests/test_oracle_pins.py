@@ -1,0 +1,287 @@
+"""CPU: pins of the oracle (oracle/ipcs_oracle.py, oracle/ipcs_cpu.c).
+
+The reference cannot run here and its tests carry no numeric vectors for this path (see the
+oracle's header), so the oracle is pinned by: closed-form element matrices, the mesh/nnz counts of
+SURVEY.md section 8, exactness identities, the restated reference test
+test/test_tentative_velocity.py (split operators == monolithic form, matrices included), scipy's
+solvers, the analytic Taylor-Green solution of reference demo/taylor_green.py, and the committed
+(self-generated) golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import ipcs_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_quadrature_exact_on_monomials():
+    import math
+
+    for d in (2, 3):
+        bary, w = O.simplex_quadrature(d, 4)
+        assert abs(w.sum() - 1.0 / math.factorial(d)) < 1e-15
+        # int lambda^alpha = alpha! / (|alpha| + d)!
+        for alpha in [(7, 0, 0, 0), (3, 2, 1, 1), (2, 2, 2, 1), (0, 5, 0, 2)]:
+            a = alpha[: d + 1]
+            num = np.prod([math.factorial(k) for k in a])
+            exact = num / math.factorial(sum(a) + d)
+            val = float((w * np.prod(bary ** np.array(a), axis=1)).sum())
+            assert abs(val - exact) < 1e-16 + 1e-13 * exact
+
+
+def test_reference_element_matrices_closed_form():
+    # P1 mass on a simplex: |T|/((d+1)(d+2)) * (1 + delta_ij)
+    for d, coords, cells in ((2, [[0, 0], [1, 0], [0, 1]], [[0, 1, 2]]),
+                             (3, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], [[0, 1, 2, 3]])):
+        F = O.Forms(np.array(coords, float), np.array(cells), 1, 1)
+        vol = F.volume()
+        M = F.mass_v().toarray()
+        exp = vol / ((d + 1) * (d + 2)) * (np.ones((d + 1, d + 1)) + np.eye(d + 1))
+        assert np.abs(M - exp).max() < 1e-16
+    # P1 stiffness on the unit right triangle
+    F = O.Forms(np.array([[0, 0], [1, 0], [0, 1]], float), np.array([[0, 1, 2]]), 1, 1)
+    K = F.stiffness_v().toarray()
+    assert np.abs(K - 0.5 * np.array([[2, -1, -1], [-1, 1, 0], [-1, 0, 1]])).max() < 1e-15
+    # P2 mass on the reference triangle (x 360): classic table
+    F = O.Forms(np.array([[0, 0], [1, 0], [0, 1]], float), np.array([[0, 1, 2]]), 2, 1)
+    M2 = F.mass_v().toarray() * 360
+    # vertex-vertex 6 / -1, vertex-opposite-edge -4, vertex-adjacent-edge 0, edge-edge 32 / 16
+    assert np.allclose(np.diag(M2)[:3], 6) and np.allclose(np.diag(M2)[3:], 32)
+    assert np.isclose(M2[0, 1], -1) and np.isclose(M2[3, 4], 16)
+    # global edge dofs are numbered by sorted vertex pair: 3 = (0,1), 4 = (0,2), 5 = (1,2)
+    assert np.isclose(M2[0, 5], -4) and np.isclose(M2[0, 3], 0) and np.isclose(M2[2, 3], -4)
+
+
+@pytest.mark.parametrize("N", [2, 3, 5])
+def test_box_mesh_counts_match_survey_formulas(N):
+    c, cl = O.create_box_mesh([0, 0, 0], [1, 1, 1], [N, N, N])
+    F = O.Forms(c, cl, 2, 1)
+    assert cl.shape[0] == 6 * N ** 3 and c.shape[0] == (N + 1) ** 3
+    assert F.nv == (2 * N + 1) ** 3 and F.nq == (N + 1) ** 3
+    assert F.nv - F.nq == 7 * N ** 3 + 9 * N ** 2 + 3 * N  # edges
+    assert F.stiffness_q().nnz == 15 * N ** 3 + 21 * N ** 2 + 9 * N + 1
+    assert F.mass_v().nnz == 230 * N ** 3 + 138 * N ** 2 + 24 * N + 1
+    assert F.p_vdxi_mat(0).nnz <= 65 * N ** 3 + 57 * N ** 2 + 15 * N + 1  # exact zeros may drop out
+    assert abs(F.volume() - 1.0) < 1e-14
+
+
+def test_rectangle_mesh_counts_c1():
+    c, cl = O.create_rectangle_mesh([-1, -1], [1, 1], [32, 32])
+    F = O.Forms(c, cl, 2, 1)
+    assert (cl.shape[0], F.nv, F.nq) == (2048, 4225, 1089)
+    assert F.mass_v().nnz == 47617 and F.stiffness_q().nnz == 7361
+
+
+@pytest.mark.parametrize("dim,N,deg", [(2, 5, 1), (2, 4, 2), (3, 3, 1), (3, 2, 2)])
+def test_exactness_identities(dim, N, deg):
+    rng = np.random.default_rng(0)
+    if dim == 2:
+        c, cl = O.create_rectangle_mesh([-1, -0.5], [1, 1], [N, N + 1])
+    else:
+        c, cl = O.create_box_mesh([-1, -1, 0], [1, 0.5, 1], [N, N, N + 1])
+    F = O.Forms(c, cl, deg, 1)
+    vol = F.volume()
+    assert abs(F.mass_v().sum() - vol) < 1e-13
+    one = np.ones(F.nv)
+    assert np.abs(F.stiffness_v() @ one).max() < 1e-12
+    C = F.convection(rng.standard_normal((F.nv, dim)))
+    assert np.abs(C @ one).max() < 1e-13
+    # energy of a representable field: int |grad f|^2 for f = x0 (+ x0*x1 when P2)
+    x = F.x_v
+    f = x[:, 0] + (x[:, 0] * x[:, 1] if deg == 2 else 0.0)
+    ex = vol if deg == 1 else None
+    e = f @ (F.stiffness_v() @ f)
+    if deg == 1:
+        assert abs(e - ex) < 1e-12
+    else:
+        g = lambda X: (1 + X[1]) ** 2 + X[0] ** 2  # noqa: E731  |grad f|^2
+        bary, w = O.simplex_quadrature(dim, 4)
+        xq = np.einsum("qa,cak->cqk", bary, c[cl])
+        val = np.einsum("q,cq,c->", w, g(np.moveaxis(xq, 2, 0)), F.adet)
+        assert abs(e - val) < 1e-11
+    # discretely divergence-free: u = (x0, -x1, 0) is in the space -> sum_i D_i u_i = 0
+    u = np.zeros((F.nv, dim))
+    u[:, 0], u[:, 1] = x[:, 0], -x[:, 1]
+    assert np.abs(F.divu_vec(u)).max() < 1e-13
+    # matrix and matrix-free variants of the rectangular operators agree
+    p = rng.standard_normal(F.nq)
+    for i in range(dim):
+        assert np.abs(F.p_vdxi_mat(i) @ p - F.p_vdxi_vec(p, i)).max() < 1e-13
+        assert np.abs(F.grad_p_mat(i) @ p - F.grad_p_vec(p, i)).max() < 1e-13
+    assert np.abs(sum(F.divu_mat(i) @ u[:, i] for i in range(dim)) - F.divu_vec(u)).max() < 1e-13
+    # integration by parts on the whole domain for interior-supported test functions:
+    # P_i (p * v.dx(i)) and G_i (p.dx(i) * v) satisfy P_i + G_i = boundary term -> equal up to sign
+    # on rows whose basis function vanishes on the boundary
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    interior = np.setdiff1d(np.arange(F.nv), O.boundary_dofs(x, lo, hi))
+    for i in range(dim):
+        s = (F.p_vdxi_mat(i) + F.grad_p_mat(i))[interior]
+        assert abs(s).max() < 1e-13
+
+
+@pytest.mark.parametrize("low_memory", [True, False])
+@pytest.mark.parametrize("body_force", [True, False])
+def test_tentative_split_equals_monolithic(low_memory, body_force):
+    """Restated reference test/test_tentative_velocity.py:87-235 (10x10 unit square, P1-P1,
+    dt = 0.1, nu = 0.5): the split-operator A and rhs1 equal a direct quadrature of the monolithic
+    form (u-u_n)/dt v + uab.grad(0.5(u+u_n)) v + nu grad(0.5(u+u_n)).grad v  (+ p v.dx(i) + f v).
+    Unlike the reference, the matrices ARE compared."""
+    dt, nu = 0.1, 0.5
+    c, cl = O.create_rectangle_mesh([0, 0], [1, 1], [10, 10])
+    F = O.Forms(c, cl, 1, 1)
+    d = 2
+    f = (0.3, -0.1) if body_force else None
+    inlet = lambda x, t: (1 + t) * np.sin(np.pi * x[1])  # noqa: E731
+    left = np.nonzero(np.isclose(F.x_v[:, 0], 0))[0]
+    tb = np.nonzero(np.isclose(F.x_v[:, 1], 0) | np.isclose(F.x_v[:, 1], 1))[0]
+    clock = {"t": dt}
+    bcs = [[O.DirichletData(left, lambda x: inlet(x, clock["t"])), O.DirichletData(tb, 0.0)],
+           [O.DirichletData(left, 0.0), O.DirichletData(tb, 0.0)]]
+    S = O.OracleFractionalStep(F, F.x_v, F.x_q, bcs, body_force=f, low_memory=low_memory,
+                               solver_options={"tentative": {"ksp_type": "preonly", "pc_type": "lu"}})
+    X = np.zeros((3, F.nv))
+    X[:2] = F.x_v.T
+    for i in range(d):
+        S.u2[:, i] = inlet(X, -2 * dt)
+        S.u1[:, i] = inlet(X, -dt)
+    S.ps[:] = F.x_q[:, 1]
+    S.assemble_first(dt, nu)
+    S.velocity_tentative_assemble()
+    # monolithic assembly by direct quadrature
+    uab = 1.5 * S.u1 - 0.5 * S.u2
+    w, phi, gv, adet = F.w, F.phi_v, F.grad_v, F.adet
+    uq = np.einsum("qk,ckd->cqd", phi, uab[F.vd])
+    conv_j = np.einsum("cqd,cqjd->cqj", uq, gv)
+    Ae = (np.einsum("q,qi,qj->ij", w, phi, phi)[None] / dt
+          + 0.5 * np.einsum("q,qi,cqj->cij", w, phi, conv_j)
+          + 0.5 * nu * np.einsum("q,cqid,cqjd->cij", w, gv, gv)) * adet[:, None, None]
+    Amono = F._csr(Ae, F.vd, F.vd, (F.nv, F.nv)).tolil()
+    for r in np.unique(np.concatenate([left, tb])):
+        Amono.rows[r], Amono.data[r] = list(Amono.rows[r]), [1.0 if cc == r else 0.0 for cc in Amono.rows[r]]
+    assert abs(Amono.tocsr() - S.A).max() < 1e-13
+    pq = np.einsum("qs,cs->cq", F.phi_q, S.ps[F.qd])
+    for i in range(d):
+        un = S.u1[:, i][F.vd]
+        unq = np.einsum("qk,ck->cq", phi, un)
+        gun = np.einsum("cqkd,ck->cqd", gv, un)
+        Le = (np.einsum("q,cq,qi->ci", w, unq, phi) / dt
+              - 0.5 * np.einsum("q,cq,qi->ci", w, np.einsum("cqd,cqd->cq", uq, gun), phi)
+              - 0.5 * nu * np.einsum("q,cqd,cqid->ci", w, gun, gv)
+              + np.einsum("q,cq,cqi->ci", w, pq, gv[:, :, :, i]))
+        if f is not None:
+            Le = Le + f[i] * np.einsum("q,qi->i", w, phi)[None]
+        b = F._vec(Le * adet[:, None], F.vd, F.nv)
+        rhs = S.rhs1[:, i].copy()
+        for bc in bcs[i]:
+            bc.apply(b)
+            bc.apply(rhs)
+        assert np.abs(b - rhs).max() < 1e-13
+    diff, errors = S.velocity_tentative_solve()
+    assert (errors > 0).all()
+
+
+def test_krylov_against_scipy():
+    c, cl = O.create_box_mesh([0, 0, 0], [1, 1, 1], [4, 4, 4])
+    F = O.Forms(c, cl, 2, 1)
+    rng = np.random.default_rng(2)
+    A = (F.mass_v() * 30 + F.stiffness_v()).tocsr()
+    b = rng.standard_normal(F.nv)
+    x, reason, its, rn = O.jacobi_cg(A, b, rtol=1e-12, atol=1e-30)
+    assert reason == O.CONVERGED_RTOL
+    assert np.abs(x - spla.spsolve(A.tocsc(), b)).max() < 1e-9
+    B = (A + 0.5 * F.convection(rng.standard_normal((F.nv, 3)))).tocsr()
+    x, reason, its, rn = O.jacobi_bicgstab(B, b, rtol=1e-12, atol=1e-30)
+    assert reason == O.CONVERGED_RTOL
+    assert np.abs(x - spla.spsolve(B.tocsc(), b)).max() < 1e-9
+    xs, info = spla.bicgstab(B, b, rtol=1e-12, atol=0.0, M=sp.diags(1.0 / B.diagonal()))
+    assert info == 0 and np.abs(x - xs).max() < 1e-8
+    # nonzero initial guess converges to the same answer
+    x2, reason, its2, _ = O.jacobi_cg(A, b, x0=x * 0 + 0.1, rtol=1e-12, atol=1e-30)
+    assert reason > 0 and np.abs(x2 - spla.spsolve(A.tocsc(), b)).max() < 1e-9
+
+
+def test_taylor_green_2d_converges_to_the_analytic_solution():
+    """reference demo/taylor_green.py with CI's arguments (-N 8 16 32 -dt 0.005): space-time L2
+    errors sqrt(dt sum ||e||^2) over the first 20 steps fall at better than 2nd / 1.5th order."""
+    dt, nu, steps = 0.005, 0.01, 20
+    lu = {k: {"ksp_type": "preonly", "pc_type": "lu"} for k in ("tentative", "pressure", "scalar")}
+    eu, ep = [], []
+    for N in (8, 16, 32):
+        S, clock = O.taylor_green_problem(N, 2, nu=nu, dt=dt, solver_options=lu)
+        su = sp_ = 0.0
+        t = 0.0
+        for _ in range(steps):
+            t += dt
+            clock["t"] = t
+            S.solve(dt, nu, max_iter=1)
+            su += sum(S.F.l2_error_sq(S.u1[:, i], lambda x, f=f: f(x, t, nu)) for i, f in enumerate((O.tg_u, O.tg_v)))
+            sp_ += S.F.l2_error_sq(S.p, lambda x: O.tg_p(x, t - dt / 2, nu), space="q")
+        eu.append(np.sqrt(dt * su))
+        ep.append(np.sqrt(dt * sp_))
+    ru = np.log2(np.array(eu[:-1]) / np.array(eu[1:]))
+    rp = np.log2(np.array(ep[:-1]) / np.array(ep[1:]))
+    assert (ru > 2.0).all() and (rp > 1.5).all(), (eu, ep, ru, rp)
+    assert eu[-1] < 5e-4 and ep[-1] < 2e-3
+
+
+def test_taylor_green_3d_extruded_matches_2d():
+    """The 3-D benchmark field is the z-extruded 2-D one: after a step (u, v) are close to the
+    analytic field and w is at discretisation-error level (the 6-tet split of the cubes is not
+    z-symmetric, so w is O(h^2), not 0)."""
+    dt, nu = 0.005, 0.01
+    lu = {k: {"ksp_type": "preonly", "pc_type": "lu"} for k in ("tentative", "pressure", "scalar")}
+    S, clock = O.taylor_green_problem(6, 3, nu=nu, dt=dt, solver_options=lu)
+    clock["t"] = dt
+    S.solve(dt, nu, max_iter=1)
+    X = np.zeros((3, S.x_v.shape[0]))
+    X[:] = S.x_v.T
+    assert np.abs(S.u1[:, 2]).max() < 1e-2
+    assert np.abs(S.u1[:, 0] - O.tg_u(X, dt, nu)).max() < 2e-2
+
+
+def test_c_port_matches_numpy_oracle():
+    from oracle import cpu_baseline as CB
+
+    so = {k: {"ksp_type": t, "pc_type": "jacobi", "ksp_rtol": 1e-11, "ksp_atol": 1e-30}
+          for k, t in (("tentative", "bcgs"), ("pressure", "cg"), ("scalar", "cg"))}
+    for dim, N, ud in ((2, 8, 2), (3, 4, 2), (3, 4, 1)):
+        S, clock = O.taylor_green_problem(N, dim, u_deg=ud, solver_options=so)
+        cpu = CB.from_oracle(S, {"rtol": 1e-11, "atol": 1e-30, "max_it": 10000, "guess": False})
+        dt, nu, t = 0.005, 0.01, 0.0
+        for _ in range(2):
+            t += dt
+            clock["t"] = t
+            S.solve(dt, nu, max_iter=1)
+            bc = S.bcs_u[0][0].dofs
+            cpu.step(dt, nu, np.stack([S.bcs_u[i][0].g[bc] for i in range(dim)]))
+        assert np.abs(cpu.u1.T - S.u1).max() < 1e-9 and np.abs(cpu.p - S.p).max() < 1e-8
+        assert cpu.its["tentative"] == S.its["tentative"] and cpu.its["update"] == S.its["update"]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
+def test_oracle_reproduces_golden_fixtures(path):
+    g = np.load(path)
+    dim = g["coords"].shape[1]
+    lu = {k: {"ksp_type": "preonly", "pc_type": "lu"} for k in ("tentative", "pressure", "scalar")}
+    S, clock = O.taylor_green_problem(0, dim, u_deg=int(g["u_deg"]), nu=float(g["nu"]), dt=float(g["dt"]),
+                                      solver_options=lu, mesh=(g["coords"], g["cells"]), vd=g["vd"], qd=g["qd"],
+                                      x_v=g["x_v"], x_q=g["x_q"])
+    dt, nu = float(g["dt"]), float(g["nu"])
+    last = max(int(k[2:]) for k in g.files if k.startswith("u_") and k[2:].isdigit())
+    t = 0.0
+    for s in range(1, last + 1):
+        t += dt
+        clock["t"] = t
+        S.solve(dt, nu, max_iter=1)
+        if s == 1:
+            A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=S.A.shape)
+            assert abs(A - S.A).max() < 1e-12
+            assert np.abs(S.rhs1 - g["rhs1"]).max() < 1e-12
+        if f"u_{s}" in g.files:
+            assert np.abs(S.u1 - g[f"u_{s}"]).max() < 1e-11
+            assert np.abs(S.p - g[f"p_{s}"]).max() < 1e-10
