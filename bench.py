@@ -106,7 +106,12 @@ def main():
         return (np.isclose(np.abs(x[0]), 1.0) | np.isclose(np.abs(x[1]), 1.0) | np.isclose(np.abs(x[2]), 1.0))
 
     t_setup = time.perf_counter()
-    mesh = M.create_box(None, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N])
+    comm = None
+    if world > 1:
+        from oasisx_amd.parallel import init_comm
+
+        comm = init_comm()  # RCCL communicator of the library, bootstrapped over torch.distributed
+    mesh = M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N])
     fns = [tg_u, tg_v, tg_w]
     bcs_u = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"]), ox.LocatorMethod.GEOMETRICAL, on_boundary)]
              for f in fns]
@@ -200,7 +205,8 @@ def main():
             "config": {"workload": f"3D Taylor-Green {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
                                    f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
                                    f"initial_guess_nonzero={not args.zero_guess}, max_iter=1",
-                       "cells": mesh.num_cells, "n_u_per_component": S._n_u, "n_p": S._n_q,
+                       "cells": mesh.num_cells, "n_u_per_component": S._Vi[0][0].num_dofs_global,
+                       "n_p": S._Q.num_dofs_global,
                        "nnz_velocity": Pu.nnz, "nnz_pressure": Pp.nnz, "parallelism": f"mesh-partition x{world}"},
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
@@ -208,7 +214,7 @@ def main():
             "setup_s": t_setup,
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             try:
                 from oracle.cpu_baseline import run_cpu_baseline
 

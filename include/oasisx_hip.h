@@ -181,9 +181,10 @@ int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const doubl
                  const ox_dist *dist, void *stream);
 
 /* ---- V3 + A10: nullspace.remove and mean shift (fracstep.py:573-574, 579-591) -------- */
-/* x[i] -= (sum_i w[i]*x[i]) / wsum ;  w == NULL -> arithmetic mean (wsum = n). */
-int ox_remove_mean(int64_t n, double *x, const double *w, double wsum, const ox_dist *dist,
-                   void *stream);
+/* m = (sum_{i<n} w[i]*x[i], all ranks) / wsum;  x[i] -= m for i < n_apply (owned + ghost rows);
+ * w == NULL -> plain sum (arithmetic mean when wsum = global n). */
+int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, double wsum,
+                   const ox_dist *dist, void *stream);
 
 /* ---- measurement: per-kernel HIP-event timing on the launching stream (bench.py) ------- */
 /* tags: 10*ncomp+epi for SpMV (epi 0 plain, 1 CG p.q, 2/3 BiCGStab), 100 assemble_first,
@@ -193,10 +194,13 @@ int ox_profile_end(void);
 int ox_profile_get(int tag, long long *count, double *total_ms);
 
 /* ---- H1 + collectives: mesh-partitioned runs (one process per GPU, RCCL) -------------- */
-int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 */
-/* send_idx: device, owned rows to pack; per-peer counts; ghosts arrive contiguously per peer
- * at x[n_owned + recv_off[p] ...]. */
-int ox_dist_create(const char *id128, int rank, int nranks, int n_peers, const int32_t *peers,
+int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 (broadcast it out of band) */
+int ox_comm_create(const char *id128, int rank, int nranks, void **comm_out); /* ncclCommInitRank */
+int ox_comm_destroy(void *comm);
+/* Halo plan of one function space on communicator `comm`.  send_idx: device, owned rows to
+ * pack, grouped per peer by send_off; ghosts arrive contiguously per peer at
+ * x[n_owned + recv_off[p] ...] (the ghost block of a vector is ordered by (owner, global id)). */
+int ox_dist_create(void *comm, int rank, int nranks, int n_peers, const int32_t *peers,
                    const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
                    int64_t n_owned, int64_t n_ghost, ox_dist **out);
 int ox_dist_destroy(ox_dist *d);

@@ -92,12 +92,14 @@ SIGNATURES = {
     "ox_ksp_work_bytes": (C.c_size_t, [_L, _L, _I, _I]),
     "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _P,
                           C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
-    "ox_remove_mean": (_I, [_L, _P, _P, _D, _P, _P]),
+    "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_profile_begin": (_I, [_I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(_D)]),
     "ox_comm_unique_id": (_I, [C.c_char_p]),
-    "ox_dist_create": (_I, [C.c_char_p, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
+    "ox_comm_create": (_I, [C.c_char_p, _I, _I, C.POINTER(_P)]),
+    "ox_comm_destroy": (_I, [_P]),
+    "ox_dist_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
                             C.POINTER(_L), _L, _L, C.POINTER(_P)]),
     "ox_dist_destroy": (_I, [_P]),
     "ox_halo_forward": (_I, [_P, _P, _I, _P]),

@@ -85,6 +85,8 @@ class DirichletBC:
         dev = V.mesh.device
         self._dofs = np.asarray(self._dofs, dtype=np.int32)
         self._dofs_dev = torch.from_numpy(self._dofs).to(dev)
+        # matrix rows exist for owned dofs only (mesh-partitioned runs keep ghosts in the vectors)
+        self._rows_dev = torch.from_numpy(self._dofs[self._dofs < V.n_owned]).to(dev)
         self._xbc = np.ascontiguousarray(V.tabulate_dof_coordinates()[self._dofs].T)  # (3, nbc)
         self._g_dev = torch.zeros(self._dofs.shape[0], dtype=torch.float64, device=dev)
         self._g_stamp = None

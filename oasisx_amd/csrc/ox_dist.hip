@@ -22,17 +22,28 @@ extern "C" int ox_comm_unique_id(char *id128) {
   return 0;
 }
 
-extern "C" int ox_dist_create(const char *id128, int rank, int nranks, int n_peers,
-                              const int32_t *peers, const int64_t *send_off,
-                              const int32_t *send_idx_dev, const int64_t *recv_off, int64_t n_owned,
-                              int64_t n_ghost, ox_dist **out) {
-  if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) OX_FAIL("ox_dist_create: bad argument");
-  ox_dist *d = static_cast<ox_dist *>(calloc(1, sizeof(ox_dist)));
-  if (!d) OX_FAIL("ox_dist_create: out of memory");
+extern "C" int ox_comm_create(const char *id128, int rank, int nranks, void **comm_out) {
+  if (!id128 || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) OX_FAIL("ox_comm_create: bad argument");
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   ncclComm_t comm;
   OX_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
+  *comm_out = comm;
+  return 0;
+}
+
+extern "C" int ox_comm_destroy(void *comm) {
+  if (comm) ncclCommDestroy(static_cast<ncclComm_t>(comm));
+  return 0;
+}
+
+extern "C" int ox_dist_create(void *comm, int rank, int nranks, int n_peers, const int32_t *peers,
+                              const int64_t *send_off, const int32_t *send_idx_dev,
+                              const int64_t *recv_off, int64_t n_owned, int64_t n_ghost,
+                              ox_dist **out) {
+  if (!comm || !out || nranks < 1 || rank < 0 || rank >= nranks) OX_FAIL("ox_dist_create: bad argument");
+  ox_dist *d = static_cast<ox_dist *>(calloc(1, sizeof(ox_dist)));
+  if (!d) OX_FAIL("ox_dist_create: out of memory");
   d->comm = comm;
   d->rank = rank;
   d->nranks = nranks;
@@ -42,7 +53,7 @@ extern "C" int ox_dist_create(const char *id128, int rank, int nranks, int n_pee
   d->recv_off = static_cast<int64_t *>(malloc(sizeof(int64_t) * (n_peers + 1)));
   d->send_off[0] = d->recv_off[0] = 0;
   for (int p = 0; p < n_peers; ++p) d->peers[p] = peers[p];
-  for (int p = 0; p <= n_peers; ++p) {
+  for (int p = 0; p <= n_peers && n_peers > 0; ++p) {
     d->send_off[p] = send_off[p];
     d->recv_off[p] = recv_off[p];
   }
@@ -59,7 +70,6 @@ extern "C" int ox_dist_create(const char *id128, int rank, int nranks, int n_pee
 extern "C" int ox_dist_destroy(ox_dist *d) {
   if (!d) return 0;
   if (d->send_buf) (void)hipFree(d->send_buf);
-  if (d->comm) ncclCommDestroy(static_cast<ncclComm_t>(d->comm));
   free(d->peers);
   free(d->send_off);
   free(d->recv_off);

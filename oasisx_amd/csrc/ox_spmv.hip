@@ -265,19 +265,20 @@ __global__ __launch_bounds__(256) void k_shift(int64_t n, double *x, const doubl
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] -= m;
 }
 
-extern "C" int ox_remove_mean(int64_t n, double *x, const double *w, double wsum,
+extern "C" int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, double wsum,
                               const ox_dist *dist, void *stream) {
-  if (n <= 0) return 0;
+  if (n_apply < n) n_apply = n;
+  if (n_apply <= 0) return 0;
   if (ox_scratch_init()) return -1;
   if (wsum == 0.0) OX_FAIL("ox_remove_mean: wsum == 0");
   hipStream_t st = ox_stream(stream);
-  const int nblk = ox_vec_blocks(n);
+  const int nblk = ox_vec_blocks(n > 0 ? n : 1);
   double *partial = g_scratch, *sums = g_scratch + OX_VEC_MAX_BLOCKS * 4;
   hipLaunchKernelGGL(k_wsum, dim3(nblk), dim3(256), 0, st, n, x, w, partial);
   OX_LAUNCH_CHECK();
   if (ox_reduce_partials(partial, nblk, 1, sums, st)) return -1;
   if (dist && ox_allreduce_impl(dist, sums, 1, st)) return -1;
-  hipLaunchKernelGGL(k_shift, dim3(nblk), dim3(256), 0, st, n, x, sums, 1.0 / wsum);
+  hipLaunchKernelGGL(k_shift, dim3(ox_vec_blocks(n_apply)), dim3(256), 0, st, n_apply, x, sums, 1.0 / wsum);
   OX_LAUNCH_CHECK();
   return 0;
 }

@@ -35,16 +35,18 @@ def local_edges(gdim: int):
     return [(1, 2), (0, 2), (0, 1)] if gdim == 2 else [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
 
 
-def cell_geometry(mesh: Mesh) -> torch.Tensor:
+def cell_geometry(mesh: Mesh, cell_ids=None) -> torch.Tensor:
     """[n_cells][gs] rows of grad(lambda_1..d) then |detJ| (gs = 6 in 2-D, 10 in 3-D)."""
     d = mesh.gdim
-    x = mesh.coords[mesh.cells]  # (nc, d+1, d)
+    cells = mesh.cells if cell_ids is None else mesh.cells[cell_ids]
+    x = mesh.coords[cells]  # (nc, d+1, d)
     J = (x[:, 1:, :] - x[:, :1, :]).transpose(1, 2).contiguous()  # columns = edge vectors
     det = torch.linalg.det(J)
     Jinv = torch.linalg.inv(J)  # rows = grad lambda_a, a = 1..d
     gs = 6 if d == 2 else 10
-    geom = torch.zeros((mesh.num_cells, gs), dtype=torch.float64, device=mesh.device)
-    geom[:, : d * d] = Jinv.reshape(mesh.num_cells, d * d)
+    ncl = int(cells.shape[0])
+    geom = torch.zeros((ncl, gs), dtype=torch.float64, device=mesh.device)
+    geom[:, : d * d] = Jinv.reshape(ncl, d * d)
     geom[:, d * d] = det.abs()
     return geom
 
@@ -62,6 +64,7 @@ class SellPattern:
         self.size = int(cols.shape[0])
         self.nnz = int(row_len.sum().item())
         self.device = cols.device
+        self.dist = None  # ox_dist* (halo plan) of the column space, mesh-partitioned runs
         # width bins for the LDS-accumulating row kernels
         w = torch.from_numpy(widths.astype(np.int64))
         order = torch.argsort(w, stable=True)
@@ -142,8 +145,8 @@ class _Element:
 class _DofMap:
     def __init__(self, V):
         self._V = V
-        self.index_map = type("IndexMap", (), {"size_local": V.num_dofs, "num_ghosts": 0,
-                                               "size_global": V.num_dofs})()
+        self.index_map = type("IndexMap", (), {"size_local": V.n_owned, "num_ghosts": V.n_local - V.n_owned,
+                                               "size_global": V.num_dofs_global})()
         self.index_map_bs = 1
 
     def cell_dofs(self, c):
@@ -151,9 +154,14 @@ class _DofMap:
 
 
 class FunctionSpace:
-    """Scalar Lagrange space of degree 1 or 2 on a simplicial mesh."""
+    """Scalar Lagrange space of degree 1 or 2 on a simplicial mesh.
 
-    def __init__(self, mesh: Mesh, degree: int, window: int = 4096, build_operator: bool = True,
+    With ``part`` (a :class:`oasisx_amd.parallel.MeshPartition`) the space is the rank-local
+    piece of a mesh-partitioned space: rows = the dofs this rank owns (SELL order), columns =
+    owned dofs followed by the ghost dofs grouped by owner rank, cells = every cell that touches
+    an owned dof (own cells + one ghost layer), so that every owned row is assembled locally."""
+
+    def __init__(self, mesh: Mesh, degree: int, window: int = 4096, part=None,
                  chunk_cells: int = 1 << 21):
         if degree not in (1, 2):
             raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
@@ -161,101 +169,208 @@ class FunctionSpace:
         self.degree = degree
         self.element = _Element(degree, mesh.gdim)
         self.num_sub_spaces = 0
+        self.part = part
         dev = mesh.device
         d = mesh.gdim
         nverts = mesh.num_vertices
-        cells = mesh.cells
-        nc = mesh.num_cells
-        # ---- 1. initial dofs: vertices, then edges --------------------------------------
+        rank = 0 if part is None else part.rank
+        # ---- 1. global initial dof ids: vertices, then edges; restricted to the local cells ----
+        if part is None:
+            cells = mesh.cells
+            self.local_cells = None
+        else:
+            self.local_cells = part.local_cells
+            cells = mesh.cells[part.local_cells]
+        nc = int(cells.shape[0])
         if degree == 1:
-            cd0 = cells
-            ndofs = nverts
-            x0 = mesh.coords
+            cd0g = cells
+            n_glob = nverts
             self._edge_keys = None
         else:
-            ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)
-            eb = torch.tensor([e[1] for e in local_edges(d)], device=dev)
-            a, b = cells[:, ea], cells[:, eb]
-            key = torch.minimum(a, b) * nverts + torch.maximum(a, b)
-            uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)
-            cd0 = torch.cat([cells, nverts + inv.reshape(nc, -1)], dim=1)
-            ndofs = nverts + int(uniq.shape[0])
-            x0 = torch.cat([mesh.coords, 0.5 * (mesh.coords[uniq // nverts] + mesh.coords[uniq % nverts])])
+            if part is None:
+                ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)
+                eb = torch.tensor([e[1] for e in local_edges(d)], device=dev)
+                a, b = cells[:, ea], cells[:, eb]
+                key = torch.minimum(a, b) * nverts + torch.maximum(a, b)
+                uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)
+                cell_edges = inv.reshape(nc, -1)
+                del a, b, key, inv
+            else:
+                uniq = part.edge_keys
+                cell_edges = part.cell_edges[part.local_cells]
             self._edge_keys = uniq
-            del a, b, key, inv
-        nd = int(cd0.shape[1])
+            cd0g = torch.cat([cells, nverts + cell_edges], dim=1)
+            n_glob = nverts + int(uniq.shape[0])
+        nd = int(cd0g.shape[1])
         self.nd = nd
-        self.num_dofs = ndofs
-        # ---- 2. spatial (z, y, x) ordering ---------------------------------------------
-        lo = x0.min(dim=0).values
-        span = (x0.max(dim=0).values - lo).clamp_min(1e-300)
-        q = torch.round((x0 - lo) / span * float(1 << 20)).to(torch.int64)
+        self.num_dofs_global = n_glob
+        if part is None:
+            gl = None
+            cdL = cd0g
+            nL = n_glob
+            owned = None
+        else:
+            gl = torch.unique(cd0g.reshape(-1))  # sorted global ids of the local dofs
+            cdL = torch.searchsorted(gl, cd0g.reshape(-1)).reshape(nc, nd)
+            nL = int(gl.shape[0])
+            ownerL = part.owner0(degree)[gl]
+            owned = ownerL == rank
+        self._gl = gl
+        # dof coordinates in the local initial numbering
+        ids = torch.arange(n_glob, device=dev) if gl is None else gl
+        isv = ids < nverts
+        xL = torch.empty((nL, d), dtype=torch.float64, device=dev)
+        xL[isv] = mesh.coords[ids[isv]]
+        if degree == 2:
+            ek = self._edge_keys[ids[~isv] - nverts]
+            xL[~isv] = 0.5 * (mesh.coords[torch.div(ek, nverts, rounding_mode="floor")] + mesh.coords[ek % nverts])
+        del isv
+        # ---- 2. owned dofs in spatial (z, y, x) order, then ghosts by (owner, global id) -------
+        lo = mesh.coords.min(dim=0).values
+        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
+        q = torch.round((xL - lo) / span * float(1 << 20)).to(torch.int64)
         skey = q[:, d - 1]
         for k in range(d - 2, -1, -1):
             skey = skey * (1 << 21) + q[:, k]
-        perm1 = torch.argsort(skey, stable=True)
+        del q
+        if owned is None:
+            perm1 = torch.argsort(skey, stable=True)
+            n_owned = nL
+            ghost_owner = None
+        else:
+            io = torch.nonzero(owned).reshape(-1)
+            io = io[torch.argsort(skey[io], stable=True)]
+            ig = torch.nonzero(~owned).reshape(-1)  # ascending global id already
+            ig = ig[torch.argsort(ownerL[ig], stable=True)]
+            perm1 = torch.cat([io, ig])
+            n_owned = int(io.shape[0])
+            ghost_owner = ownerL[ig]
         rank1 = torch.empty_like(perm1)
-        rank1[perm1] = torch.arange(ndofs, device=dev)
-        del skey, q
-        cd1 = rank1[cd0]
-        # ---- 3. pattern in that numbering (chunked unique of row*n+col keys) -------------
+        rank1[perm1] = torch.arange(nL, device=dev)
+        del skey
+        self.n_owned, self.n_local = n_owned, nL
+        self.num_dofs = nL  # DOLFINx convention: local arrays hold owned dofs, then ghosts
+        cd1 = rank1[cdL]
+        # ---- 3. pattern of the owned rows (chunked unique of row*nL+col keys) ------------------
         keys = None
         for c0 in range(0, nc, chunk_cells):
             blk = cd1[c0:c0 + chunk_cells]
-            kk = torch.unique((blk.unsqueeze(2) * ndofs + blk.unsqueeze(1)).reshape(-1))
+            kk = (blk.unsqueeze(2) * nL + blk.unsqueeze(1)).reshape(-1)
+            if n_owned < nL:
+                kk = kk[kk < n_owned * nL]
+            kk = torch.unique(kk)
             keys = kk if keys is None else torch.unique(torch.cat([keys, kk]))
-        row1 = torch.div(keys, ndofs, rounding_mode="floor")
-        len1 = torch.bincount(row1, minlength=ndofs)
-        # ---- 4. window sort by decreasing row length (stable) -----------------------------
-        lmax = int(len1.max().item())
-        wkey = (torch.arange(ndofs, device=dev) // window) * (lmax + 1) + (lmax - len1)
+        row1 = torch.div(keys, nL, rounding_mode="floor")
+        len1 = torch.bincount(row1, minlength=n_owned)[:n_owned]
+        # ---- 4. window sort of the owned rows by decreasing length (stable) --------------------
+        lmax = int(len1.max().item()) if n_owned else 0
+        wkey = (torch.arange(n_owned, device=dev) // window) * (lmax + 1) + (lmax - len1)
         perm2 = torch.argsort(wkey, stable=True)
-        rank2 = torch.empty_like(perm2)
-        rank2[perm2] = torch.arange(ndofs, device=dev)
+        rank2 = torch.arange(nL, device=dev)
+        rank2[perm2] = torch.arange(n_owned, device=dev)
         del wkey
-        rank = rank2[rank1]  # initial dof -> final dof
-        self._rank_initial = rank
-        self.cell_dofs = rank[cd0].to(torch.int32).contiguous()
-        xf = torch.empty_like(x0)
-        xf[rank] = x0
-        self.x = xf  # (ndofs, gdim) dof coordinates
+        rank_f = rank2[rank1]  # local initial dof -> final local dof
+        self._rank_initial = rank_f
+        self.cell_dofs = rank_f[cdL].to(torch.int32).contiguous()
+        xf = torch.empty_like(xL)
+        xf[rank_f] = xL
+        self.x = xf  # (n_local, gdim) dof coordinates
         self._x3 = None
-        self.vertex_dofs = rank[:nverts]
         self.dofmap = _DofMap(self)
-        self.pattern = None
-        self.adj = None
-        if not build_operator:
-            del keys
-            self._build_adjacency(None, None)
-            return
-        # ---- 5. final pattern: relabel + sort ---------------------------------------------
-        keys2 = torch.sort(rank2[row1] * ndofs + rank2[keys - row1 * ndofs]).values
+        # ---- 5. final pattern: relabel + sort ----------------------------------------------------
+        keys2 = torch.sort(rank2[row1] * nL + rank2[keys - row1 * nL]).values
         del keys, row1
-        rowf = torch.div(keys2, ndofs, rounding_mode="floor")
-        colf = (keys2 - rowf * ndofs).to(torch.int32)
-        row_len = torch.bincount(rowf, minlength=ndofs)
-        row_ptr = torch.zeros(ndofs + 1, dtype=torch.int64, device=dev)
+        rowf = torch.div(keys2, nL, rounding_mode="floor")
+        colf = (keys2 - rowf * nL).to(torch.int32)
+        row_len = torch.bincount(rowf, minlength=n_owned)[:n_owned]
+        row_ptr = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
         row_ptr[1:] = torch.cumsum(row_len, 0)
-        self.pattern = build_sell(ndofs, ndofs, rowf, colf, row_len, row_ptr)
+        self.pattern = build_sell(n_owned, nL, rowf, colf, row_len, row_ptr)
         self._build_adjacency(keys2, row_ptr)
         del keys2
+        # ---- 6. halo plan ---------------------------------------------------------------------------
+        self.halo = None
+        self.dist = None
+        if part is not None:
+            self.halo = self._build_halo(part, ghost_owner, cd0g)
+
+    # ---------------------------------------------------------------------------------
+    def global_to_local(self, gids: torch.Tensor) -> torch.Tensor:
+        """Final local dof of global initial dof ids (-1 where the dof is not local)."""
+        if self._gl is None:
+            return self._rank_initial[gids]
+        pos = torch.searchsorted(self._gl, gids).clamp_max(self._gl.shape[0] - 1)
+        ok = self._gl[pos] == gids
+        return torch.where(ok, self._rank_initial[pos], torch.full_like(pos, -1))
+
+    def _build_halo(self, part, ghost_owner, cd0g):
+        """Who sends what: ghosts are ordered by (owner, global id) on the receiver, and the owner
+        lists exactly those dofs in the same order -- computed from the replicated partition data,
+        no communication at set-up."""
+        dev = self.mesh.device
+        nverts = self.mesh.num_vertices
+        owner0 = part.owner0(self.degree)
+        peers, send_lists, recv_counts = [], [], []
+        for qr in range(part.nparts):
+            if qr == part.rank:
+                continue
+            nrecv = int((ghost_owner == qr).sum().item())
+            cm = part.cell_mask(qr)
+            cq = self.mesh.cells[cm]
+            ids = cq if self.degree == 1 else torch.cat([cq, nverts + part.cell_edges[cm]], dim=1)
+            ids = torch.unique(ids.reshape(-1))
+            ids = ids[owner0[ids] == part.rank]  # ascending global id = the receiver's order
+            if nrecv == 0 and ids.shape[0] == 0:
+                continue
+            loc = self.global_to_local(ids)
+            if loc.numel():
+                assert int(loc.min().item()) >= 0 and int(loc.max().item()) < self.n_owned
+            peers.append(qr)
+            send_lists.append(loc.to(torch.int32))
+            recv_counts.append(nrecv)
+        send_off = np.zeros(len(peers) + 1, dtype=np.int64)
+        recv_off = np.zeros(len(peers) + 1, dtype=np.int64)
+        for i in range(len(peers)):
+            send_off[i + 1] = send_off[i] + send_lists[i].shape[0]
+            recv_off[i + 1] = recv_off[i] + recv_counts[i]
+        assert recv_off[-1] == self.n_local - self.n_owned
+        send_idx = (torch.cat(send_lists) if send_lists else torch.zeros(0, dtype=torch.int32, device=dev)).contiguous()
+        return {"peers": np.asarray(peers, dtype=np.int32), "send_off": send_off, "recv_off": recv_off,
+                "send_idx": send_idx}
+
+    def attach_comm(self, comm):
+        """Create the device halo plan (ox_dist) of this space on an RCCL communicator."""
+        if self.halo is None or comm is None or comm.handle is None:
+            return
+        lib = _lib.load()
+        h = self.halo
+        out = C.c_void_p()
+        _lib.check(lib.ox_dist_create(comm.handle, comm.rank, comm.size, int(h["peers"].shape[0]),
+                                      h["peers"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                      h["send_off"].ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(h["send_idx"]),
+                                      h["recv_off"].ctypes.data_as(C.POINTER(C.c_int64)), self.n_owned,
+                                      self.n_local - self.n_owned, C.byref(out)), "ox_dist_create")
+        self.dist = out
+        self.pattern.dist = out
 
     # ---------------------------------------------------------------------------------
     def _build_adjacency(self, keys_sorted, row_ptr, chunk_pairs: int = 1 << 24):
         dev = self.mesh.device
-        nd, ndofs, nc = self.nd, self.num_dofs, self.mesh.num_cells
-        n_slices = (ndofs + SLICE - 1) // SLICE
+        nd, n_owned, nL = self.nd, self.n_owned, self.n_local
+        n_slices = (n_owned + SLICE - 1) // SLICE
         dof = self.cell_dofs.reshape(-1).to(torch.int64)
         order = torch.argsort(dof, stable=True)  # pairs grouped by dof, cells ascending
         dof_s = dof[order]
+        keep = dof_s < n_owned  # rows exist for owned dofs only
+        order, dof_s = order[keep], dof_s[keep]
         cell_s = torch.div(order, nd, rounding_mode="floor")
         loc_s = order - cell_s * nd
-        cnt = torch.bincount(dof_s, minlength=ndofs)
-        start = torch.zeros(ndofs + 1, dtype=torch.int64, device=dev)
+        cnt = torch.bincount(dof_s, minlength=n_owned)
+        start = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
         start[1:] = torch.cumsum(cnt, 0)
         t = torch.arange(dof_s.shape[0], device=dev) - start[dof_s]
         cpad = torch.zeros(n_slices * SLICE, dtype=torch.int64, device=dev)
-        cpad[:ndofs] = cnt
+        cpad[:n_owned] = cnt
         T = cpad.reshape(n_slices, SLICE).max(dim=1).values
         adj_ptr = torch.zeros(n_slices + 1, dtype=torch.int64, device=dev)
         adj_ptr[1:] = torch.cumsum(T * SLICE, 0)
@@ -265,20 +380,18 @@ class FunctionSpace:
         adj_cell[off] = cell_s.to(torch.int32)
         adj_loc = torch.zeros(npairs, dtype=torch.uint8, device=dev)
         adj_loc[off] = loc_s.to(torch.uint8)
-        adj_pos, pw = None, 0
-        if keys_sorted is not None:
-            pw = 4 if nd <= 4 else (8 if nd <= 8 else 16)
-            if int(self.pattern.widths.max()) > 255:
-                raise ValueError("row longer than 255 entries: position bytes overflow")
-            adj_pos = torch.zeros((npairs, pw), dtype=torch.uint8, device=dev)
-            P = dof_s.shape[0]
-            for p0 in range(0, P, chunk_pairs):
-                sl = slice(p0, min(P, p0 + chunk_pairs))
-                r = dof_s[sl]
-                cd = self.cell_dofs[cell_s[sl]].to(torch.int64)  # (m, nd)
-                g = torch.searchsorted(keys_sorted, (r.unsqueeze(1) * ndofs + cd).reshape(-1))
-                k = g.reshape(-1, nd) - row_ptr[r].unsqueeze(1)
-                adj_pos[off[sl], :nd] = k.to(torch.uint8)
+        pw = 4 if nd <= 4 else (8 if nd <= 8 else 16)
+        if int(self.pattern.widths.max()) > 255:
+            raise ValueError("row longer than 255 entries: position bytes overflow")
+        adj_pos = torch.zeros((npairs, pw), dtype=torch.uint8, device=dev)
+        P = dof_s.shape[0]
+        for p0 in range(0, P, chunk_pairs):
+            sl = slice(p0, min(P, p0 + chunk_pairs))
+            r = dof_s[sl]
+            cd = self.cell_dofs[cell_s[sl]].to(torch.int64)  # (m, nd)
+            g = torch.searchsorted(keys_sorted, (r.unsqueeze(1) * nL + cd).reshape(-1))
+            k = g.reshape(-1, nd) - row_ptr[r].unsqueeze(1)
+            adj_pos[off[sl], :nd] = k.to(torch.uint8)
         self.adj = AdjTable(n_slices, nd, adj_ptr, adj_cell, adj_loc, adj_pos, pw)
         self.adj_count = cnt
 
@@ -291,22 +404,22 @@ class FunctionSpace:
         return self._x3
 
     def entity_dofs(self, dim: int, entities) -> np.ndarray:
-        """Dofs on the closure of mesh entities (vertices + edges for P2)."""
+        """Local dofs on the closure of mesh entities (vertices + edges for P2)."""
         mesh = self.mesh
+        dev = mesh.device
         ev, _ = mesh._entities(dim)
         verts = ev[np.asarray(entities, dtype=np.int64)].reshape(len(entities), -1)
-        vd = self.vertex_dofs.cpu().numpy()
-        dofs = [vd[verts.ravel()]]
+        gids = [torch.from_numpy(verts.ravel().astype(np.int64)).to(dev)]
         if self.degree == 2 and verts.shape[1] >= 2:
-            ek = self._edge_keys.cpu().numpy()
-            rank = self._rank_initial.cpu().numpy()
+            ek = self._edge_keys
             nv = mesh.num_vertices
             for a, b in itertools.combinations(range(verts.shape[1]), 2):
-                lo = np.minimum(verts[:, a], verts[:, b])
-                hi = np.maximum(verts[:, a], verts[:, b])
-                idx = np.searchsorted(ek, lo * np.int64(nv) + hi)
-                dofs.append(rank[nv + idx])
-        return np.unique(np.concatenate(dofs)).astype(np.int32)
+                lo = torch.from_numpy(np.minimum(verts[:, a], verts[:, b]).astype(np.int64)).to(dev)
+                hi = torch.from_numpy(np.maximum(verts[:, a], verts[:, b]).astype(np.int64)).to(dev)
+                gids.append(nv + torch.searchsorted(ek, lo * nv + hi))
+        loc = self.global_to_local(torch.cat(gids))
+        loc = loc[loc >= 0]
+        return np.unique(loc.cpu().numpy()).astype(np.int32)
 
 
 def build_sell(n_rows, n_cols, rowf, colf, row_len, row_ptr) -> SellPattern:

@@ -82,16 +82,30 @@ class FractionalStep_AB_CN:
         window = int((options or {}).get("sell_window", 4096))
 
         # ---- spaces (reference fracstep.py:186-216) ----------------------------------------
-        Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window)
+        comm = getattr(mesh, "comm", None)
+        self._comm = comm
+        part = None
+        if comm is not None and getattr(comm, "size", 1) > 1:
+            from .parallel import MeshPartition
+
+            part = MeshPartition(mesh, comm.rank, comm.size)
+        self._part = part
+        Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part)
         if isinstance(p_element, FunctionSpace):
             Q = p_element
         else:
-            Q = Vi if u_deg == p_deg else FunctionSpace(mesh, p_deg, window=window)
+            Q = Vi if u_deg == p_deg else FunctionSpace(mesh, p_deg, window=window, part=part)
+        if part is not None:
+            Vi.attach_comm(comm)
+            if Q is not Vi:
+                Q.attach_comm(comm)
         self._V = VectorFunctionSpace(Vi, gdim)
         self._Vi = [self._V.sub(i).collapse() for i in range(gdim)]
         self._Q = Q
-        nu_, nq_ = Vi.num_dofs, Q.num_dofs
+        nu_, nq_ = Vi.n_local, Q.n_local  # owned + ghost rows of every field block
         self._n_u, self._n_q = nu_, nq_
+        self._no_u, self._no_q = Vi.n_owned, Q.n_owned
+        self._du, self._dq = Vi.dist, Q.dist  # halo plans (None on one GPU)
 
         def block():
             return FieldStorage(nu_, gdim, dev)
@@ -154,8 +168,8 @@ class FractionalStep_AB_CN:
         compiled here -- the element kernels are the templated HIP kernels of ox_assemble.hip)."""
         mesh = self._mesh
         Vi, Q = self._Vi[0][0], self._Q
-        self._geom = cell_geometry(mesh)
-        self._cells = _lib.ox_cells(mesh.gdim, 0, mesh.num_cells, self._geom.data_ptr())
+        self._geom = cell_geometry(mesh, Vi.local_cells)
+        self._cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
         self._adj_u = Vi.adj.struct()
         self._adj_q = Q.adj.struct()
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
@@ -180,15 +194,16 @@ class FractionalStep_AB_CN:
         self._assemble_matrix(1, Vi, self._adj_u, self._K)  # stiffness   (:375)
         self._assemble_matrix(1, Q, self._adj_q, self._Ap)  # pressure Laplacian (:379)
         # int phi_r dx on both spaces: body force vector (:387-390), mean of phi (:585-590)
-        self._wV = torch.empty(Vi.num_dofs, dtype=torch.float64, device=dev)
-        self._wQ = torch.empty(Q.num_dofs, dtype=torch.float64, device=dev)
-        _lib.check(lib.ox_assemble_weights(Vi.degree, C.byref(self._cells), C.byref(self._adj_u), Vi.num_dofs,
+        self._wV = torch.zeros(Vi.n_owned, dtype=torch.float64, device=dev)
+        self._wQ = torch.zeros(Q.n_owned, dtype=torch.float64, device=dev)
+        _lib.check(lib.ox_assemble_weights(Vi.degree, C.byref(self._cells), C.byref(self._adj_u), Vi.n_owned,
                                            _lib.ptr(self._wV), st), "ox_assemble_weights")
-        _lib.check(lib.ox_assemble_weights(Q.degree, C.byref(self._cells), C.byref(self._adj_q), Q.num_dofs,
+        _lib.check(lib.ox_assemble_weights(Q.degree, C.byref(self._cells), C.byref(self._adj_q), Q.n_owned,
                                            _lib.ptr(self._wQ), st), "ox_assemble_weights")
         f = torch.tensor(self._body_force, dtype=torch.float64, device=dev)
-        self._B0.dev()[: Vi.num_dofs] = self._wV.unsqueeze(1) * f.unsqueeze(0)
-        self._vol = float(self._wQ.sum().item())  # assemble_scalar(1*dx) (:581-584)
+        self._B0.dev()[: Vi.n_owned] = self._wV.unsqueeze(1) * f.unsqueeze(0)
+        vol = float(self._wQ.sum().item())  # assemble_scalar(1*dx) + allreduce (:581-584)
+        self._vol = vol if self._part is None else float(self._comm.allreduce(vol))
 
     # ------------------------------------------------------------------------------------
     def assemble_first(self, dt: float, nu: float):
@@ -208,13 +223,13 @@ class FractionalStep_AB_CN:
         self._A.version += 1
         # NOTE (reference :470): rows of the FIRST component's BCs only
         for bcu in self._bcs_u[0]:
-            self._A.zero_rows(bcu._dofs_dev, 1.0)
+            self._A.zero_rows(bcu._rows_dev, 1.0)
 
     def velocity_tentative_assemble(self):
         """rhs1_k = b_first_k + int p* dv/dx_k (reference fracstep.py:474-506)."""
         Vi, Q = self._Vi[0][0], self._Q
         _lib.check(self._lib.ox_assemble_grad_vector(0, Vi.degree, Q.degree, C.byref(self._cells),
-                                                     _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.num_dofs,
+                                                     _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
                                                      self._PS.ptr(), self._BFIRST.ptr(), 1.0, self._RHS1.ptr(),
                                                      _lib.current_stream()), "ox_assemble_grad_vector")
 
@@ -232,7 +247,7 @@ class FractionalStep_AB_CN:
         # diff = sum_i || u_i^old - u_i ||_2 (:523-524)
         _lib.check(lib.ox_axpby(n, 1.0, self._WRK.ptr(), -1.0, self._U.ptr(), self._WRK.ptr(), st), "ox_axpby")
         out = (C.c_double * 4)()
-        _lib.check(lib.ox_dot(self._n_u, gdim, self._WRK.ptr(), self._WRK.ptr(), out, None, st), "ox_dot")
+        _lib.check(lib.ox_dot(self._no_u, gdim, self._WRK.ptr(), self._WRK.ptr(), out, self._du, st), "ox_dot")
         diff = float(sum(np.sqrt(out[i]) for i in range(gdim)))
         return diff, errors
 
@@ -240,7 +255,7 @@ class FractionalStep_AB_CN:
         """b2 = -(1/dt) int div(u) q (reference fracstep.py:527-551)."""
         Vi, Q = self._Vi[0][0], self._Q
         _lib.check(self._lib.ox_assemble_div_vector(Q.degree, Vi.degree, C.byref(self._cells),
-                                                    _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.num_dofs,
+                                                    _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.n_owned,
                                                     self._U.ptr(), -1.0 / float(dt), self._B2.ptr(),
                                                     _lib.current_stream()), "ox_assemble_div_vector")
 
@@ -248,15 +263,16 @@ class FractionalStep_AB_CN:
         """Solve the pressure-correction problem (reference fracstep.py:553-605)."""
         lib, st = self._lib, _lib.current_stream()
         logger = logging.getLogger("oasisx")
-        nq = self._n_q
+        nq, nqo = self._n_q, self._no_q
         if len(self._bcs_p) == 0:
             # nullspace.remove(b2): subtract the arithmetic mean (:573-574)
-            _lib.check(lib.ox_remove_mean(nq, self._B2.ptr(), None, float(nq), None, st), "ox_remove_mean")
+            _lib.check(lib.ox_remove_mean(nqo, nqo, self._B2.ptr(), None, float(self._Q.num_dofs_global),
+                                          self._dq, st), "ox_remove_mean")
         converged = self._solver_p.solve_block(self._B2, self._DP)[0]
         if len(self._bcs_p) == 0:
             logger.debug("Making sure that mean of phi is 0 with lack of pressure conditions")
             # dp -= (int dp dx) / (int 1 dx) (:579-591)
-            _lib.check(lib.ox_remove_mean(nq, self._DP.ptr(), _lib.ptr(self._wQ), self._vol, None, st),
+            _lib.check(lib.ox_remove_mean(nqo, nq, self._DP.ptr(), _lib.ptr(self._wQ), self._vol, self._dq, st),
                        "ox_remove_mean")
         # ps = p + dp (:604)
         _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 1.0, self._DP.ptr(), self._PS.ptr(), st), "ox_axpby")
@@ -270,7 +286,7 @@ class FractionalStep_AB_CN:
         gdim = self._gdim
         self._M.mult(self._U.dev(), self._B3.dev(), gdim)
         _lib.check(lib.ox_assemble_grad_vector(1, Vi.degree, Q.degree, C.byref(self._cells),
-                                               _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.num_dofs,
+                                               _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
                                                self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr(), st),
                    "ox_assemble_grad_vector")
         return np.asarray(self._solver_c.solve_block(self._B3, self._U), dtype=np.int32)

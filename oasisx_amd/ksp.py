@@ -35,7 +35,6 @@ class KSPSolver:
         self._dinv = None
         self._dinv_version = -1
         self._work = None
-        self._dist = None
         self.last_result = None
         self.check_every = None
         self.updateOptions({} if petsc_options is None else petsc_options)
@@ -53,9 +52,6 @@ class KSPSolver:
     def setOperators(self, A: SellMatrix, P: typing.Optional[SellMatrix] = None):
         self._A = A
         self._dinv_version = -1
-
-    def set_dist(self, dist):
-        self._dist = dist
 
     def solve(self, b, x: Function) -> int:
         """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
@@ -116,8 +112,10 @@ class KSPSolver:
         every = self.check_every or (16 if meth == _lib.KSP_CG else 4)
         _lib.check(lib.ox_ksp_solve(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
                                     max_it, int(guess), int(every), _lib.ptr(self._work),
-                                    int(self._work.shape[0]), C.byref(res), self._dist, st),
+                                    int(self._work.shape[0]), C.byref(res), A.pattern.dist, st),
                    "ox_ksp_solve")
+        if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
+            _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")
         self.last_result = res
         reasons = [int(res.reason[c]) for c in range(nc)]
         if direct:

@@ -34,11 +34,12 @@ class SellMatrix:
         """Host copy as scipy CSR (tests / diagnostics)."""
         return self.pattern.to_csr(self.vals)
 
-    def mult(self, x: torch.Tensor, y: torch.Tensor, ncomp: int = 1, dist=None):
-        """y = A x on interleaved (n, ncomp) device blocks (PETSc Mat.mult)."""
+    def mult(self, x: torch.Tensor, y: torch.Tensor, ncomp: int = 1):
+        """y = A x on interleaved (n, ncomp) device blocks (PETSc Mat.mult); in mesh-partitioned
+        runs the ghost block of x is refreshed first (halo exchange)."""
         lib = _lib.load()
-        _lib.check(lib.ox_spmv(self.ref(), _lib.ptr(x), _lib.ptr(y), ncomp, dist, _lib.current_stream()),
-                   "ox_spmv")
+        _lib.check(lib.ox_spmv(self.ref(), _lib.ptr(x), _lib.ptr(y), ncomp, self.pattern.dist,
+                               _lib.current_stream()), "ox_spmv")
 
     def zero_rows(self, rows_dev: torch.Tensor, diag: float = 1.0):
         """Mat.zeroRowsLocal(rows, diag): keeps the columns (reference fracstep.py:471-472)."""

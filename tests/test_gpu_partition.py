@@ -1,0 +1,125 @@
+"""GPU: the device kernels on rank-local (owned + ghost) data.  One process builds the local
+problem of every rank of a 2- and 3-way partition in turn and checks that the owned rows of
+every assembled operator / vector equal the corresponding rows of the unpartitioned problem.
+(The collectives themselves -- RCCL halo exchange and all-reduce -- need one GPU per rank and are
+exercised by the driver's multi-GPU run; their host logic is covered over gloo in test_dist_cpu.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeComm:
+    def __init__(self, rank, size):
+        self.rank, self.size, self.handle = rank, size, None
+
+    def allreduce(self, v, op=None):
+        return v
+
+
+def _key(c):
+    q = np.round(c * 4096).astype(np.int64)
+    k = q[:, 0]
+    for j in range(1, q.shape[1]):
+        k = k * (1 << 20) + q[:, j]
+    return k
+
+
+def _match(x_global, x_local):
+    kg = _key(x_global)
+    og = np.argsort(kg)
+    return og[np.searchsorted(kg[og], _key(x_local))]
+
+
+def _problem(dim, N, deg, comm):
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+    from oracle import ipcs_oracle as O
+    from tests.helpers import KRYLOV, on_boundary, on_boundary3
+
+    mesh = (M.create_rectangle(comm, [[-1.0, -1.0], [1.0, 1.0]], [N, N]) if dim == 2
+            else M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N]))
+    fns = [O.tg_u, O.tg_v, O.tg_w][:dim]
+    marker = on_boundary if dim == 2 else on_boundary3
+    bcs = [[ox.DirichletBC(lambda x, f=f: f(x, 0.1, 0.01), ox.LocatorMethod.GEOMETRICAL, marker)] for f in fns]
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", deg), ("Lagrange", 1), bcs_u=bcs, bcs_p=[],
+                                solver_options=KRYLOV, options={"sell_window": 128}, body_force=(0.1, -0.2, 0.3)[:dim])
+    for i in range(dim):
+        S._u2[i].interpolate(lambda x, i=i: np.sin(x[0] + i) * np.cos(2 * x[1]) + 0.1 * x[dim - 1])
+        S._u1[i].interpolate(lambda x, i=i: np.cos(x[0] - i) * np.sin(x[1]) - 0.2 * x[dim - 1] ** 2)
+        S._u[i].interpolate(lambda x, i=i: np.cos(2 * x[0] + i) + x[1] * x[dim - 1])
+    S._ps.interpolate(lambda x: np.sin(x[0]) * x[1] + x[dim - 1])
+    S._dp.interpolate(lambda x: np.cos(x[0] * x[1]) - x[dim - 1] ** 2)
+    return S
+
+
+@pytest.mark.parametrize("dim,N,deg,P", [(2, 8, 2, 2), (3, 4, 2, 2), (3, 4, 2, 3), (3, 5, 1, 2)])
+def test_owned_rows_of_partitioned_operators_match_global(hip, dim, N, deg, P):
+    import torch
+
+    dt, nu = 0.05, 0.3
+    G = _problem(dim, N, deg, None)
+    G.assemble_first(dt, nu)
+    G.velocity_tentative_assemble()
+    G.pressure_assemble(dt)
+    Ag, Mg = G._A.to_scipy(), G._M.to_scipy()
+    xg_u, xg_q = G._Vi[0][0].x.cpu().numpy(), G._Q.x.cpu().numpy()
+    bfg = G._BFIRST.dev().cpu().numpy()
+    rhsg = G._RHS1.dev().cpu().numpy()
+    b2g = G._B2.dev().cpu().numpy()[:, 0]
+    yg = torch.zeros_like(G._U.dev())
+    G._M.mult(G._U.dev(), yg, dim)
+    yg = yg.cpu().numpy()
+    owned_total = 0
+    for r in range(P):
+        S = _problem(dim, N, deg, FakeComm(r, P))
+        Vi, Q = S._Vi[0][0], S._Q
+        assert Vi.n_local > Vi.n_owned > 0
+        owned_total += Vi.n_owned
+        S.assemble_first(dt, nu)
+        S.velocity_tentative_assemble()
+        S.pressure_assemble(dt)
+        xu = Vi.x.cpu().numpy()
+        iu = _match(xg_u, xu)  # global index of every local dof (owned and ghost)
+        iq = _match(xg_q, Q.x.cpu().numpy())
+        no, nqo = Vi.n_owned, Q.n_owned
+        # matrices: owned rows, columns mapped through the coordinates
+        for mine, ref in ((S._A.to_scipy(), Ag), (S._M.to_scipy(), Mg)):
+            loc = mine.tocoo()
+            refd = np.asarray(ref[iu[loc.row], iu[loc.col]]).ravel()
+            assert np.abs(loc.data - refd).max() <= 1e-12 * abs(ref).max()
+            assert mine.nnz == ref[iu[:no]].nnz
+        assert np.abs(S._BFIRST.dev().cpu().numpy()[:no] - bfg[iu[:no]]).max() <= 1e-11 * np.abs(bfg).max()
+        assert np.abs(S._RHS1.dev().cpu().numpy()[:no] - rhsg[iu[:no]]).max() <= 1e-11 * np.abs(rhsg).max()
+        assert np.abs(S._B2.dev().cpu().numpy()[:nqo, 0] - b2g[iq[:nqo]]).max() <= 1e-11 * np.abs(b2g).max()
+        y = torch.zeros_like(S._U.dev())
+        S._M.mult(S._U.dev(), y, dim)
+        assert np.abs(y.cpu().numpy()[:no] - yg[iu[:no]]).max() <= 1e-12 * np.abs(yg).max()
+        # int 1 dx over the owned pressure weights adds up to the volume
+        assert S._wQ.shape[0] == nqo
+    assert owned_total == G._Vi[0][0].num_dofs
+
+
+def test_rccl_single_rank_communicator(hip):
+    """ncclCommInitRank / halo plan / all-reduce entry points load and run with one rank."""
+    import ctypes as C
+
+    import torch
+
+    from oasisx_amd import _lib
+
+    buf = C.create_string_buffer(128)
+    _lib.check(hip.ox_comm_unique_id(buf), "ox_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(hip.ox_comm_create(buf.raw, 0, 1, C.byref(comm)), "ox_comm_create")
+    d = C.c_void_p()
+    z64 = (C.c_int64 * 1)(0)
+    _lib.check(hip.ox_dist_create(comm, 0, 1, 0, None, z64, None, z64, 10, 0, C.byref(d)), "ox_dist_create")
+    x = torch.arange(10, dtype=torch.float64, device="cuda")
+    _lib.check(hip.ox_halo_forward(d, _lib.ptr(x), 1, _lib.current_stream()), "ox_halo_forward")
+    _lib.check(hip.ox_allreduce_sum(d, _lib.ptr(x), 10, _lib.current_stream()), "ox_allreduce_sum")
+    out = (C.c_double * 4)()
+    _lib.check(hip.ox_dot(10, 1, _lib.ptr(x), _lib.ptr(x), out, d, _lib.current_stream()), "ox_dot")
+    assert out[0] == 285.0
+    _lib.check(hip.ox_dist_destroy(d), "ox_dist_destroy")
+    _lib.check(hip.ox_comm_destroy(comm), "ox_comm_destroy")
