@@ -203,6 +203,17 @@ int ox_comm_destroy(void *comm);
 int ox_dist_create(void *comm, int rank, int nranks, int n_peers, const int32_t *peers,
                    const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
                    int64_t n_owned, int64_t n_ghost, ox_dist **out);
+/* Same plan on a caller-supplied transport instead of RCCL (rehearsals on one GPU, other
+ * fabrics): halo_cb(user, packed_send_values_dev, ghost_block_dev, ncomp) and
+ * allreduce_cb(user, buf_dev, n) are called at the points where ncclSend/ncclRecv and
+ * ncclAllReduce would be, after the stream has been drained; both return 0 on success. */
+int ox_dist_create_custom(int rank, int nranks, int n_peers, const int32_t *peers,
+                          const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
+                          int64_t n_owned, int64_t n_ghost,
+                          int (*halo_cb)(void *, const double *, double *, int),
+                          int (*allreduce_cb)(void *, double *, int), void *user, ox_dist **out);
+/* blocking copy helper for such transports: to_device = 1 host->device, 0 device->host */
+int ox_memcpy(void *dst, const void *src, size_t bytes, int to_device, void *stream);
 int ox_dist_destroy(ox_dist *d);
 /* scatter_forward (owner -> ghost) of an interleaved vector (fracstep.py:453,...). */
 int ox_halo_forward(const ox_dist *d, double *x, int ncomp, void *stream);

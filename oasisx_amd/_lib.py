@@ -101,6 +101,9 @@ SIGNATURES = {
     "ox_comm_destroy": (_I, [_P]),
     "ox_dist_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
                             C.POINTER(_L), _L, _L, C.POINTER(_P)]),
+    "ox_dist_create_custom": (_I, [_I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P, C.POINTER(_L), _L, _L,
+                                   _P, _P, _P, C.POINTER(_P)]),
+    "ox_memcpy": (_I, [_P, _P, C.c_size_t, _I, _P]),
     "ox_dist_destroy": (_I, [_P]),
     "ox_halo_forward": (_I, [_P, _P, _I, _P]),
     "ox_allreduce_sum": (_I, [_P, _P, _I, _P]),

@@ -67,6 +67,31 @@ extern "C" int ox_dist_create(void *comm, int rank, int nranks, int n_peers, con
   return 0;
 }
 
+extern "C" int ox_dist_create_custom(int rank, int nranks, int n_peers, const int32_t *peers,
+                                     const int64_t *send_off, const int32_t *send_idx_dev,
+                                     const int64_t *recv_off, int64_t n_owned, int64_t n_ghost,
+                                     int (*halo_cb)(void *, const double *, double *, int),
+                                     int (*allreduce_cb)(void *, double *, int), void *user,
+                                     ox_dist **out) {
+  if (!halo_cb || !allreduce_cb) OX_FAIL("ox_dist_create_custom: null callback");
+  static int dummy_comm;
+  int rc = ox_dist_create(&dummy_comm, rank, nranks, n_peers, peers, send_off, send_idx_dev, recv_off,
+                          n_owned, n_ghost, out);
+  if (rc) return rc;
+  (*out)->comm = nullptr;
+  (*out)->halo_cb = halo_cb;
+  (*out)->allreduce_cb = allreduce_cb;
+  (*out)->user = user;
+  return 0;
+}
+
+extern "C" int ox_memcpy(void *dst, const void *src, size_t bytes, int to_device, void *stream) {
+  hipStream_t st = ox_stream(stream);
+  OX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 extern "C" int ox_dist_destroy(ox_dist *d) {
   if (!d) return 0;
   if (d->send_buf) (void)hipFree(d->send_buf);
@@ -96,6 +121,11 @@ int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st)
                        ns, ncomp, d->send_buf);
     OX_LAUNCH_CHECK();
   }
+  if (d->halo_cb) {
+    OX_HIP(hipStreamSynchronize(st));
+    if (d->halo_cb(d->user, d->send_buf, x + d->n_owned * ncomp, ncomp)) OX_FAIL("halo callback failed");
+    return 0;
+  }
   OX_NCCL(ncclGroupStart());
   for (int p = 0; p < d->n_peers; ++p) {
     const int64_t sc = d->send_off[p + 1] - d->send_off[p];
@@ -113,6 +143,11 @@ int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st)
 
 int ox_allreduce_impl(const ox_dist *d, double *buf, int n, hipStream_t st) {
   if (!d || d->nranks == 1) return 0;
+  if (d->allreduce_cb) {
+    OX_HIP(hipStreamSynchronize(st));
+    if (d->allreduce_cb(d->user, buf, n)) OX_FAIL("allreduce callback failed");
+    return 0;
+  }
   OX_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, static_cast<ncclComm_t>(d->comm), st));
   return 0;
 }

@@ -339,8 +339,14 @@ class FunctionSpace:
                 "send_idx": send_idx}
 
     def attach_comm(self, comm):
-        """Create the device halo plan (ox_dist) of this space on an RCCL communicator."""
-        if self.halo is None or comm is None or comm.handle is None:
+        """Create the device halo plan (ox_dist) of this space on an RCCL communicator (or on the
+        communicator's host-staged rehearsal transport when it has no RCCL handle)."""
+        if self.halo is None or comm is None:
+            return
+        if comm.handle is None:
+            if getattr(comm, "make_transport", None) is not None and torch.cuda.is_available():
+                self.dist = comm.make_transport(self)
+                self.pattern.dist = self.dist
             return
         lib = _lib.load()
         h = self.halo

@@ -49,6 +49,73 @@ class Comm:
         if self.size > 1:
             dist.barrier()
 
+    def make_transport(self, V):
+        """Host-staged rehearsal transport over the job's (gloo) process group: the halo plan of
+        space ``V`` as an ox_dist whose exchange points call back into Python.  For testing the
+        partitioned path where RCCL cannot run (several ranks on ONE GPU); never the fast path."""
+        import numpy as np
+        import torch.distributed as dist
+
+        lib = _lib.load()
+        h = V.halo
+        npeer = int(h["peers"].shape[0])
+        ns, ng = int(h["send_off"][-1]), V.n_local - V.n_owned
+        HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+        ARED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+        def halo_cb(user, send_dev, ghost_dev, nc):
+            try:
+                sb = np.empty(max(ns * nc, 1))
+                gb = np.empty(max(ng * nc, 1))
+                if ns:
+                    _lib.check(lib.ox_memcpy(sb.ctypes.data, send_dev, ns * nc * 8, 0, None), "ox_memcpy")
+                reqs, recvs = [], []
+                for i, q in enumerate(h["peers"]):
+                    s0, s1 = int(h["send_off"][i]) * nc, int(h["send_off"][i + 1]) * nc
+                    r0, r1 = int(h["recv_off"][i]) * nc, int(h["recv_off"][i + 1]) * nc
+                    if s1 > s0:
+                        reqs.append(dist.isend(torch.from_numpy(sb[s0:s1].copy()), int(q)))
+                    if r1 > r0:
+                        t = torch.empty(r1 - r0, dtype=torch.float64)
+                        reqs.append(dist.irecv(t, int(q)))
+                        recvs.append((t, r0, r1))
+                for r in reqs:
+                    r.wait()
+                for t, r0, r1 in recvs:
+                    gb[r0:r1] = t.numpy()
+                if ng:
+                    _lib.check(lib.ox_memcpy(ghost_dev, gb.ctypes.data, ng * nc * 8, 1, None), "ox_memcpy")
+                return 0
+            except Exception:  # noqa: BLE001 -- never unwind through the C frame
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def ared_cb(user, buf_dev, n):
+            try:
+                b = np.empty(n)
+                _lib.check(lib.ox_memcpy(b.ctypes.data, buf_dev, n * 8, 0, None), "ox_memcpy")
+                t = torch.from_numpy(b)
+                dist.all_reduce(t)
+                _lib.check(lib.ox_memcpy(buf_dev, b.ctypes.data, n * 8, 1, None), "ox_memcpy")
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        cbs = (HALO(halo_cb), ARED(ared_cb))
+        self._keep = getattr(self, "_keep", []) + [cbs]  # keep the thunks alive
+        out = C.c_void_p()
+        _lib.check(lib.ox_dist_create_custom(
+            self.rank, self.size, npeer, h["peers"].ctypes.data_as(C.POINTER(C.c_int32)),
+            h["send_off"].ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(h["send_idx"]),
+            h["recv_off"].ctypes.data_as(C.POINTER(C.c_int64)), V.n_owned, ng,
+            C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), None, C.byref(out)), "ox_dist_create_custom")
+        return out
+
 
 def init_comm() -> Comm:
     """Communicator of the current ``torch.distributed`` job.  With the nccl (= RCCL) backend the

@@ -1,0 +1,103 @@
+"""GPU, 2 (and 3) processes on ONE device: the whole mesh-partitioned step -- partitioned assembly,
+the C Krylov loops with their halo exchanges and merged all-reduces, ghost-consistency of every
+field -- against the serial run.  RCCL refuses several ranks on one GPU, so the exchange points go
+through the library's callback transport (gloo, host staged) instead of ncclSend/Recv/AllReduce;
+everything else (pack kernel, call sites, kernels, host logic) is the production path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _key(c):
+    q = np.round(c * 4096).astype(np.int64)
+    k = q[:, 0]
+    for j in range(1, q.shape[1]):
+        k = k * (1 << 20) + q[:, j]
+    return k
+
+
+def _run(dim, N, deg, comm, steps):
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+    from oracle import ipcs_oracle as O
+    from tests.helpers import KRYLOV, on_boundary, on_boundary3
+
+    nu, dt = 0.01, 0.005
+    mesh = (M.create_rectangle(comm, [[-1.0, -1.0], [1.0, 1.0]], [N, N]) if dim == 2
+            else M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N]))
+    clock = {"t": 0.0}
+    fns = [O.tg_u, O.tg_v, O.tg_w][:dim]
+    marker = on_boundary if dim == 2 else on_boundary3
+    bcs = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"], nu), ox.LocatorMethod.GEOMETRICAL, marker)] for f in fns]
+    opts = {k: dict(v, ksp_initial_guess_nonzero=True) for k, v in KRYLOV.items()}
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", deg), ("Lagrange", 1), bcs_u=bcs, bcs_p=[], solver_options=opts,
+                                options={"sell_window": 128})
+    for i, f in enumerate(fns):
+        S._u2[i].interpolate(lambda x, f=f: f(x, -dt, nu))
+        S._u1[i].interpolate(lambda x, f=f: f(x, 0.0, nu))
+    S._p.interpolate(lambda x: O.tg_p(x, -dt / 2, nu))
+    diffs = []
+    for _ in range(steps):
+        clock["t"] += dt
+        diffs.append(S.solve(dt, nu, max_iter=1))
+    return S, diffs
+
+
+def _worker(rank, world, port, dim, N, deg, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oasisx_amd.parallel import init_comm
+
+        comm = init_comm()
+        assert comm.size == world and comm.handle is None
+        S, diffs = _run(dim, N, deg, comm, steps=2)
+        G, gdiffs = _run(dim, N, deg, None, steps=2)
+        Vi, Q = S._Vi[0][0], S._Q
+        assert Vi.dist is not None and Vi.n_local > Vi.n_owned
+        kg = _key(G._Vi[0][0].x.cpu().numpy())
+        og = np.argsort(kg)
+        iu = og[np.searchsorted(kg[og], _key(Vi.x.cpu().numpy()))]
+        kq = _key(G._Q.x.cpu().numpy())
+        oq = np.argsort(kq)
+        iq = oq[np.searchsorted(kq[oq], _key(Q.x.cpu().numpy()))]
+        ug = G._U1.dev().cpu().numpy()
+        pg = G._P.dev().cpu().numpy()[:, 0]
+        ul = S._U1.dev().cpu().numpy()
+        pl = S._P.dev().cpu().numpy()[:, 0]
+        # owned AND ghost entries agree with the serial run (ghosts are kept consistent)
+        du = float(np.abs(ul - ug[iu]).max())
+        dp = float(np.abs(pl - pg[iq]).max())
+        assert du < 1e-8 and dp < 1e-7, (du, dp)
+        assert abs(diffs[-1] - gdiffs[-1]) < 1e-8 * max(1.0, abs(gdiffs[-1]))
+        assert abs(S._vol - G._vol) < 1e-12
+        out[rank] = (du, dp, S.iteration_counts(), G.iteration_counts())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dim,N,deg,world", [(3, 6, 2, 2), (2, 12, 2, 3), (3, 6, 1, 2)])
+def test_partitioned_steps_match_serial(hip, dim, N, deg, world):
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, out), nprocs=world, join=True)
+    assert len(out) == world, dict(out)
