@@ -608,3 +608,57 @@ def locate_dofs_geometrical(V, marker) -> np.ndarray:
 
 def locate_dofs_topological(V, entity_dim: int, entities) -> np.ndarray:
     return V.entity_dofs(entity_dim, np.asarray(entities))
+
+
+# ---- error functionals of the demo harness (reference demo/taylor_green.py:193-207) -----------
+
+
+def _simplex_rule(d: int, n: int):
+    """Collapsed Gauss-Jacobi rule, exact to degree 2n-1; barycentric points, weights sum 1/d!."""
+    from scipy.special import roots_jacobi
+
+    pts = []
+    for a in range(d - 1, -1, -1):
+        s, w = roots_jacobi(n, float(a), 0.0)
+        pts.append(((1 + s) / 2, w / 2 ** (a + 1)))
+    grids = np.meshgrid(*[p[0] for p in pts], indexing="ij")
+    W = np.ones_like(grids[0])
+    for k, p in enumerate(pts):
+        shape = [1] * d
+        shape[k] = n
+        W = W * p[1].reshape(shape)
+    coords, rem = [], np.ones_like(grids[0])
+    for g in grids:
+        coords.append(rem * g)
+        rem = rem * (1 - g)
+    X = np.stack([c.ravel() for c in coords], axis=1)
+    bary = np.concatenate([1 - X.sum(axis=1, keepdims=True), X], axis=1)
+    return bary, W.ravel()
+
+
+def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
+    """int (u_h - exact)^2 dx over the local cells (``assemble_scalar`` of the demo's error form).
+    ``exact`` maps x:(3, npts) -> (npts,).  Host numpy; a harness functional, not the hot path."""
+    V = u.function_space
+    mesh = V.mesh
+    d = mesh.gdim
+    bary, w = _simplex_rule(d, V.degree + degree_raise)
+    nv = d + 1
+    if V.degree == 1:
+        phi = bary
+    else:
+        cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
+        cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
+        phi = np.stack(cols, axis=1)
+    cells = mesh.cells.cpu().numpy()
+    if V.local_cells is not None:
+        cells = cells[V.local_cells.cpu().numpy()]
+    xc = mesh.coords.cpu().numpy()[cells]
+    xq = np.einsum("qa,cak->cqk", bary, xc)
+    X = np.zeros((3, xq.shape[0] * xq.shape[1]))
+    X[:d] = xq.reshape(-1, d).T
+    ex = np.asarray(exact(X)).reshape(xq.shape[0], xq.shape[1])
+    uh = u.x.array[V.cell_dofs.cpu().numpy()] @ phi.T
+    J = np.moveaxis(xc[:, 1:, :] - xc[:, :1, :], 1, 2)
+    adet = np.abs(np.linalg.det(J))
+    return float(np.einsum("q,cq,c->", w, (uh - ex) ** 2, adet))
