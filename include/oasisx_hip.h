@@ -115,6 +115,11 @@ int ox_dot(int64_t n_rows, int ncomp, const double *x, const double *y, double *
 int ox_set_bc(double *b, const int32_t *dofs, const double *g, int64_t n, int ncomp, int comp,
               void *stream);
 
+/* A11: adding the assembled outlet term to the RHS (reference fracstep.py:461-465):
+ * b[rows[k]*ncomp+comp] += scale * y[k]; rows must be unique (no atomics). */
+int ox_scatter_add(double *b, const int32_t *rows, const double *y, int64_t n, int ncomp, int comp,
+                   double scale, void *stream);
+
 /* ---- S4: Mat.zeroRowsLocal(rows, diag) (fracstep.py:471-472); keeps columns -------- */
 int ox_zero_rows(const ox_sell *A, const int32_t *rows, int64_t n, double diag, void *stream);
 /* DOLFINx assemble_matrix(..., bcs) on the pressure Laplacian (fracstep.py:379):

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ox_axpby": (_I, [_L, _D, _P, _D, _P, _P, _P]),
     "ox_dot": (_I, [_L, _I, _P, _P, C.POINTER(_D), _P, _P]),
     "ox_set_bc": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "ox_scatter_add": (_I, [_P, _P, _P, _L, _I, _I, _D, _P]),
     "ox_zero_rows": (_I, [C.POINTER(ox_sell), _P, _L, _D, _P]),
     "ox_zero_rows_cols": (_I, [C.POINTER(ox_sell), _P, _D, _P]),
     "ox_assemble_matrix": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,

@@ -131,26 +131,193 @@ class DirichletBC:
                    "ox_set_bc")
 
 
-class PressureBC:
-    """Natural pressure condition on outlet facets (reference bcs.py:142-268).
+class _SurfaceForm:
+    """What ``PressureBC.rhs(i)`` returns: the assembled-on-demand outlet term of component i."""
 
-    Not on the hot path of any benchmark configuration (all are enclosed, Dirichlet-only
-    flows); constructing one is allowed, using it in ``FractionalStep_AB_CN`` raises
-    ``NotImplementedError`` until the facet kernel lands."""
+    def __init__(self, bc, i):
+        self.bc, self.i, self.rank = bc, i, 1
+
+
+class PressureBC:
+    """Natural pressure condition on a set of tagged exterior facets (reference bcs.py:142-268).
+
+    The value h (float, ``Constant`` or callable interpolated into Q) enters the tentative
+    velocity RHS as ``int_Gamma h n_i dv/dx_i ds`` (bcs.py:226-242, fracstep.py:461-465) and the
+    pressure correction gets a homogeneous Dirichlet condition on the facets' pressure dofs
+    (bcs.py:245-253).
+
+    Device form: the term is linear in the nodal values of h, so ``create_bcs`` builds, once,
+    one small SELL-64 operator per component on the rows (velocity dofs) of the cells behind the
+    facets; per step the term is d tiny SpMVs plus a scatter-add -- no atomics."""
 
     def __init__(self, value, marker):
         self._subdomain_data, self._subdomain_id = marker
         self._value = value
 
     def create_bcs(self, V, Q):
-        raise NotImplementedError("PressureBC (outlet facet term) is not implemented on the HIP path yet")
+        import itertools
 
-    def update_bc(self):
-        raise NotImplementedError
+        from .fem import build_sell, local_edges
+        from .la import SellMatrix
+
+        mesh = V.mesh
+        assert mesh.topology is self._subdomain_data.topology
+        dev = mesh.device
+        d = mesh.gdim
+        tags = self._subdomain_data
+        if isinstance(self._subdomain_id, tuple):
+            facets = tags.indices[np.isin(tags.values, np.asarray(self._subdomain_id, dtype=np.int32))]
+        else:
+            facets = tags.find(np.int32(self._subdomain_id))
+        self._facets = np.asarray(facets, dtype=np.int64)
+        # facet -> (cell, opposite local vertex)
+        _, cf = mesh._entities(d - 1)
+        combos = list(itertools.combinations(range(d + 1), d))
+        opp_of_combo = np.array([[a for a in range(d + 1) if a not in c][0] for c in combos])
+        mask = np.isin(cf, self._facets)
+        fcell, fslot = np.nonzero(mask)
+        fopp = opp_of_combo[fslot]
+        # local cell index of each facet's cell (mesh-partitioned runs keep a subset of the cells)
+        if V.local_cells is not None:
+            lc = V.local_cells.cpu().numpy()
+            pos = np.searchsorted(lc, fcell)
+            ok = (pos < lc.shape[0]) & (lc[np.minimum(pos, lc.shape[0] - 1)] == fcell)
+            fcell_g, fopp, floc = fcell[ok], fopp[ok], pos[ok]
+        else:
+            fcell_g, floc = fcell, fcell
+        nf = fcell_g.shape[0]
+        self._V, self._Q = V, Q
+        self._n_facets = nf
+        # geometry of those cells: all d+1 barycentric gradients, |detJ|
+        xc = mesh.coords[mesh.cells[torch.from_numpy(fcell_g).to(dev)]]  # (nf, d+1, d)
+        J = (xc[:, 1:, :] - xc[:, :1, :]).transpose(1, 2)
+        adet = torch.linalg.det(J).abs()
+        Ginv = torch.linalg.inv(J)
+        G = torch.cat([-Ginv.sum(dim=1, keepdim=True), Ginv], dim=1)  # (nf, d+1, d)
+        # facet quadrature (degree >= 3) in the barycentric coordinates of the cell
+        from .fem import _simplex_rule
+
+        if d == 2:
+            from numpy.polynomial.legendre import leggauss
+
+            sq, wq = leggauss(3)
+            bf, wf = np.stack([(1 - sq) / 2, (1 + sq) / 2], axis=1), wq / 2
+        else:
+            bf, wf = _simplex_rule(2, 3)
+        # weights sum to 1/(d-1)!;  int_F g n_i ds = -|detJ| (grad lambda_opp)_i sum_q w_q g(x_q)
+        nq_ = bf.shape[0]
+        nvl = d + 1
+        bary = np.zeros((nf, nq_, nvl))
+        for f in range(nvl):  # facets grouped by opposite vertex
+            sel = fopp == f
+            others = [b_ for b_ in range(nvl) if b_ != f]
+            tmp = np.zeros((nq_, nvl))
+            tmp[:, others] = bf
+            bary[sel] = tmp
+        lam = torch.from_numpy(bary).to(dev)  # (nf, q, d+1)
+        psi = lam  # P1 pressure basis
+        if V.degree == 1:
+            dphi = torch.eye(nvl, dtype=torch.float64, device=dev).expand(nf, nq_, nvl, nvl)
+        else:
+            nd = V.nd
+            dphi = torch.zeros((nf, nq_, nd, nvl), dtype=torch.float64, device=dev)
+            for a in range(nvl):
+                dphi[:, :, a, a] = 4 * lam[:, :, a] - 1
+            for e, (a, b_) in enumerate(local_edges(d)):
+                dphi[:, :, nvl + e, a] = 4 * lam[:, :, b_]
+                dphi[:, :, nvl + e, b_] = 4 * lam[:, :, a]
+        grad = torch.einsum("fqrb,fbk->fqrk", dphi, G)  # (nf, q, nd_v, d)
+        ia = torch.from_numpy(fopp).to(dev)
+        Ga = G[torch.arange(nf, device=dev), ia]  # (nf, d) = grad lambda_opp;  n |F| = -|detJ| Ga
+        w = torch.from_numpy(wf).to(dev)
+        # S_i[r, c] = sum_q w_q psi_c dphi_r/dx_i * (-|detJ| Ga_i)
+        vals = torch.einsum("q,fqc,fqrk->fkrc", w, psi, grad) * (-(adet.unsqueeze(1) * Ga)).unsqueeze(2).unsqueeze(3)
+        tl = torch.from_numpy(floc).to(dev)
+        rows = V.cell_dofs[tl].to(torch.int64)  # (nf, nd_v)
+        cols = Q.cell_dofs[tl].to(torch.int64)  # (nf, d+1)
+        R = rows.unsqueeze(2).expand(-1, -1, nvl).reshape(-1)
+        Cc = cols.unsqueeze(1).expand(-1, rows.shape[1], -1).reshape(-1)
+        keep = R < V.n_owned
+        R, Cc = R[keep], Cc[keep]
+        nq_loc = Q.n_local
+        key = R * nq_loc + Cc
+        ukey, inv = torch.unique(key, return_inverse=True)
+        urow = torch.div(ukey, nq_loc, rounding_mode="floor")
+        ucol = (ukey - urow * nq_loc).to(torch.int32)
+        self._rows_b, rinv = torch.unique(urow, return_inverse=True)  # touched velocity rows
+        nrb = int(self._rows_b.shape[0])
+        row_len = torch.bincount(rinv, minlength=nrb)
+        row_ptr = torch.zeros(nrb + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:] = torch.cumsum(row_len, 0)
+        self._rows_b32 = self._rows_b.to(torch.int32)
+        self._S = []
+        if nrb > 0:
+            pat = build_sell(nrb, nq_loc, rinv, ucol, row_len, row_ptr)
+            k = torch.arange(ukey.shape[0], device=dev) - row_ptr[rinv]
+            off = pat.slice_ptr[rinv // 64] + (k // 2) * 128 + (rinv % 64) * 2 + (k % 2)
+            for i in range(d):
+                Sm = SellMatrix(pat, name=f"S{i}")
+                csr_vals = torch.zeros(ukey.shape[0], dtype=torch.float64, device=dev)
+                csr_vals.index_add_(0, inv, vals[:, i].reshape(-1)[keep])
+                Sm.vals[off] = csr_vals
+                self._S.append(Sm)
+        self._y = torch.zeros(max(nrb, 1), dtype=torch.float64, device=dev)
+        # homogeneous Dirichlet condition of the pressure correction (bcs.py:245-253)
+        mesh.topology.create_connectivity(d - 1, d)
+        dofs = locate_dofs_topological(Q, d - 1, self._facets)
+        self._dofs = np.asarray(dofs, dtype=np.int32)
+        self._dofs_dev = torch.from_numpy(self._dofs).to(dev)
+        self._zero_dev = torch.zeros(self._dofs.shape[0], dtype=torch.float64, device=dev)
+        self._bc = _BCHandle(self._dofs)
+        # nodal values of h on the facets' pressure dofs
+        self._h = torch.zeros(nq_loc, dtype=torch.float64, device=dev)
+        self._xq = np.ascontiguousarray(Q.tabulate_dof_coordinates()[self._dofs].T)
+        self._rhs = [_SurfaceForm(self, i) for i in range(d)]
+        if callable(self._value):
+            self._u = True
+        self.update_bc(force=True)
+
+    def update_bc(self, force: bool = False):
+        """Re-evaluate h (reference bcs.py:255-260 re-interpolates a callable value)."""
+        if callable(self._value):
+            if hasattr(self, "_u") or force:
+                g = np.asarray(self._value(self._xq), dtype=np.float64).reshape(-1)
+                self._h[self._dofs_dev.to(torch.int64)] = torch.from_numpy(np.ascontiguousarray(g)).to(self._h.device)
+        else:
+            v = float(self._value.value) if isinstance(self._value, Constant) else float(self._value)
+            self._h[self._dofs_dev.to(torch.int64)] = v
+
+    def add_surface_terms(self, B):
+        """B[:, i] += int_Gamma h n_i dv/dx_i ds for every component (fracstep.py:461-465)."""
+        if not callable(self._value):
+            self.update_bc()  # Constants are tracked by reference
+        lib = _lib.load()
+        st = _lib.current_stream()
+        nrb = int(self._rows_b.shape[0])
+        for i, Sm in enumerate(self._S):
+            _lib.check(lib.ox_spmv(Sm.ref(), _lib.ptr(self._h), _lib.ptr(self._y), 1, None, st), "ox_spmv")
+            _lib.check(lib.ox_scatter_add(B.ptr(), _lib.ptr(self._rows_b32), _lib.ptr(self._y), nrb, B.nc, i, 1.0, st),
+                       "ox_scatter_add")
+
+    def surface_vector_host(self, i: int) -> np.ndarray:
+        """The assembled term of component i as a full vector (tests; reference test_bcs.py:166-217)."""
+        from .fem import FieldStorage
+
+        B = FieldStorage(self._V.n_local, len(self._S) or 1, self._V.mesh.device)
+        self.add_surface_terms(B)
+        return B.host()[:, i].copy()
+
+    def apply_homogeneous(self, x: Vector):
+        """set_bc(b2, [bc]) with value 0 (fracstep.py:549-550)."""
+        s = x._s
+        _lib.check(_lib.load().ox_set_bc(s.ptr(), _lib.ptr(self._dofs_dev), _lib.ptr(self._zero_dev),
+                                        int(self._dofs.shape[0]), s.nc, 0 if x._c is None else x._c,
+                                        _lib.current_stream()), "ox_set_bc")
 
     @property
     def bc(self):
-        raise NotImplementedError
+        return self._bc
 
     def rhs(self, i: int):
-        raise NotImplementedError
+        assert i < len(self._rhs)
+        return self._rhs[i]

@@ -303,6 +303,23 @@ extern "C" int ox_set_bc(double *b, const int32_t *dofs, const double *g, int64_
   return 0;
 }
 
+__global__ void k_scatter_add(double *b, const int32_t *rows, const double *y, int64_t n, int ncomp,
+                              int comp, double scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[(int64_t)rows[i] * ncomp + comp] += scale * y[i];
+}
+
+extern "C" int ox_scatter_add(double *b, const int32_t *rows, const double *y, int64_t n, int ncomp,
+                              int comp, double scale, void *stream) {
+  if (n <= 0) return 0;
+  if (!b || !rows || !y) OX_FAIL("ox_scatter_add: null argument");
+  if (comp < 0 || comp >= ncomp) OX_FAIL("ox_scatter_add: comp=%d ncomp=%d", comp, ncomp);
+  hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ox_stream(stream),
+                     b, rows, y, n, ncomp, comp, scale);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
 __device__ __forceinline__ int64_t ox_entry(const int64_t base, int k, int lane) {
   return base + (int64_t)(k / OX_KV) * (64 * OX_KV) + lane * OX_KV + (k % OX_KV);
 }

@@ -77,8 +77,6 @@ class FractionalStep_AB_CN:
             raise NotImplementedError("pressure space must be Lagrange degree 1")
         if rotational:
             raise NotImplementedError("rotational pressure update is not implemented on the HIP path yet")
-        if len(bcs_p) > 0:
-            raise NotImplementedError("PressureBC (open boundaries) is not implemented on the HIP path yet")
         window = int((options or {}).get("sell_window", 4096))
 
         # ---- spaces (reference fracstep.py:186-216) ----------------------------------------
@@ -136,6 +134,10 @@ class FractionalStep_AB_CN:
             for bc in bc_i:
                 bc.create_bc(Vi)
         self._bcs_p = bcs_p
+        for bcp in self._bcs_p:  # reference fracstep.py:219-227
+            bcp.create_bcs(Vi, Q)
+        if len(self._bcs_p) > 0:
+            self._p_surf = [[bcp.rhs(i) for bcp in self._bcs_p] for i in range(gdim)]
 
         # ---- solvers (reference fracstep.py:229-255) -------------------------------------
         solver_options = {} if solver_options is None else solver_options
@@ -193,6 +195,12 @@ class FractionalStep_AB_CN:
         self._assemble_matrix(0, Vi, self._adj_u, self._M)  # mass        (:373)
         self._assemble_matrix(1, Vi, self._adj_u, self._K)  # stiffness   (:375)
         self._assemble_matrix(1, Q, self._adj_q, self._Ap)  # pressure Laplacian (:379)
+        if len(self._bcs_p) > 0:  # assemble_matrix(..., bcs): BC rows and columns -> identity
+            is_bc = torch.zeros(Q.n_local, dtype=torch.uint8, device=dev)
+            for bcp in self._bcs_p:
+                is_bc[bcp._dofs_dev.to(torch.int64)] = 1
+            _lib.check(lib.ox_zero_rows_cols(self._Ap.ref(), _lib.ptr(is_bc), 1.0, st), "ox_zero_rows_cols")
+            self._Ap.version += 1
         # int phi_r dx on both spaces: body force vector (:387-390), mean of phi (:585-590)
         self._wV = torch.zeros(Vi.n_owned, dtype=torch.float64, device=dev)
         self._wQ = torch.zeros(Q.n_owned, dtype=torch.float64, device=dev)
@@ -221,6 +229,10 @@ class FractionalStep_AB_CN:
                                          self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
                                          float(dt), float(nu), nb, bptr, bsl, bw, st), "ox_assemble_first")
         self._A.version += 1
+        # outlet terms int h n_i dv/dx_i ds (:445-446, :461-465)
+        for bcp in self._bcs_p:
+            bcp.update_bc()
+            bcp.add_surface_terms(self._BFIRST)
         # NOTE (reference :470): rows of the FIRST component's BCs only
         for bcu in self._bcs_u[0]:
             self._A.zero_rows(bcu._rows_dev, 1.0)
@@ -258,6 +270,8 @@ class FractionalStep_AB_CN:
                                                     _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.n_owned,
                                                     self._U.ptr(), -1.0 / float(dt), self._B2.ptr(),
                                                     _lib.current_stream()), "ox_assemble_div_vector")
+        for bcp in self._bcs_p:  # homogeneous Dirichlet condition on the correction (:549-550)
+            bcp.apply_homogeneous(self._b2.x)
 
     def pressure_solve(self, nu: float | None = None, rotational: bool = False):
         """Solve the pressure-correction problem (reference fracstep.py:553-605)."""

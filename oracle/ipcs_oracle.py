@@ -358,6 +358,59 @@ class Forms:
         be *= self.adet[:, None]
         return self._vec(be, self.vd, self.nv)
 
+    def exterior_facets(self):
+        """(cell, opposite local vertex) of every exterior facet."""
+        d = self.d
+        nvl = d + 1
+        keys, owner = [], []
+        for a in range(nvl):
+            fv = np.sort(np.delete(self.cells, a, axis=1), axis=1)
+            k = np.zeros(fv.shape[0], dtype=np.int64)
+            for j in range(d):
+                k = k * np.int64(self.coords.shape[0]) + fv[:, j]
+            keys.append(k)
+            owner.append(np.stack([np.arange(self.cells.shape[0]), np.full(self.cells.shape[0], a)], axis=1))
+        keys = np.concatenate(keys)
+        owner = np.concatenate(owner)
+        uniq, idx, cnt = np.unique(keys, return_index=True, return_counts=True)
+        ext = idx[cnt == 1]
+        return owner[ext, 0], owner[ext, 1]
+
+    def facet_midpoints(self, fc, fa):
+        x = self.coords[self.cells[fc]]  # (nf, d+1, d)
+        mask = np.ones((fc.shape[0], self.d + 1), dtype=bool)
+        mask[np.arange(fc.shape[0]), fa] = False
+        return x[mask].reshape(fc.shape[0], self.d, self.d).mean(axis=1)
+
+    def pressure_surface_vec(self, fc, fa, h, i):
+        """int_Gamma h n_i dv/dx_i ds over the facets (cell fc, opposite vertex fa); h is a vector
+        of Q-dof values (reference bcs.py:226-242, fracstep.py:461-465)."""
+        d = self.d
+        bf, wf = simplex_quadrature(d - 1, 3) if d > 2 else (None, None)
+        if d == 2:
+            from numpy.polynomial.legendre import leggauss
+            s, w = leggauss(3)
+            bf = np.stack([(1 - s) / 2, (1 + s) / 2], axis=1)
+            wf = w / 2
+        out = np.zeros(self.nv)
+        for f in range(fc.shape[0]):
+            c, a = fc[f], fa[f]
+            others = [b for b in range(d + 1) if b != a]
+            bary = np.zeros((bf.shape[0], d + 1))
+            bary[:, others] = bf
+            phi_q, _ = tabulate(d, self.p_deg, bary)
+            _, dphi = tabulate(d, self.u_deg, bary)
+            G = self.G[c]
+            gnorm = np.linalg.norm(G[a])
+            n = -G[a] / gnorm
+            area = self.adet[c] * gnorm  # x (d-1)! folded into the rule's weights below
+            hq = phi_q @ h[self.qd[c]]
+            gi = np.einsum("qrb,b->qr", dphi, G[:, i])
+            fac = math.factorial(d - 1)
+            out_c = np.einsum("q,q,qr->r", wf * fac, hq, gi) * n[i] * area / fac
+            np.add.at(out, self.vd[c], out_c)
+        return out
+
     def volume(self):
         """assemble_scalar(1*dx) (reference fracstep.py:581-584)."""
         return float(self.adet.sum() / math.factorial(self.d))
@@ -548,6 +601,33 @@ class DirichletData:
         b[self.dofs] = self.g[self.dofs]
 
 
+class PressureData:
+    """Natural pressure condition on a set of exterior facets (reference bcs.py:142-268):
+    value h (float or callable on x) enters b_first_i as int h n_i dv/dx_i ds, and the pressure
+    correction gets a homogeneous Dirichlet condition on the facets' Q dofs."""
+
+    def __init__(self, facet_cells, facet_opp, value):
+        self.fc, self.fa, self.value = np.asarray(facet_cells), np.asarray(facet_opp), value
+        self.dofs = None
+        self.h = None
+
+    def create(self, F, x_q):
+        d = F.d
+        dofs = []
+        for c, a in zip(self.fc, self.fa):
+            dofs.extend(F.qd[c][[b for b in range(d + 1) if b != a]])
+        self.dofs = np.unique(np.asarray(dofs, dtype=np.int64))
+        self.update(x_q)
+
+    def update(self, x_q):
+        if callable(self.value):
+            X = np.zeros((3, x_q.shape[0]))
+            X[: x_q.shape[1]] = x_q.T
+            self.h = np.asarray(self.value(X), dtype=np.float64)
+        else:
+            self.h = np.full(x_q.shape[0], float(self.value))
+
+
 class OracleFractionalStep:
     """Restatement of reference fracstep.py:149-705 (``FractionalStep_AB_CN``)
     for Dirichlet-only velocity BCs and no pressure BC (all BASELINE configs).
@@ -556,7 +636,7 @@ class OracleFractionalStep:
     ``_u[i].x.array``."""
 
     def __init__(self, forms: Forms, x_v, x_q, bcs_u, solver_options=None, body_force=None,
-                 low_memory=True):
+                 low_memory=True, bcs_p=None):
         self.F = forms
         d = forms.d
         self.d = d
@@ -586,6 +666,16 @@ class OracleFractionalStep:
         self.M = forms.mass_v()
         self.K = forms.stiffness_v()
         self.Ap = forms.stiffness_q()
+        self.bcs_p = list(bcs_p or [])
+        for bp in self.bcs_p:
+            bp.create(forms, x_q)
+        if self.bcs_p:  # assemble_matrix(Ap, bcs): rows and columns -> identity (fracstep.py:379)
+            pd = np.unique(np.concatenate([bp.dofs for bp in self.bcs_p]))
+            keep = np.ones(nq)
+            keep[pd] = 0.0
+            D = sp.diags(keep)
+            self.Ap = (D @ self.Ap @ D + sp.diags(1.0 - keep)).tocsr()
+            self.p_bc_dofs = pd
         self.b0 = np.stack([forms.body_force_vec(float(f[i])) for i in range(d)], axis=1)
         if not low_memory:
             self.P = [forms.p_vdxi_mat(i) for i in range(d)]
@@ -603,8 +693,12 @@ class OracleFractionalStep:
         self.uab[:] = 1.5 * self.u1 - 0.5 * self.u2
         C = self.F.convection(self.uab)
         A = -0.5 * C + (1.0 / dt) * self.M + (-0.5 * nu) * self.K
+        for bp in self.bcs_p:  # fracstep.py:445-446
+            bp.update(self.x_q)
         for i in range(self.d):
             self.b_first[:, i] = A @ self.u1[:, i] + self.b0[:, i]
+            for bp in self.bcs_p:  # fracstep.py:461-465
+                self.b_first[:, i] += self.F.pressure_surface_vec(bp.fc, bp.fa, bp.h, i)
         A = -A + (2.0 / dt) * self.M
         A = A.tolil()
         for bc in self.bcs_u[0]:  # bcs_u[0] ONLY (fracstep.py:470-472)
@@ -647,9 +741,18 @@ class OracleFractionalStep:
         else:
             self.b2[:] = sum(self.D[i] @ self.u[:, i] for i in range(self.d))
         self.b2 *= -1.0 / dt
+        if self.bcs_p:  # set_bc(b2, bcs_p): homogeneous (fracstep.py:549-550)
+            self.b2[self.p_bc_dofs] = 0.0
 
-    # fracstep.py:553-605 (no pressure BC: constant null space)
+    # fracstep.py:553-605
     def pressure_solve(self):
+        if self.bcs_p:  # non-singular: plain solve, no mean handling
+            x = self.dp.copy()
+            reason = self.solver_p.solve(self.b2, x)
+            self.dp[:] = x
+            self.its["pressure"] = self.solver_p.its
+            self.ps[:] = self.p + self.dp
+            return reason
         self.b2 -= self.b2.mean()  # nullspace.remove (fracstep.py:573-574)
         if self.solver_p.ksp_type == "preonly":
             # MUMPS with null-pivot detection (fracstep.py:564-571) returns *a*

@@ -1,0 +1,135 @@
+"""GPU: open boundaries (PressureBC) -- reference test/test_bcs.py:166-217 and the complete
+reference test/test_tentative_velocity.py set-up (inlet, walls, pressure outlet), against the
+oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _facet_pairs(F, mesh, facets):
+    """(cell, opposite vertex) pairs of product facet ids, for the oracle."""
+    import itertools
+
+    d = mesh.gdim
+    _, cf = mesh._entities(d - 1)
+    combos = list(itertools.combinations(range(d + 1), d))
+    opp = np.array([[a for a in range(d + 1) if a not in c][0] for c in combos])
+    fcell, fslot = np.nonzero(np.isin(cf, facets))
+    return fcell, opp[fslot]
+
+
+@pytest.mark.parametrize("dim,P", [(2, 1), (2, 2), (3, 1), (3, 2)])
+@pytest.mark.parametrize("kind", ["const", "callable"])
+def test_pressure_condition(hip, dim, P, kind):
+    """PressureBC.rhs(i) assembles int h n_i dv/dx_i ds; .bc holds the tagged pressure dofs."""
+    from oasisx_amd import PressureBC, fem
+    from oasisx_amd import mesh as M
+    from oracle import ipcs_oracle as O
+
+    mesh = (M.create_unit_square(None, 6, 5) if dim == 2 else M.create_unit_cube(None, 3, 3, 2))
+    V, Q = fem.FunctionSpace(mesh, P, window=64), fem.FunctionSpace(mesh, 1, window=64)
+    fd = dim - 1
+    facets = M.locate_entities_boundary(mesh, fd, lambda x: np.isclose(x[0], 1.0))
+    tags = M.meshtags(mesh, fd, facets, np.full(facets.shape, 2, dtype=np.int32))
+    hfun = (lambda x: 1.0 + 2 * x[1] - x[dim - 1] ** 1) if kind == "callable" else None
+    bc = PressureBC(hfun if hfun else 4.0, (tags, 2))
+    bc.create_bcs(V, Q)
+    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), P, 1, vd=V.cell_dofs.cpu().numpy(),
+                qd=Q.cell_dofs.cpu().numpy(), nv_dofs=V.num_dofs, nq_dofs=Q.num_dofs)
+    fc, fa = _facet_pairs(F, mesh, facets)
+    xq = Q.x.cpu().numpy()
+    X = np.zeros((3, xq.shape[0]))
+    X[:dim] = xq.T
+    h = hfun(X) if hfun else np.full(xq.shape[0], 4.0)
+    for i in range(dim):
+        ref = F.pressure_surface_vec(fc, fa, h, i)
+        got = bc.surface_vector_host(i)
+        assert np.abs(got - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max()), i
+        assert bc.rhs(i).rank == 1
+    exp_dofs = np.nonzero(np.isclose(xq[:, 0], 1.0))[0]
+    assert (np.sort(bc.bc._cpp_object.dof_indices()[0]) == exp_dofs).all()
+
+
+@pytest.mark.parametrize("low_memory", [True, False])
+@pytest.mark.parametrize("body_force", [True, False])
+@pytest.mark.parametrize("u_deg", [1, 2])
+def test_tentative_with_outlet(hip, low_memory, body_force, u_deg):
+    """The reference's test_tentative set-up (10x10 unit square, dt 0.1, nu 0.5, sin inlet,
+    no-slip walls, PressureBC(4.0) outlet), then a full solve() to cover the pressure Dirichlet
+    path: A, rhs1 and the fields after a step equal the oracle's."""
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+    from oracle import ipcs_oracle as O
+    from tests.helpers import KRYLOV
+
+    dt, nu = 0.1, 0.5
+    mesh = M.create_unit_square(None, 10, 10)
+    fd = 1
+    left = M.locate_entities_boundary(mesh, fd, lambda x: np.isclose(x[0], 0))
+    tb = M.locate_entities_boundary(mesh, fd, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1))
+    right = M.locate_entities_boundary(mesh, fd, lambda x: np.isclose(x[0], 1))
+    facets = np.hstack([left, tb, right])
+    values = np.hstack([np.full_like(left, 1), np.full_like(tb, 2), np.full_like(right, 3)]).astype(np.int32)
+    srt = np.argsort(facets)
+    tags = M.meshtags(mesh, fd, facets[srt], values[srt])
+    clock = {"t": 0.0}
+    inlet = lambda x: (1 + clock["t"]) * np.sin(np.pi * x[1])  # noqa: E731
+    bc_tb = ox.DirichletBC(0.0, ox.LocatorMethod.TOPOLOGICAL, (tags, 2))
+    bc_in_x = ox.DirichletBC(inlet, ox.LocatorMethod.TOPOLOGICAL, (tags, 1))
+    bc_in_y = ox.DirichletBC(0.0, ox.LocatorMethod.TOPOLOGICAL, (tags, 1))
+    f = (0.3, -0.1) if body_force else None
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", u_deg), ("Lagrange", 1), bcs_u=[[bc_in_x, bc_tb], [bc_in_y, bc_tb]],
+                                bcs_p=[ox.PressureBC(4.0, (tags, 3))], solver_options=KRYLOV, body_force=f,
+                                options={"low_memory_version": low_memory, "sell_window": 128})
+    Vi, Q = S._Vi[0][0], S._Q
+    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), u_deg, 1, vd=Vi.cell_dofs.cpu().numpy(),
+                qd=Q.cell_dofs.cpu().numpy(), nv_dofs=Vi.num_dofs, nq_dofs=Q.num_dofs)
+    xv = Vi.x.cpu().numpy()
+    ld = np.nonzero(np.isclose(xv[:, 0], 0))[0]
+    td = np.nonzero(np.isclose(xv[:, 1], 0) | np.isclose(xv[:, 1], 1))[0]
+    rclock = {"t": 0.0}
+    obcs = [[O.DirichletData(ld, lambda x: (1 + rclock["t"]) * np.sin(np.pi * x[1])), O.DirichletData(td, 0.0)],
+            [O.DirichletData(ld, 0.0), O.DirichletData(td, 0.0)]]
+    fc, fa = _facet_pairs(F, mesh, right)
+    R = O.OracleFractionalStep(F, xv, Q.x.cpu().numpy(), obcs, solver_options=KRYLOV, body_force=f,
+                               low_memory=low_memory, bcs_p=[O.PressureData(fc, fa, 4.0)])
+    X = np.zeros((3, xv.shape[0]))
+    X[:2] = xv.T
+    for i in range(2):
+        for t, (a, b) in ((-2 * dt, (S._u2, R.u2)), (-dt, (S._u1, R.u1))):
+            clock["t"] = t
+            a[i].interpolate(inlet)
+            b[:, i] = (1 + t) * np.sin(np.pi * X[1])
+    S._ps.interpolate(lambda x: x[1])
+    S._p.interpolate(lambda x: x[1])
+    R.ps[:] = Q.x.cpu().numpy()[:, 1]
+    R.p[:] = R.ps
+    clock["t"] = rclock["t"] = dt
+    for bcl in S._bcs_u:
+        for bc in bcl:
+            bc.update_bc()
+    for bcl in R.bcs_u:
+        for bc in bcl:
+            bc.update(R.x_v)
+    S.assemble_first(dt, nu)
+    R.assemble_first(dt, nu)
+    S.velocity_tentative_assemble()
+    R.velocity_tentative_assemble()
+    assert abs(S._A.to_scipy() - R.A).max() <= 1e-12 * abs(R.A).max()
+    diff, errors = S.velocity_tentative_solve()
+    rdiff, rerrors = R.velocity_tentative_solve()
+    assert (errors > 0).all()
+    rhs1 = np.stack([g.x.array for g in S._rhs1], axis=1)
+    assert np.abs(rhs1 - R.rhs1).max() <= 1e-12 * np.abs(R.rhs1).max()
+    # the rest of the step: pressure correction with the homogeneous Dirichlet outlet
+    assert abs(S._Ap.to_scipy() - R.Ap).max() <= 1e-12 * abs(R.Ap).max()
+    S.pressure_assemble(dt)
+    R.pressure_assemble(dt)
+    # b2 depends on the Krylov-solved tentative velocity (rtol 1e-11), scaled by 1/dt and 1/h
+    assert np.abs(S._b2.x.array - R.b2).max() <= 1e-8 * np.abs(R.b2).max()
+    assert S.pressure_solve(nu=nu) > 0 and R.pressure_solve() > 0
+    S.velocity_update(dt)
+    R.velocity_update(dt)
+    u = S.u.x.array.reshape(-1, 2)
+    assert np.abs(u - R.u).max() < 1e-8 and np.abs(S._ps.x.array - R.ps).max() < 1e-7
