@@ -45,6 +45,27 @@ def _degree(element):
     return int(element[1])
 
 
+class _RotationalUpdate:
+    """The linear form int (p + dp - xi nu div(u)) q dx of the rotational pressure update
+    (reference fracstep.py:240): M_Q (p + dp) - xi nu int div(u) q."""
+
+    def __init__(self, solver):
+        self.s = solver
+
+    def assemble_rhs_into(self, B):
+        s = self.s
+        lib, st = s._lib, _lib.current_stream()
+        Vi, Q = s._Vi[0][0], s._Q
+        nq = s._n_q
+        tmp = s._B2  # free at this point of the step: the pressure system has been solved
+        _lib.check(lib.ox_axpby(nq, 1.0, s._P.ptr(), 1.0, s._DP.ptr(), tmp.ptr(), st), "ox_axpby")
+        s._projector_p._A.mult(tmp.dev(), B.dev(), 1)
+        _lib.check(lib.ox_assemble_div_vector(Q.degree, Vi.degree, C.byref(s._cells), _lib.ptr(Vi.cell_dofs),
+                                              C.byref(s._adj_q), Q.n_owned, s._U.ptr(), 1.0, tmp.ptr(), st),
+                   "ox_assemble_div_vector")
+        _lib.check(lib.ox_axpby(Q.n_owned, 1.0, B.ptr(), -s._xi * s._nu, tmp.ptr(), B.ptr(), st), "ox_axpby")
+
+
 class FractionalStep_AB_CN:
     """
     Create the fractional step solver with Adam-Bashforth linearization
@@ -56,7 +77,7 @@ class FractionalStep_AB_CN:
         p_element: ``("Lagrange", 1)`` for the pressure
         bcs_u: list of Dirichlet BCs for each component of the velocity
         bcs_p: list of pressure BCs
-        rotational: rotational pressure update (not implemented on the HIP path yet)
+        rotational: If True, use rotational form of pressure update
         solver_options: dict with keys ``'tentative'``, ``'pressure'``, ``'scalar'`` leading
             to PETSc-style option dicts (see :mod:`oasisx_amd.ksp`)
         jit_options: accepted for compatibility, ignored (nothing is JIT compiled)
@@ -75,8 +96,6 @@ class FractionalStep_AB_CN:
         u_deg, p_deg = _degree(u_element), _degree(p_element)
         if p_deg != 1:
             raise NotImplementedError("pressure space must be Lagrange degree 1")
-        if rotational:
-            raise NotImplementedError("rotational pressure update is not implemented on the HIP path yet")
         window = int((options or {}).get("sell_window", 4096))
 
         # ---- spaces (reference fracstep.py:186-216) ----------------------------------------
@@ -144,7 +163,10 @@ class FractionalStep_AB_CN:
         self._solver_u = KSPSolver(mesh.comm, solver_options.get("tentative"), prefix="tentative_velocity")
         self._solver_p = KSPSolver(mesh.comm, solver_options.get("pressure"), prefix="pressure_correction")
         self._solver_c = KSPSolver(mesh.comm, solver_options.get("scalar"), prefix="velocity_update")
+        self._rotational = bool(rotational)
         self._projector_p = None
+        self._xi = 0.5 if rotational else None  # reference fracstep.py:238
+        self._nu = 1.0 if rotational else None
 
         if options is None:
             options = {}
@@ -156,6 +178,11 @@ class FractionalStep_AB_CN:
         self._compile_and_allocate_forms()
         self._preassemble()
 
+        if self._rotational:  # Projector(p + dp - xi nu div(u), Q) (fracstep.py:237-247)
+            from .function import Projector
+
+            self._projector_p = Projector(_RotationalUpdate(self), Q, bcs=[],
+                                          petsc_options=solver_options.get("scalar"), jit_options=jit_options)
         # reference fracstep.py:270-275
         self._solver_p.setOperators(self._Ap)
         self._solver_p.setOptions(self._Ap)
@@ -288,8 +315,16 @@ class FractionalStep_AB_CN:
             # dp -= (int dp dx) / (int 1 dx) (:579-591)
             _lib.check(lib.ox_remove_mean(nqo, nq, self._DP.ptr(), _lib.ptr(self._wQ), self._vol, self._dq, st),
                        "ox_remove_mean")
-        # ps = p + dp (:604)
-        _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 1.0, self._DP.ptr(), self._PS.ptr(), st), "ox_axpby")
+        if self._projector_p is not None:  # rotational update (:593-602)
+            if nu is None:
+                raise RuntimeWarning("Kinematic viscosity not set for rotational pressure correction")
+            self._nu = float(nu)
+            error = self._projector_p.solve(assemble_rhs=True)
+            assert int(error) > 0
+            _lib.check(lib.ox_axpby(nq, 1.0, self._projector_p._X.ptr(), 0.0, None, self._PS.ptr(), st), "ox_axpby")
+        else:
+            # ps = p + dp (:604)
+            _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 1.0, self._DP.ptr(), self._PS.ptr(), st), "ox_axpby")
         return converged
 
     def velocity_update(self, dt) -> np.ndarray:

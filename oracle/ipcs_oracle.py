@@ -636,7 +636,7 @@ class OracleFractionalStep:
     ``_u[i].x.array``."""
 
     def __init__(self, forms: Forms, x_v, x_q, bcs_u, solver_options=None, body_force=None,
-                 low_memory=True, bcs_p=None):
+                 low_memory=True, bcs_p=None, rotational=False):
         self.F = forms
         d = forms.d
         self.d = d
@@ -660,6 +660,12 @@ class OracleFractionalStep:
         self.solver_u = OracleKSP(so.get("tentative"))
         self.solver_p = OracleKSP(so.get("pressure"))
         self.solver_c = OracleKSP(so.get("scalar"))
+        self.rotational = rotational
+        if rotational:  # Projector(p + dp - xi nu div u, Q) with the "scalar" options (fracstep.py:237-247)
+            self.Mq = forms.mass_q()
+            self.solver_proj = OracleKSP(so.get("scalar"))
+            self.solver_proj.set_operator(self.Mq)
+            self.xi = 0.5
         self.low_memory = low_memory
         f = (0.0,) * d if body_force is None else body_force
         # _preassemble (fracstep.py:360-409)
@@ -745,13 +751,24 @@ class OracleFractionalStep:
             self.b2[self.p_bc_dofs] = 0.0
 
     # fracstep.py:553-605
-    def pressure_solve(self):
+    def _update_ps(self, nu):
+        if self.rotational:  # fracstep.py:593-602
+            if nu is None:
+                raise RuntimeWarning("Kinematic viscosity not set for rotational pressure correction")
+            rhs = self.Mq @ (self.p + self.dp) - self.xi * nu * self.F.divu_vec(self.u)
+            x = np.zeros_like(self.ps)
+            assert self.solver_proj.solve(rhs, x) > 0
+            self.ps[:] = x
+        else:
+            self.ps[:] = self.p + self.dp  # fracstep.py:604
+
+    def pressure_solve(self, nu=None):
         if self.bcs_p:  # non-singular: plain solve, no mean handling
             x = self.dp.copy()
             reason = self.solver_p.solve(self.b2, x)
             self.dp[:] = x
             self.its["pressure"] = self.solver_p.its
-            self.ps[:] = self.p + self.dp
+            self._update_ps(nu)
             return reason
         self.b2 -= self.b2.mean()  # nullspace.remove (fracstep.py:573-574)
         if self.solver_p.ksp_type == "preonly":
@@ -773,7 +790,7 @@ class OracleFractionalStep:
             self.its["pressure"] = self.solver_p.its
         phi_avg = self.F.integral_q(self.dp) / self.vol  # fracstep.py:579-591
         self.dp -= phi_avg
-        self.ps[:] = self.p + self.dp  # fracstep.py:604
+        self._update_ps(nu)
         return reason
 
     # fracstep.py:607-658 (un-BC'd M, no BC re-imposition)
@@ -809,7 +826,7 @@ class OracleFractionalStep:
             diff, errors = self.velocity_tentative_solve()
             assert (errors > 0).all()
             self.pressure_assemble(dt)
-            error_p = self.pressure_solve()
+            error_p = self.pressure_solve(nu)
             assert int(error_p) > 0
         self.velocity_update(dt)
         self.u2[:] = self.u1
@@ -852,7 +869,7 @@ def boundary_dofs(xdofs, p0, p1, tol=1e-10):
 
 def taylor_green_problem(N, dim=2, u_deg=2, p_deg=1, nu=0.01, dt=0.005, t0=0.0,
                          solver_options=None, low_memory=True, mesh=None, vd=None, qd=None,
-                         x_v=None, x_q=None):
+                         x_v=None, x_q=None, rotational=False):
     """Set up the demo's problem (demo/taylor_green.py:104-182): exact Dirichlet
     velocity on every exterior facet, no pressure BC, u2(t0-dt), u1(t0), p(t0-dt/2).
     Returns (solver, clock) where clock['t'] is the time the BC callables read."""
@@ -876,7 +893,7 @@ def taylor_green_problem(N, dim=2, u_deg=2, p_deg=1, nu=0.01, dt=0.005, t0=0.0,
     bd = boundary_dofs(x_v, lo, hi)
     bcs_u = [[DirichletData(bd, (lambda x, f=f: f(x, clock["t"], nu)))] for f in fns]
     S = OracleFractionalStep(F, x_v, x_q, bcs_u, solver_options=solver_options,
-                             low_memory=low_memory)
+                             low_memory=low_memory, rotational=rotational)
     X = np.zeros((3, x_v.shape[0]))
     X[:d] = x_v.T
     Xq = np.zeros((3, x_q.shape[0]))

@@ -33,7 +33,7 @@ def on_boundary3(x):
 
 
 def make_hip_problem(dim, N, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=None, window=256,
-                     body_force=None):
+                     body_force=None, rotational=False):
     """FractionalStep_AB_CN on the HIP path with the demo's set-up
     (reference demo/taylor_green.py:104-182)."""
     import oasisx_amd as ox
@@ -46,7 +46,7 @@ def make_hip_problem(dim, N, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=
              for f in fns]
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", u_deg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                 solver_options=solver_options or KRYLOV, body_force=body_force,
-                                options={"sell_window": window})
+                                options={"sell_window": window}, rotational=rotational)
     for i, f in enumerate(fns):
         S._u2[i].interpolate(lambda x, f=f: f(x, t0 - dt, nu))
         S._u1[i].interpolate(lambda x, f=f: f(x, t0, nu))
@@ -54,19 +54,20 @@ def make_hip_problem(dim, N, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=
     return S, clock, mesh
 
 
-def make_oracle_twin(S, mesh, dim, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=None):
+def make_oracle_twin(S, mesh, dim, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=None, rotational=False):
     """The CPU oracle on the product's mesh arrays and dof numbering."""
     Vi, Q = S._Vi[0][0], S._Q
     return O.taylor_green_problem(
         0, dim, u_deg=u_deg, p_deg=1, nu=nu, dt=dt, t0=t0, solver_options=solver_options or KRYLOV,
         mesh=(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy()),
         vd=Vi.cell_dofs.cpu().numpy(), qd=Q.cell_dofs.cpu().numpy(),
-        x_v=Vi.x.cpu().numpy(), x_q=Q.x.cpu().numpy())
+        x_v=Vi.x.cpu().numpy(), x_q=Q.x.cpu().numpy(), rotational=rotational)
 
 
-def run_tg_pair(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, hip_options=None, oracle_options=None):
-    S, clock, mesh = make_hip_problem(dim, N, u_deg, nu, dt, solver_options=hip_options)
-    R, rclock = make_oracle_twin(S, mesh, dim, u_deg, nu, dt, solver_options=oracle_options)
+def run_tg_pair(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, hip_options=None, oracle_options=None,
+                rotational=False):
+    S, clock, mesh = make_hip_problem(dim, N, u_deg, nu, dt, solver_options=hip_options, rotational=rotational)
+    R, rclock = make_oracle_twin(S, mesh, dim, u_deg, nu, dt, solver_options=oracle_options, rotational=rotational)
     t = 0.0
     for _ in range(steps):
         t += dt

@@ -147,3 +147,33 @@ def test_full_steps_match_oracle_lu(hip):
 
     r = run_tg_pair(2, 8, 2, steps=3, hip_options=LU, oracle_options=LU)
     assert r["du"] < 1e-8 and r["dp"] < 1e-7, (r["du"], r["dp"])
+
+
+@pytest.mark.parametrize("dim,N", [(2, 8), (3, 4)])
+def test_rotational_pressure_update(hip, dim, N):
+    """rotational=True (reference fracstep.py:237-251,593-602): ps = Proj_Q(p + dp - xi nu div u)."""
+    from tests.helpers import run_tg_pair
+
+    r = run_tg_pair(dim, N, 2, steps=2, rotational=True)
+    assert r["du"] < 1e-8 and r["dp"] < 1e-7, (r["du"], r["dp"])
+    plain = run_tg_pair(dim, N, 2, steps=2, rotational=False)
+    assert np.abs(r["R"].p - plain["R"].p).max() > 1e-6  # the rotational term does change p
+
+
+def test_projector_of_a_function(hip):
+    """Projector(Function, space): the L2 projection of a field of the space is the field
+    (reference test/test_projector.py checks exactness for representable targets, atol 1e-12)."""
+    from oasisx_amd import Projector, fem
+    from tests.helpers import tg_mesh
+
+    mesh = tg_mesh(2, 10)
+    V = fem.FunctionSpace(mesh, 2, window=128)
+    u = fem.Function(V)
+    u.interpolate(lambda x: x[0] * x[0] + 3 * x[1] + 2 * x[1] * x[1])
+    proj = Projector(u, V, [], petsc_options={"ksp_type": "preonly", "pc_type": "lu"})
+    assert proj.solve() > 0
+    assert np.abs(proj.x.x.array - u.x.array).max() < 1e-10
+    u.interpolate(lambda x: x[0] + 2 * x[1] * x[1])
+    proj.assemble_rhs()
+    assert proj.solve(assemble_rhs=False) > 0
+    assert np.abs(proj.x.x.array - u.x.array).max() < 1e-10
