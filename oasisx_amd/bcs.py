@@ -178,13 +178,11 @@ class PressureBC:
         fcell, fslot = np.nonzero(mask)
         fopp = opp_of_combo[fslot]
         # local cell index of each facet's cell (mesh-partitioned runs keep a subset of the cells)
-        if V.local_cells is not None:
-            lc = V.local_cells.cpu().numpy()
-            pos = np.searchsorted(lc, fcell)
-            ok = (pos < lc.shape[0]) & (lc[np.minimum(pos, lc.shape[0] - 1)] == fcell)
-            fcell_g, fopp, floc = fcell[ok], fopp[ok], pos[ok]
-        else:
-            fcell_g, floc = fcell, fcell
+        lc = V.local_cells.cpu().numpy()  # kernel-side cell order (and, partitioned, a subset)
+        srt = np.argsort(lc)
+        pos = np.searchsorted(lc[srt], fcell)
+        ok = (pos < lc.shape[0]) & (lc[srt][np.minimum(pos, lc.shape[0] - 1)] == fcell)
+        fcell_g, fopp, floc = fcell[ok], fopp[ok], srt[pos[ok]]
         nf = fcell_g.shape[0]
         self._V, self._Q = V, Q
         self._n_facets = nf

@@ -3,6 +3,7 @@
 // slice mapping.  No MFMA: the path is sparse and HBM-bound.
 #include "ox_common.h"
 #include "ox_kernels.h"
+#include <stdlib.h>
 
 thread_local char ox_err_buf[512] = "";
 
@@ -28,7 +29,7 @@ extern "C" int ox_device_info(int *n_cu, char *name, int name_len) {
 // loads 16 B of values + 8 B of columns (coalesced over the wave: 1 KiB + 512 B) and gathers
 // NC doubles of x per entry.  EPI selects the fused epilogue the Krylov loops need.
 // ---------------------------------------------------------------------------------------
-template <int NC, int EPI>
+template <int NC, int EPI, int VAR>
 __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restrict__ x,
                                               double *__restrict__ y,
                                               const double *__restrict__ dinv,
@@ -62,16 +63,38 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
     const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);  // width / OX_KV
     const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
     const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
-#pragma unroll 4
-    for (int k = 0; k < npair; ++k) {
-      const double2 v = vp[(size_t)k * 64];
-      const int2 c = cp[(size_t)k * 64];
+    auto body = [&](int k) {
+      double2 v;
+      int2 c;
+      if (VAR & 1) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2d vv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(vp + (size_t)k * 64));
+        const v2i ci = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(cp + (size_t)k * 64));
+        v.x = vv.x;
+        v.y = vv.y;
+        c.x = ci.x;
+        c.y = ci.y;
+      } else {
+        v = vp[(size_t)k * 64];
+        c = cp[(size_t)k * 64];
+      }
       const double *x0 = x + (size_t)c.x * NC;
       const double *x1 = x + (size_t)c.y * NC;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.x, x0[cc], acc[cc]);
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
+    };
+    if (VAR & 4) {
+#pragma unroll 16
+      for (int k = 0; k < npair; ++k) body(k);
+    } else if (VAR & 2) {
+#pragma unroll 8
+      for (int k = 0; k < npair; ++k) body(k);
+    } else {
+#pragma unroll 4
+      for (int k = 0; k < npair; ++k) body(k);
     }
     if (row < A.n_rows) {
       if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
@@ -101,16 +124,35 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   }
 }
 
+#define OX_SPMV_DEFAULT_VARIANT 1  // nontemporal matrix stream (measured: tools/spmv_bench.py)
+static int g_spmv_variant = -1;
+extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
+  g_spmv_variant = v & 7;
+  return 0;
+}
+
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
                    hipStream_t st) {
   const int nblk = ox_spmv_blocks(A);
   if (nblk == 0) return 0;
+  if (g_spmv_variant < 0) {
+    const char *e = getenv("OX_SPMV_VARIANT");
+    g_spmv_variant = e ? atoi(e) & 7 : OX_SPMV_DEFAULT_VARIANT;
+  }
+  const int var = g_spmv_variant;
+#define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
+  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st);                                      \
-    hipLaunchKernelGGL((k_spmv<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, \
-                       done);                                                                   \
+    switch (var) {                                                                              \
+      case 1: OX_SPMV_LAUNCH(NC, E, 1); break;                                                  \
+      case 2: OX_SPMV_LAUNCH(NC, E, 2); break;                                                  \
+      case 3: OX_SPMV_LAUNCH(NC, E, 3); break;                                                  \
+      case 5: OX_SPMV_LAUNCH(NC, E, 5); break;                                                  \
+      default: OX_SPMV_LAUNCH(NC, E, 0); break;                                                 \
+    }                                                                                           \
     if (ox_prof_on) ox_prof_stop(st);                                                           \
     OX_LAUNCH_CHECK();                                                                          \
     return 0;                                                                                   \

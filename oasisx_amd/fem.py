@@ -2,8 +2,8 @@
 
 A ``FunctionSpace`` owns, as torch tensors on the setup device:
 
-* the cell->dof table in the FINAL dof numbering.  Dofs are first ordered lexicographically
-  by coordinate (z, y, x) for gather locality and then, inside windows of ``window`` rows,
+* the cell->dof table in the FINAL dof numbering.  Dofs are first ordered by (tile_z, tile_y, z, y, x)
+  (``locality_key``) for gather coalescing + L2 locality and then, inside windows of ``window`` rows,
   stably by decreasing row length: the numbering itself is the SELL-64 row order, so a
   wave's 64 rows have (nearly) equal length and equal cell counts -- no padding waste, no
   divergence, no row permutation at run time;
@@ -33,6 +33,30 @@ default_scalar_type = np.float64
 
 def local_edges(gdim: int):
     return [(1, 2), (0, 2), (0, 1)] if gdim == 2 else [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+
+
+TILE_BITS = 4  # 2^4 = 16 tiles per direction in y and z
+
+
+def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bits: int = TILE_BITS,
+                 bits: int = 18) -> torch.Tensor:
+    """Ordering key of points: (tile_z, tile_y, z, y, x) -- lexicographic inside tiles that span the
+    whole x extent and 1/2^tile_bits of the y and z extents.
+
+    * whole x-lines stay contiguous, so the 64 rows of a wave (and their neighbours' columns) are
+      consecutive: the x gathers of a wave-instruction coalesce;
+    * rows that an XCD works on at one time (~65 K P2 rows at 128^3) form one compact y-z tile, so
+      their gather footprint (tile + halo, ~2.5 MB) fits the 4 MiB L2 instead of ~5 whole lattice
+      planes (8 MB) under plane-by-plane lexicographic order.
+    A full Z-order (Morton) curve was measured 15 % slower: it destroys the coalescing."""
+    d = x.shape[1]
+    q = torch.round((x - lo) / span * float((1 << bits) - 1)).to(torch.int64)
+    key = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+    for k in range(d - 1, 0, -1):  # tile index of the slow directions, slowest first
+        key = (key << tile_bits) | (q[:, k] >> (bits - tile_bits))
+    for k in range(d - 1, -1, -1):
+        key = (key << bits) | q[:, k]
+    return key
 
 
 def cell_geometry(mesh: Mesh, cell_ids=None) -> torch.Tensor:
@@ -175,12 +199,14 @@ class FunctionSpace:
         nverts = mesh.num_vertices
         rank = 0 if part is None else part.rank
         # ---- 1. global initial dof ids: vertices, then edges; restricted to the local cells ----
-        if part is None:
-            cells = mesh.cells
-            self.local_cells = None
-        else:
-            self.local_cells = part.local_cells
-            cells = mesh.cells[part.local_cells]
+        lo = mesh.coords.min(dim=0).values
+        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
+        cell_ids = torch.arange(mesh.num_cells, device=dev) if part is None else part.local_cells
+        ckey = locality_key(mesh.coords[mesh.cells[cell_ids]].mean(dim=1), lo, span)
+        # kernel-side cell order: tiled order of the centroids (index i of every per-cell array = this list's i)
+        self.local_cells = cell_ids[torch.argsort(ckey, stable=True)]
+        del ckey
+        cells = mesh.cells[self.local_cells]
         nc = int(cells.shape[0])
         if degree == 1:
             cd0g = cells
@@ -197,7 +223,7 @@ class FunctionSpace:
                 del a, b, key, inv
             else:
                 uniq = part.edge_keys
-                cell_edges = part.cell_edges[part.local_cells]
+                cell_edges = part.cell_edges[self.local_cells]
             self._edge_keys = uniq
             cd0g = torch.cat([cells, nverts + cell_edges], dim=1)
             n_glob = nverts + int(uniq.shape[0])
@@ -225,14 +251,8 @@ class FunctionSpace:
             ek = self._edge_keys[ids[~isv] - nverts]
             xL[~isv] = 0.5 * (mesh.coords[torch.div(ek, nverts, rounding_mode="floor")] + mesh.coords[ek % nverts])
         del isv
-        # ---- 2. owned dofs in spatial (z, y, x) order, then ghosts by (owner, global id) -------
-        lo = mesh.coords.min(dim=0).values
-        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
-        q = torch.round((xL - lo) / span * float(1 << 20)).to(torch.int64)
-        skey = q[:, d - 1]
-        for k in range(d - 2, -1, -1):
-            skey = skey * (1 << 21) + q[:, k]
-        del q
+        # ---- 2. owned dofs in tiled spatial order, then ghosts by (owner, global id) --------------
+        skey = locality_key(xL, lo, span)
         if owned is None:
             perm1 = torch.argsort(skey, stable=True)
             n_owned = nL
@@ -400,6 +420,19 @@ class FunctionSpace:
             adj_pos[off[sl], :nd] = k.to(torch.uint8)
         self.adj = AdjTable(n_slices, nd, adj_ptr, adj_cell, adj_loc, adj_pos, pw)
         self.adj_count = cnt
+
+    def cells_in_kernel_order(self) -> np.ndarray:
+        """Vertex ids of the cells in the order every per-cell device array uses (host copy)."""
+        return self.mesh.cells[self.local_cells].cpu().numpy()
+
+    def kernel_cell_index(self, cell_ids) -> np.ndarray:
+        """Position of mesh cell ids in the kernel-side cell list (-1 if the cell is not local)."""
+        lc = self.local_cells.cpu().numpy()
+        srt = np.argsort(lc)
+        cell_ids = np.asarray(cell_ids)
+        pos = np.searchsorted(lc[srt], cell_ids)
+        pos = np.minimum(pos, lc.shape[0] - 1)
+        return np.where(lc[srt][pos] == cell_ids, srt[pos], -1)
 
     # ---- DOLFINx-shaped helpers -------------------------------------------------------
     def tabulate_dof_coordinates(self) -> np.ndarray:
@@ -650,9 +683,7 @@ def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
         cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
         cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
         phi = np.stack(cols, axis=1)
-    cells = mesh.cells.cpu().numpy()
-    if V.local_cells is not None:
-        cells = cells[V.local_cells.cpu().numpy()]
+    cells = mesh.cells.cpu().numpy()[V.local_cells.cpu().numpy()]
     xc = mesh.coords.cpu().numpy()[cells]
     xq = np.einsum("qa,cak->cqk", bary, xc)
     X = np.zeros((3, xq.shape[0] * xq.shape[1]))

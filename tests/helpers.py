@@ -59,7 +59,7 @@ def make_oracle_twin(S, mesh, dim, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_op
     Vi, Q = S._Vi[0][0], S._Q
     return O.taylor_green_problem(
         0, dim, u_deg=u_deg, p_deg=1, nu=nu, dt=dt, t0=t0, solver_options=solver_options or KRYLOV,
-        mesh=(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy()),
+        mesh=(mesh.coords.cpu().numpy(), Vi.cells_in_kernel_order()),
         vd=Vi.cell_dofs.cpu().numpy(), qd=Q.cell_dofs.cpu().numpy(),
         x_v=Vi.x.cpu().numpy(), x_q=Q.x.cpu().numpy(), rotational=rotational)
 

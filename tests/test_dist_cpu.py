@@ -106,7 +106,7 @@ def _worker(rank, world, port, dim, N, deg, out):
             rz = rzn
         # serial reference on rank 0's copy of the global problem
         Vg = fem.FunctionSpace(m, deg, window=128)
-        Fg = O.Forms(m.coords.numpy(), m.cells.numpy(), deg, 1, vd=Vg.cell_dofs.numpy(), qd=m.cells.numpy(),
+        Fg = O.Forms(m.coords.numpy(), Vg.cells_in_kernel_order(), deg, 1, vd=Vg.cell_dofs.numpy(), qd=Vg.cells_in_kernel_order(),
                      nv_dofs=Vg.num_dofs, nq_dofs=m.num_vertices)
         Ag = (Fg.stiffness_v() + 40.0 * Fg.mass_v()).tocsr()
         xg = Vg.x.numpy()

@@ -25,8 +25,8 @@ def test_spmv_matches_scipy(hip, dim, N, deg, ncomp):
     from oracle import ipcs_oracle as O
 
     mesh, V = _spaces(dim, N, deg)
-    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), deg, 1, vd=V.cell_dofs.cpu().numpy(),
-                qd=mesh.cells.cpu().numpy(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), deg, 1, vd=V.cell_dofs.cpu().numpy(),
+                qd=V.cells_in_kernel_order(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
     rng = np.random.default_rng(0)
     Kc = F.stiffness_v() + 0.3 * F.convection(rng.standard_normal((V.num_dofs, dim)))
     A = SellMatrix(V.pattern)
@@ -107,8 +107,8 @@ def test_krylov_matches_oracle_iterations(hip, ksp, ncomp):
     from oracle import ipcs_oracle as O
 
     mesh, V = _spaces(3, 4, 2)
-    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), 2, 1, vd=V.cell_dofs.cpu().numpy(),
-                qd=mesh.cells.cpu().numpy(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), 2, 1, vd=V.cell_dofs.cpu().numpy(),
+                qd=V.cells_in_kernel_order(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
     rng = np.random.default_rng(3)
     Amat = F.mass_v() * 50.0 + F.stiffness_v()
     if ksp == "bcgs":

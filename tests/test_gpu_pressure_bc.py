@@ -35,9 +35,10 @@ def test_pressure_condition(hip, dim, P, kind):
     hfun = (lambda x: 1.0 + 2 * x[1] - x[dim - 1] ** 1) if kind == "callable" else None
     bc = PressureBC(hfun if hfun else 4.0, (tags, 2))
     bc.create_bcs(V, Q)
-    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), P, 1, vd=V.cell_dofs.cpu().numpy(),
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), P, 1, vd=V.cell_dofs.cpu().numpy(),
                 qd=Q.cell_dofs.cpu().numpy(), nv_dofs=V.num_dofs, nq_dofs=Q.num_dofs)
     fc, fa = _facet_pairs(F, mesh, facets)
+    fc = V.kernel_cell_index(fc)
     xq = Q.x.cpu().numpy()
     X = np.zeros((3, xq.shape[0]))
     X[:dim] = xq.T
@@ -83,7 +84,7 @@ def test_tentative_with_outlet(hip, low_memory, body_force, u_deg):
                                 bcs_p=[ox.PressureBC(4.0, (tags, 3))], solver_options=KRYLOV, body_force=f,
                                 options={"low_memory_version": low_memory, "sell_window": 128})
     Vi, Q = S._Vi[0][0], S._Q
-    F = O.Forms(mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy(), u_deg, 1, vd=Vi.cell_dofs.cpu().numpy(),
+    F = O.Forms(mesh.coords.cpu().numpy(), Vi.cells_in_kernel_order(), u_deg, 1, vd=Vi.cell_dofs.cpu().numpy(),
                 qd=Q.cell_dofs.cpu().numpy(), nv_dofs=Vi.num_dofs, nq_dofs=Q.num_dofs)
     xv = Vi.x.cpu().numpy()
     ld = np.nonzero(np.isclose(xv[:, 0], 0))[0]
@@ -92,6 +93,7 @@ def test_tentative_with_outlet(hip, low_memory, body_force, u_deg):
     obcs = [[O.DirichletData(ld, lambda x: (1 + rclock["t"]) * np.sin(np.pi * x[1])), O.DirichletData(td, 0.0)],
             [O.DirichletData(ld, 0.0), O.DirichletData(td, 0.0)]]
     fc, fa = _facet_pairs(F, mesh, right)
+    fc = Vi.kernel_cell_index(fc)
     R = O.OracleFractionalStep(F, xv, Q.x.cpu().numpy(), obcs, solver_options=KRYLOV, body_force=f,
                                low_memory=low_memory, bcs_p=[O.PressureData(fc, fa, 4.0)])
     X = np.zeros((3, xv.shape[0]))

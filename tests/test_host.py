@@ -69,13 +69,14 @@ def test_function_space_layout(dim, N, deg):
     assert sorted(V._rank_initial.tolist()) == list(range(n))
     x = V.x.numpy()
     cd = V.cell_dofs.numpy()
-    vx = m.coords.numpy()[m.cells.numpy()]
+    kc = V.cells_in_kernel_order()
+    vx = m.coords.numpy()[kc]
     assert np.abs(x[cd[:, : dim + 1]] - vx).max() < 1e-15
     if deg == 2:
         for e, (a, b) in enumerate(fem.local_edges(dim)):
             assert np.abs(x[cd[:, dim + 1 + e]] - 0.5 * (vx[:, a] + vx[:, b])).max() < 1e-15
     # the pattern equals the oracle's on the same numbering
-    F = O.Forms(m.coords.numpy(), m.cells.numpy(), deg, 1, vd=cd, qd=m.cells.numpy(), nv_dofs=n,
+    F = O.Forms(m.coords.numpy(), kc, deg, 1, vd=cd, qd=kc, nv_dofs=n,
                 nq_dofs=m.num_vertices)
     Mo = F.mass_v()
     assert P.nnz == Mo.nnz

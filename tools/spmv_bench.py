@@ -1,0 +1,34 @@
+"""SpMV micro-benchmark on the bench workload's matrices (x_j = sin(j*1e-3)+1,
+200 repetitions after 20 warm-up), HIP-event timed.  OX_SPMV_VARIANT selects a kernel variant."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oasisx_amd import fem, _lib, mesh as M
+from oasisx_amd.la import SellMatrix
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+which = sys.argv[2] if len(sys.argv) > 2 else "p"
+mesh = M.create_box(None, [[-1.,-1.,-1.],[1.,1.,1.]], [N,N,N])
+deg, nc = (1, 1) if which == "p" else (2, 3)
+V = fem.FunctionSpace(mesh, deg)
+A = SellMatrix(V.pattern); A.vals.uniform_(0.5, 1.5)
+P = V.pattern
+x = (torch.sin(torch.arange(P.n_cols*nc, device="cuda", dtype=torch.float64)*1e-3)+1).reshape(P.n_cols, nc).contiguous()
+y = torch.zeros_like(x)
+lib = _lib.load()
+B = 12*P.nnz + 4*(P.n_rows+1) + nc*8*(P.n_cols+P.n_rows)
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,3,5").split(",")]
+res = {v: [] for v in variants}
+for rnd in range(7):
+    for v in variants:
+        lib.ox_set_spmv_variant(v)
+        for _ in range(5): A.mult(x, y, nc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        e0.record()
+        for _ in range(reps): A.mult(x, y, nc)
+        e1.record(); torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1)*1e3/reps)
+import statistics
+for v in variants:
+    med, mn = statistics.median(res[v]), min(res[v])
+    print(f"variant={v} {which} N={N} median={med:.1f} us min={mn:.1f} us  {B/med/1e3:.0f} GB/s ({B/med/1e3/8000:.3f} of peak)")
