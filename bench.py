@@ -90,17 +90,24 @@ def main():
         if args.verbose and rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
+    import math
+
+    # array-API style: numpy for the initial conditions, torch device tensors for the per-step
+    # Dirichlet values (DirichletBC's opt-in ``supports_torch`` path keeps them off the host)
+    def xp(x):
+        return torch if torch.is_tensor(x) else np
+
     def tg_u(x, t):
-        return -np.cos(np.pi * x[0]) * np.sin(np.pi * x[1]) * np.exp(-2.0 * nu * np.pi ** 2 * t)
+        return -xp(x).cos(np.pi * x[0]) * xp(x).sin(np.pi * x[1]) * math.exp(-2.0 * nu * np.pi ** 2 * t)
 
     def tg_v(x, t):
-        return np.cos(np.pi * x[1]) * np.sin(np.pi * x[0]) * np.exp(-2.0 * nu * np.pi ** 2 * t)
+        return xp(x).cos(np.pi * x[1]) * xp(x).sin(np.pi * x[0]) * math.exp(-2.0 * nu * np.pi ** 2 * t)
 
     def tg_w(x, t):
-        return np.zeros_like(x[0])
+        return xp(x).zeros_like(x[0])
 
     def tg_p(x, t):
-        return -0.25 * (np.cos(2 * np.pi * x[0]) + np.cos(2 * np.pi * x[1])) * np.exp(-4.0 * nu * np.pi ** 2 * t)
+        return -0.25 * (np.cos(2 * np.pi * x[0]) + np.cos(2 * np.pi * x[1])) * math.exp(-4.0 * nu * np.pi ** 2 * t)
 
     def on_boundary(x):
         return (np.isclose(np.abs(x[0]), 1.0) | np.isclose(np.abs(x[1]), 1.0) | np.isclose(np.abs(x[2]), 1.0))
@@ -113,8 +120,13 @@ def main():
         comm = init_comm()  # RCCL communicator of the library, bootstrapped over torch.distributed
     mesh = M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N])
     fns = [tg_u, tg_v, tg_w]
-    bcs_u = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"]), ox.LocatorMethod.GEOMETRICAL, on_boundary)]
-             for f in fns]
+    def bc_value(f):
+        def g(x):
+            return f(x, clock["t"])
+        g.supports_torch = True
+        return g
+
+    bcs_u = [[ox.DirichletBC(bc_value(f), ox.LocatorMethod.GEOMETRICAL, on_boundary)] for f in fns]
     ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
            "ksp_initial_guess_nonzero": not args.zero_guess}
     solver_options = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"),

@@ -98,6 +98,17 @@ class DirichletBC:
             self._refresh_constant()
 
     def _evaluate(self):
+        # A callable marked ``supports_torch = True`` is handed the boundary coordinates as a
+        # (3, nbc) torch tensor ON THE DEVICE and must return a device tensor: the Dirichlet values
+        # then never touch the host (the reference's numpy callables keep working unmarked).
+        if getattr(self._value, "supports_torch", False):
+            if not hasattr(self, "_xbc_dev"):
+                self._xbc_dev = torch.from_numpy(self._xbc).to(self._g_dev.device)
+            g = self._value(self._xbc_dev)
+            if not torch.is_tensor(g):
+                raise TypeError("a supports_torch callable must return a torch tensor")
+            self._g_dev.copy_(g.reshape(-1).to(torch.float64))
+            return
         g = np.asarray(self._value(self._xbc), dtype=np.float64).reshape(-1)
         if g.shape[0] != self._dofs.shape[0]:
             g = np.broadcast_to(g, self._dofs.shape).copy()

@@ -177,3 +177,41 @@ def test_projector_of_a_function(hip):
     proj.assemble_rhs()
     assert proj.solve(assemble_rhs=False) > 0
     assert np.abs(proj.x.x.array - u.x.array).max() < 1e-10
+
+
+def test_dirichlet_values_evaluated_on_the_device(hip):
+    """A callable marked supports_torch gets device coordinates; the imposed values equal the
+    numpy path's (reference test/test_bcs.py: apply == set_bc with the interpolated function)."""
+    import torch
+
+    from oasisx_amd import DirichletBC, LocatorMethod, fem
+    from tests.helpers import tg_mesh
+
+    mesh = tg_mesh(3, 4)
+    V = fem.FunctionSpace(mesh, 2, window=128)
+    clock = {"t": 0.3}
+
+    def f(x):
+        xp = torch if torch.is_tensor(x) else np
+        return xp.sin(x[0] + clock["t"]) * x[1] + x[2] ** 2
+
+    def fdev(x):
+        return f(x)
+
+    fdev.supports_torch = True
+    marker = lambda x: np.isclose(np.abs(x[2]), 1.0)  # noqa: E731
+    a, b = DirichletBC(f, LocatorMethod.GEOMETRICAL, marker), DirichletBC(fdev, LocatorMethod.GEOMETRICAL, marker)
+    a.create_bc(V)
+    b.create_bc(V)
+    for t in (0.1, 0.2):
+        clock["t"] = t
+        a.update_bc()
+        b.update_bc()
+        assert np.abs(a.values_host() - b.values_host()).max() < 1e-14
+    S = fem.FieldStorage(V.num_dofs, 3, "cuda")
+    u = fem.Function(V, "u", S, 1)
+    b.apply(u.x)
+    X = V.tabulate_dof_coordinates()
+    exp = np.zeros(V.num_dofs)
+    exp[b._dofs] = f(X[b._dofs].T)
+    assert np.abs(S.host()[:, 1] - exp).max() < 1e-14 and np.abs(S.host()[:, 0]).max() == 0.0
