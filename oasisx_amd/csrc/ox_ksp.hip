@@ -19,7 +19,10 @@ struct KspState {
 
 struct KspParams {
   double rtol, atol;
-  int max_it, nc;
+  int max_it;
+  int nc;        // columns of THIS launch (sums are indexed 0..nc-1)
+  int c0;        // state column of launch column 0 (narrowed continuation: the one live column)
+  int nc_total;  // columns of the solve
 };
 
 enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3 };
@@ -34,8 +37,10 @@ __device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P
 // Scalar logic of one synchronisation point, run by thread c for component c.
 // `s` holds the globally reduced sums of that point.
 template <int PH>
-__device__ __forceinline__ void ksp_logic(KspState *S, const double *s, int c, const KspParams &P) {
+__device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int cl, const KspParams &P) {
   const int NC = P.nc;
+  const int c = P.c0 + cl;          // state column
+  const double *s = s_all + cl - c;  // so that s[c], s[NC + c], ... address launch column cl
   if (PH == PH_CG_INIT) {  // s = {r.z, z.z, (Db).(Db)}
     S->rz[c] = s[c];
     S->rn[c] = sqrt(s[NC + c]);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   ox_block_sum_wide<OX_MAX_NV>(v, red);
   if (threadIdx.x == 0) {
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, v, c, P);
-    ksp_finish(S, P.nc);
+    ksp_finish(S, P.nc_total);
   }
 }
 
@@ -161,7 +166,7 @@ __global__ void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspPar
   if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
   if (threadIdx.x == 0) {
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, sums, c, P);
-    ksp_finish(S, P.nc);
+    ksp_finish(S, P.nc_total);
   }
 }
 
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
 
 // CG: x += alpha p; r -= alpha q; z = D^-1 r; partial = {r.z, z.z}
 template <int NC>
-__global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, double *x,
+__global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *x,
                                                     double *vr, double *vz,
                                                     const double *__restrict__ vp,
                                                     const double *__restrict__ vq,
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
   if (S->done) return;
   double alpha[NC], s[2 * NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c];
+  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c0 + c];
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
   OX_ROW_LOOP {
@@ -246,12 +251,12 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
 
 // CG: p = z + beta p
 template <int NC>
-__global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S,
+__global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S, int c0,
                                                     const double *__restrict__ vz, double *vp) {
   if (S->done) return;
   double beta[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) beta[c] = S->beta[c];
+  for (int c = 0; c < NC; ++c) beta[c] = S->beta[c0 + c];
   OX_ROW_LOOP {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -297,15 +302,15 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
 
 // BiCGStab: p = r + beta (p - omega v)
 template <int NC>
-__global__ __launch_bounds__(256) void k_bcgs_p(int64_t n, const KspState *S,
+__global__ __launch_bounds__(256) void k_bcgs_p(int64_t n, const KspState *S, int c0,
                                                 const double *__restrict__ vr, double *vp,
                                                 const double *__restrict__ vv) {
   if (S->done) return;
   double beta[NC], omega[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    beta[c] = S->beta[c];
-    omega[c] = S->omega[c];
+    beta[c] = S->beta[c0 + c];
+    omega[c] = S->omega[c0 + c];
   }
   OX_ROW_LOOP {
 #pragma unroll
@@ -318,13 +323,13 @@ __global__ __launch_bounds__(256) void k_bcgs_p(int64_t n, const KspState *S,
 
 // BiCGStab: s = r - alpha v
 template <int NC>
-__global__ __launch_bounds__(256) void k_bcgs_s(int64_t n, const KspState *S,
+__global__ __launch_bounds__(256) void k_bcgs_s(int64_t n, const KspState *S, int c0,
                                                 const double *__restrict__ vr,
                                                 const double *__restrict__ vv, double *vs) {
   if (S->done) return;
   double alpha[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c];
+  for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c0 + c];
   OX_ROW_LOOP {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void k_bcgs_s(int64_t n, const KspState *S,
 
 // BiCGStab: x += alpha p + omega s; r = s - omega t; partial = {r.r, rhat.r}
 template <int NC>
-__global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, double *x, double *vr,
+__global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, int c0, double *x, double *vr,
                                                 const double *__restrict__ vrhat,
                                                 const double *__restrict__ vp,
                                                 const double *__restrict__ vs,
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, do
   double alpha[NC], omega[NC], s[2 * NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    alpha[c] = S->alpha[c];
-    omega[c] = S->omega[c];
+    alpha[c] = S->alpha[c0 + c];
+    omega[c] = S->omega[c0 + c];
   }
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, do
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KspLayout {
-  size_t state, sums, partial, vec0, vec_stride, total;
+  size_t state, sums, partial, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
 };
 
@@ -386,7 +391,9 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   L.partial = L.sums + ox_align(sizeof(double) * 4 * OX_MAXC);
   L.vec0 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
-  L.total = L.vec0 + L.vec_stride * L.nvec;
+  L.narrow0 = L.vec0 + L.vec_stride * L.nvec;
+  L.narrow_stride = ox_align(sizeof(double) * (size_t)n_cols);
+  L.total = L.narrow0 + (ncomp > 1 ? L.narrow_stride * 8 : 0);  // compact vectors of the narrowed solve
   return L;
 }
 
@@ -411,74 +418,161 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
   return 0;
 }
 
+// column extraction / insertion for the narrowed continuation
+__global__ __launch_bounds__(256) void k_extract_col(int64_t n, const double *__restrict__ src, int nc,
+                                                     int c, double *__restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i * nc + c];
+}
+__global__ __launch_bounds__(256) void k_insert_col(int64_t n, const double *__restrict__ src, int nc,
+                                                    int c, double *__restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i * nc + c] = src[i];
+}
+
+struct KspVecs {
+  double *x, *r, *z, *p, *q;       // CG (z, q) ...
+  double *rhat, *v, *s, *t;        // ... BiCGStab
+};
+
+struct KspCtx {
+  const ox_sell *A;
+  const double *dinv;
+  KspState *S;
+  double *sums, *partial;
+  const ox_dist *dist;
+  hipStream_t st;
+  int nb, nbs;
+};
+
+template <int NC>
+static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+  const int64_t n = C.A->n_rows;
+  const int *done = &C.S->done;
+  for (int k = 0; k < count; ++k) {
+    if (C.dist && ox_halo_forward_impl(C.dist, V.p, NC, C.st)) return -1;
+    if (ox_spmv_launch(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.st)) return -1;
+    if (ksp_sync_point<PH_CG_A>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.z, V.p, V.q,
+                       C.dinv, C.partial);
+    OX_LAUNCH_CHECK();
+    if (ksp_sync_point<PH_CG_B>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.z, V.p);
+    OX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <int NC>
+static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+  const int64_t n = C.A->n_rows;
+  const int *done = &C.S->done;
+  for (int k = 0; k < count; ++k) {
+    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v);
+    OX_LAUNCH_CHECK();
+    if (C.dist && ox_halo_forward_impl(C.dist, V.p, NC, C.st)) return -1;
+    if (ox_spmv_launch(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.st)) return -1;
+    if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
+    OX_LAUNCH_CHECK();
+    if (C.dist && ox_halo_forward_impl(C.dist, V.s, NC, C.st)) return -1;
+    if (ox_spmv_launch(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.st)) return -1;
+    if (ksp_sync_point<PH_BCGS_2>(C.S, C.partial, C.nbs, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
+                       V.t, C.partial);
+    OX_LAUNCH_CHECK();
+    if (ksp_sync_point<PH_BCGS_3>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
+  }
+  return 0;
+}
+
+static int ksp_read_state(const KspCtx &C) {
+  OX_HIP(hipMemcpyAsync(g_state_host, C.S, sizeof(KspState), hipMemcpyDeviceToHost, C.st));
+  OX_HIP(hipStreamSynchronize(C.st));
+  return 0;
+}
+
 template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
                    ox_ksp_result *result, const ox_dist *dist, hipStream_t st) {
   const int64_t n = A->n_rows;
   const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type);
-  KspState *S = reinterpret_cast<KspState *>(work + L.state);
-  double *sums = reinterpret_cast<double *>(work + L.sums);
-  double *partial = reinterpret_cast<double *>(work + L.partial);
+  KspCtx C;
+  C.A = A;
+  C.dinv = dinv;
+  C.S = reinterpret_cast<KspState *>(work + L.state);
+  C.sums = reinterpret_cast<double *>(work + L.sums);
+  C.partial = reinterpret_cast<double *>(work + L.partial);
+  C.dist = dist;
+  C.st = st;
+  C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
+  C.nbs = ox_spmv_blocks(A);
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
-  const int nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
-  const int nbs = ox_spmv_blocks(A);
-  const int *done = &S->done;
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, sizeof(KspState)));
-
-  if (ksp_type == OX_KSP_CG) {
-    double *vr = vec[0], *vz = vec[1], *vp = vec[2], *vq = vec[3];
+  const bool cg = ksp_type == OX_KSP_CG;
+  KspVecs V{};
+  V.x = x;
+  if (cg) {
+    V.r = vec[0], V.z = vec[1], V.p = vec[2], V.q = vec[3];
     if (guess) {
       if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
-      if (ox_spmv_launch(A, x, vq, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+      if (ox_spmv_launch(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cg_init<NC>), dim3(nb), dim3(256), 0, st, n, b, x, vq, dinv, vr, vz, vp, guess, partial);
+    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.q, dinv, V.r, V.z, V.p, guess,
+                       C.partial);
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_CG_INIT>(S, partial, nb, 3 * NC, sums, P, dist, st)) return -1;
-    for (int it = 0; it <= P.max_it;) {
-      for (int k = 0; k < check_every; ++k, ++it) {
-        if (dist && ox_halo_forward_impl(dist, vp, NC, st)) return -1;
-        if (ox_spmv_launch(A, vp, vq, NC, OX_EPI_DOT, nullptr, nullptr, partial, done, st)) return -1;
-        if (ksp_sync_point<PH_CG_A>(S, partial, nbs, NC, sums, P, dist, st)) return -1;
-        hipLaunchKernelGGL((k_cg_update1<NC>), dim3(nb), dim3(256), 0, st, n, S, x, vr, vz, vp, vq, dinv, partial);
-        OX_LAUNCH_CHECK();
-        if (ksp_sync_point<PH_CG_B>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
-        hipLaunchKernelGGL((k_cg_update2<NC>), dim3(nb), dim3(256), 0, st, n, S, vz, vp);
-        OX_LAUNCH_CHECK();
-      }
-      OX_HIP(hipMemcpyAsync(g_state_host, S, sizeof(KspState), hipMemcpyDeviceToHost, st));
-      OX_HIP(hipStreamSynchronize(st));
-      if (g_state_host->done) break;
-    }
+    if (ksp_sync_point<PH_CG_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st)) return -1;
   } else {
-    double *vr = vec[0], *vrhat = vec[1], *vp = vec[2], *vv = vec[3], *vs = vec[4], *vt = vec[5];
+    V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
     if (guess) {
       if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
-      if (ox_spmv_launch(A, x, vt, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+      if (ox_spmv_launch(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
     }
-    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(nb), dim3(256), 0, st, n, b, x, vt, dinv, vr, vrhat, vp, vv, guess, partial);
+    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.t, dinv, V.r, V.rhat, V.p, V.v,
+                       guess, C.partial);
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_BCGS_INIT>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
-    for (int it = 0; it <= P.max_it;) {
-      for (int k = 0; k < check_every; ++k, ++it) {
-        hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(nb), dim3(256), 0, st, n, S, vr, vp, vv);
+    if (ksp_sync_point<PH_BCGS_INIT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, dist, st)) return -1;
+  }
+  for (int it = 0; it <= P.max_it; it += check_every) {
+    if ((cg ? cg_iterations<NC>(C, V, P, check_every) : bcgs_iterations<NC>(C, V, P, check_every))) return -1;
+    if (ksp_read_state(C)) return -1;
+    if (g_state_host->done) break;
+    if (NC > 1) {
+      // Narrowing: the columns run in lockstep, so once all but one have converged the rest of
+      // the solve would drag NC-wide vectors along for nothing.  Extract the live column into
+      // compact vectors and continue with the 1-column kernels (same recurrences, same scalars:
+      // the state block is addressed through P.c0); insert x back at the end.
+      int live = -1, nlive = 0;
+      for (int c = 0; c < NC; ++c)
+        if (g_state_host->active[c]) live = c, ++nlive;
+      if (nlive == 1) {
+        double *cv[8];
+        for (int i = 0; i < 8; ++i) cv[i] = reinterpret_cast<double *>(work + L.narrow0 + L.narrow_stride * i);
+        KspVecs W{};
+        double *src[8] = {V.x, V.r, V.z, V.p, V.q, V.rhat, V.v, nullptr};
+        double **dst[8] = {&W.x, &W.r, &W.z, &W.p, &W.q, &W.rhat, &W.v, nullptr};
+        for (int i = 0; i < 7; ++i) {
+          *dst[i] = cv[i];
+          if (!src[i]) continue;
+          hipLaunchKernelGGL(k_extract_col, dim3(C.nb), dim3(256), 0, st, n, src[i], NC, live, cv[i]);
+          OX_LAUNCH_CHECK();
+        }
+        W.s = cv[2];  // BiCGStab temporaries share the slots CG uses for z and q
+        W.t = cv[4];
+        KspParams P1 = P;
+        P1.nc = 1;
+        P1.c0 = live;
+        for (; it <= P.max_it; it += check_every) {
+          if ((cg ? cg_iterations<1>(C, W, P1, check_every) : bcgs_iterations<1>(C, W, P1, check_every))) return -1;
+          if (ksp_read_state(C)) return -1;
+          if (g_state_host->done) break;
+        }
+        hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.x, NC, live, x);
         OX_LAUNCH_CHECK();
-        if (dist && ox_halo_forward_impl(dist, vp, NC, st)) return -1;
-        if (ox_spmv_launch(A, vp, vv, NC, OX_EPI_BCGS_V, dinv, vrhat, partial, done, st)) return -1;
-        if (ksp_sync_point<PH_BCGS_1>(S, partial, nbs, NC, sums, P, dist, st)) return -1;
-        hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(nb), dim3(256), 0, st, n, S, vr, vv, vs);
-        OX_LAUNCH_CHECK();
-        if (dist && ox_halo_forward_impl(dist, vs, NC, st)) return -1;
-        if (ox_spmv_launch(A, vs, vt, NC, OX_EPI_BCGS_T, dinv, nullptr, partial, done, st)) return -1;
-        if (ksp_sync_point<PH_BCGS_2>(S, partial, nbs, 2 * NC, sums, P, dist, st)) return -1;
-        hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(nb), dim3(256), 0, st, n, S, x, vr, vrhat, vp, vs, vt, partial);
-        OX_LAUNCH_CHECK();
-        if (ksp_sync_point<PH_BCGS_3>(S, partial, nb, 2 * NC, sums, P, dist, st)) return -1;
+        break;
       }
-      OX_HIP(hipMemcpyAsync(g_state_host, S, sizeof(KspState), hipMemcpyDeviceToHost, st));
-      OX_HIP(hipStreamSynchronize(st));
-      if (g_state_host->done) break;
     }
   }
   if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
@@ -504,7 +598,7 @@ extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, 
   if (max_it < 1) max_it = 1;
   if (check_every < 1) check_every = 1;
   memset(result, 0, sizeof(*result));
-  KspParams P{rtol, atol, max_it, ncomp};
+  KspParams P{rtol, atol, max_it, ncomp, 0, ncomp};
   hipStream_t st = ox_stream(stream);
   char *w = static_cast<char *>(work);
   switch (ncomp) {

@@ -109,7 +109,7 @@ class KSPSolver:
         if self._work is None or self._work.shape[0] < need:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
         res = _lib.ox_ksp_result()
-        every = self.check_every or (16 if meth == _lib.KSP_CG else 4)
+        every = self.check_every or (16 if (meth == _lib.KSP_CG and nc == 1) else 4)
         _lib.check(lib.ox_ksp_solve(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
                                     max_it, int(guess), int(every), _lib.ptr(self._work),
                                     int(self._work.shape[0]), C.byref(res), A.pattern.dist, st),

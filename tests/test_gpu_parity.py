@@ -215,3 +215,47 @@ def test_dirichlet_values_evaluated_on_the_device(hip):
     exp = np.zeros(V.num_dofs)
     exp[b._dofs] = f(X[b._dofs].T)
     assert np.abs(S.host()[:, 1] - exp).max() < 1e-14 and np.abs(S.host()[:, 0]).max() == 0.0
+
+
+@pytest.mark.parametrize("ksp", ["cg", "bcgs"])
+@pytest.mark.parametrize("guess", [False, True])
+def test_lockstep_solve_narrows_to_the_last_live_column(hip, ksp, guess):
+    """Columns that converge at very different iteration counts: the solve continues on a compact
+    single column once the others are done; every column still equals its own oracle solve."""
+    from oasisx_amd import _lib
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oasisx_amd.la import SellMatrix
+    from oracle import ipcs_oracle as O
+
+    mesh, V = _spaces(3, 5, 2)
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), 2, 1, vd=V.cell_dofs.cpu().numpy(),
+                qd=V.cells_in_kernel_order(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
+    rng = np.random.default_rng(5)
+    Amat = (F.mass_v() * 20.0 + F.stiffness_v()).tocsr()
+    if ksp == "bcgs":
+        Amat = (Amat + 0.5 * F.convection(rng.standard_normal((V.num_dofs, 3)))).tocsr()
+    A = SellMatrix(V.pattern, symmetric=(ksp == "cg"))
+    A.vals.copy_(V.pattern.values_from_csr(Amat))
+    n = V.num_dofs
+    b = np.zeros((n, 3))
+    b[:, 0] = Amat @ np.ones(n) * 1e-3      # easy: the solution is a constant
+    b[:, 2] = rng.standard_normal(n)         # hard: rough right-hand side
+    x0 = np.zeros((n, 3))
+    if guess:
+        x0[:, 0], x0[:, 2] = 1e-3, 0.1 * rng.standard_normal(n)
+    B, X = FieldStorage(n, 3, "cuda"), FieldStorage(n, 3, "cuda")
+    B.host()[:] = b
+    X.host()[:] = x0
+    s = KSPSolver(None, {"ksp_type": ksp, "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-12,
+                         "ksp_initial_guess_nonzero": guess})
+    s.setOperators(A)
+    reasons = s.solve_block(B, X)
+    fn = O.jacobi_cg if ksp == "cg" else O.jacobi_bicgstab
+    its = s.iterations
+    for c in range(3):
+        xr, reason, it_ref, _ = fn(Amat, b[:, c], x0[:, c].copy() if guess else None, 1e-10, 1e-12, 10000)
+        assert reasons[c] == reason and reasons[c] > 0, (c, reasons, reason)
+        assert abs(its[c] - it_ref) <= 1, (c, its, it_ref)
+        assert np.abs(X.host()[:, c] - xr).max() <= 1e-8 * max(1e-3, np.abs(xr).max())
+    assert its[2] > its[0] + 8 and its[1] == 0  # the narrowing path was taken
