@@ -174,9 +174,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    def prof(tag):
+    def prof(tag, key=-1):
         cnt, ms = C.c_longlong(0), C.c_double(0.0)
-        _lib.check(lib.ox_profile_get(tag, C.byref(cnt), C.byref(ms)), "ox_profile_get")
+        _lib.check(lib.ox_profile_get(tag, key, C.byref(cnt), C.byref(ms)), "ox_profile_get")
         return int(cnt.value), float(ms.value)
 
     gd = mesh.gdim
@@ -185,12 +185,18 @@ def main():
     # velocity SpMM on gd interleaved vectors: matrix read once, gd x/y vectors
     b_u = 12 * Pu.nnz + 4 * (Pu.n_rows + 1) + gd * 8 * (Pu.n_cols + Pu.n_rows)
     kernels = {}
-    for name, tag, nbytes in (("pressure_cg_spmv", 11, b_p), ("velocity_bcgs_spmv_v", 10 * gd + 2, b_u),
-                              ("velocity_bcgs_spmv_t", 10 * gd + 3, b_u), ("mass_cg_spmv", 10 * gd + 1, b_u),
-                              ("mass_spmv", 10 * gd + 0, b_u), ("assemble_first", 100, None),
-                              ("grad_vector_p", 110, None), ("grad_vector_dp", 111, None),
-                              ("div_vector", 120, None)):
-        cnt, ms = prof(tag)
+    ku, kp = Pu.n_rows, Pp.n_rows  # SpMV records are keyed by the matrix's row count
+    b_u1 = spmv_bytes(Pu.nnz, Pu.n_rows, Pu.n_cols)  # narrowed (1-column) solves on the velocity matrix
+    for name, tag, key, nbytes in (
+            ("pressure_cg_spmv", 11, kp, b_p),
+            ("velocity_bcgs_spmv_v", 10 * gd + 2, ku, b_u), ("velocity_bcgs_spmv_t", 10 * gd + 3, ku, b_u),
+            ("velocity_bcgs_spmv_v_narrowed", 12, ku, b_u1), ("velocity_bcgs_spmv_t_narrowed", 13, ku, b_u1),
+            ("mass_cg_spmv", 10 * gd + 1, ku, b_u), ("mass_cg_spmv_narrowed", 11, ku, b_u1),
+            ("mass_spmv", 10 * gd + 0, ku, b_u), ("assemble_first", 100, -1, None),
+            ("grad_vector_p", 110, -1, None), ("grad_vector_dp", 111, -1, None), ("div_vector", 120, -1, None)):
+        if key == kp and ku == kp and name != "pressure_cg_spmv":
+            continue  # P1-P1: both matrices have the same size; keep the pressure entry only
+        cnt, ms = prof(tag, key)
         if cnt:
             k = {"launches": cnt, "avg_us": 1e3 * ms / cnt, "total_ms": ms}
             if nbytes:
@@ -198,14 +204,34 @@ def main():
                 k["gbs"] = nbytes / (1e6 * ms / cnt)
             kernels[name] = k
     cg = kernels.get("pressure_cg_spmv")
+
+    def pmc_traffic():
+        """HBM bytes per launch of the pressure SpMV from the latest committed PMC pass
+        (profiles/*_pmc_hbm.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+        import csv
+        import glob
+
+        best = None
+        grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)  # launch grid of the pressure SpMV
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv"))):
+            for r in csv.DictReader(open(path)):
+                if r["kernel"].replace(" ", "").startswith("voidk_spmv<1,1") and int(r.get("grid_size", grid)) == grid:
+                    best = (float(r["hbm_total_MB_per_launch"]) * 1e6, os.path.basename(path))
+        return best
+
     roofline = None
     if cg:
         roofline = {"kernel": "k_spmv<1,OX_EPI_DOT> (pressure-Poisson CG SpMV, SELL-64, f64)", "bound": "hbm",
                     "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": cg["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                    "frac": cg["gbs"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_launch": b_p, "avg_launch_us": cg["avg_us"],
                     "launches": cg["launches"]}
 
+    if roofline and N == 128 and args.udeg == 2:
+        tr = pmc_traffic()
+        if tr:
+            roofline["traffic"], roofline["traffic_source"] = tr[0], "profiles/" + tr[1]
     if rank == 0:
         mean_its = {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
         out = {

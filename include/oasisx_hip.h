@@ -198,7 +198,9 @@ int ox_set_spmv_variant(int v); /* kernel-variant switch of the SpMV micro-bench
                                    matrix loads, bit1 unroll 8, bit2 unroll 16) */
 int ox_profile_begin(int max_records);
 int ox_profile_end(void);
-int ox_profile_get(int tag, long long *count, double *total_ms);
+int ox_profile_get(int tag, long long key, long long *count, double *total_ms); /* key: the matrix's
+                                   n_rows for SpMV records (tells the pressure matrix from the
+                                   velocity matrix), -1 = any */
 
 /* ---- H1 + collectives: mesh-partitioned runs (one process per GPU, RCCL) -------------- */
 int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 (broadcast it out of band) */

@@ -97,7 +97,7 @@ SIGNATURES = {
     "ox_set_spmv_variant": (_I, [_I]),
     "ox_profile_begin": (_I, [_I]),
     "ox_profile_end": (_I, []),
-    "ox_profile_get": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(_D)]),
+    "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),
     "ox_comm_unique_id": (_I, [C.c_char_p]),
     "ox_comm_create": (_I, [C.c_char_p, _I, _I, C.POINTER(_P)]),
     "ox_comm_destroy": (_I, [_P]),

@@ -89,5 +89,5 @@ int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, 
 #define OX_TAG_DIV_VECTOR 120
 #define OX_TAG_ASSEMBLE_MATRIX 130
 extern bool ox_prof_on;
-void ox_prof_start(int tag, hipStream_t st);
+void ox_prof_start(int tag, hipStream_t st, long long key = 0);
 void ox_prof_stop(hipStream_t st);

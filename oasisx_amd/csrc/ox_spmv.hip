@@ -145,7 +145,7 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
-    if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st);                                      \
+    if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
     switch (var) {                                                                              \
       case 1: OX_SPMV_LAUNCH(NC, E, 1); break;                                                  \
       case 2: OX_SPMV_LAUNCH(NC, E, 2); break;                                                  \
@@ -460,20 +460,20 @@ extern "C" int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream) {
 #include <vector>
 bool ox_prof_on = false;
 namespace {
-struct ProfRec { int tag; hipEvent_t a, b; };
+struct ProfRec { int tag; long long key; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof;
-size_t g_prof_used = 0;
+std::vector<float> g_prof_ms;
+size_t g_prof_used = 0, g_prof_n = 0;
 bool g_prof_open = false;
 constexpr int OX_PROF_NTAG = 256;
-double g_prof_ms[OX_PROF_NTAG];
-long long g_prof_cnt[OX_PROF_NTAG];
 }  // namespace
 
-void ox_prof_start(int tag, hipStream_t st) {
+void ox_prof_start(int tag, hipStream_t st, long long key) {
   g_prof_open = false;
   if (g_prof_used >= g_prof.size()) return;
   ProfRec &r = g_prof[g_prof_used];
   r.tag = tag;
+  r.key = key;
   if (hipEventRecord(r.a, st) == hipSuccess) g_prof_open = true;
 }
 void ox_prof_stop(hipStream_t st) {
@@ -492,7 +492,7 @@ extern "C" int ox_profile_begin(int max_records) {
     g_prof.push_back(r);
   }
   g_prof_used = 0;
-  for (int i = 0; i < OX_PROF_NTAG; ++i) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
+  g_prof_n = 0;
   ox_prof_on = true;
   return 0;
 }
@@ -500,19 +500,26 @@ extern "C" int ox_profile_begin(int max_records) {
 extern "C" int ox_profile_end(void) {
   ox_prof_on = false;
   OX_HIP(hipDeviceSynchronize());
+  g_prof_ms.assign(g_prof_used, 0.f);
   for (size_t i = 0; i < g_prof_used; ++i) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) == hipSuccess) {
-      const int t = g_prof[i].tag;
-      if (t >= 0 && t < OX_PROF_NTAG) { g_prof_ms[t] += ms; g_prof_cnt[t] += 1; }
-    }
+    if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) != hipSuccess) ms = -1.f;
+    g_prof_ms[i] = ms;
   }
+  g_prof_n = g_prof_used;
   return 0;
 }
 
-extern "C" int ox_profile_get(int tag, long long *count, double *total_ms) {
+extern "C" int ox_profile_get(int tag, long long key, long long *count, double *total_ms) {
   if (tag < 0 || tag >= OX_PROF_NTAG) OX_FAIL("ox_profile_get: tag=%d", tag);
-  if (count) *count = g_prof_cnt[tag];
-  if (total_ms) *total_ms = g_prof_ms[tag];
+  long long n = 0;
+  double t = 0.0;
+  for (size_t i = 0; i < g_prof_n; ++i)
+    if (g_prof[i].tag == tag && (key < 0 || g_prof[i].key == key) && g_prof_ms[i] >= 0.f) {
+      ++n;
+      t += g_prof_ms[i];
+    }
+  if (count) *count = n;
+  if (total_ms) *total_ms = t;
   return 0;
 }
