@@ -158,7 +158,9 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    _lib.check(lib.ox_profile_begin(200000), "ox_profile_begin")
+    # HIP events on the launching stream around every 8th launch of each kernel tag (an event pair costs
+    # ~12 us of stream bubbles; every launch would slow the 150 us pressure iteration by 8 %)
+    _lib.check(lib.ox_profile_begin(200000, 8), "ox_profile_begin")
     t0 = time.perf_counter()
     its = []
     for _ in range(args.steps):

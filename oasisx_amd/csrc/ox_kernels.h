@@ -27,51 +27,61 @@ static inline int ox_vec_blocks(int64_t n) {
   return (int)(b > OX_VEC_MAX_BLOCKS ? OX_VEC_MAX_BLOCKS : b);
 }
 
-#define OX_RED_THREADS 1024  // final reductions: one wide block, independent loads in flight
+#define OX_RED_THREADS 1024  // widest final-reduction block (many partials: velocity SpMV)
+#define OX_RED_THREADS_SMALL 256
+static inline int ox_red_threads(int nparts) { return nparts > 4096 ? OX_RED_THREADS : OX_RED_THREADS_SMALL; }
 
 // Per-thread slice of the ordered final reduction: v[i] = sum over this thread's partials
-// (4 partial rows in flight per thread).
+// (4 partial rows in flight per thread).  blockDim.x threads take part.
 __device__ __forceinline__ void ox_gather_partials(const double *__restrict__ partial, int nparts,
                                                    int nv, double (&v)[OX_MAX_NV]) {
+  const int T = blockDim.x;
 #pragma unroll
   for (int i = 0; i < OX_MAX_NV; ++i) v[i] = 0.0;
   int p = threadIdx.x;
-  for (; p + 3 * OX_RED_THREADS < nparts; p += 4 * OX_RED_THREADS) {
+  for (; p + 3 * T < nparts; p += 4 * T) {
     double t[4][OX_MAX_NV];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < OX_MAX_NV; ++i)
-        t[u][i] = (i < nv) ? partial[(size_t)(p + u * OX_RED_THREADS) * nv + i] : 0.0;
+        t[u][i] = (i < nv) ? partial[(size_t)(p + u * T) * nv + i] : 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < OX_MAX_NV; ++i) v[i] += t[u][i];
   }
-  for (; p < nparts; p += OX_RED_THREADS) {
+  for (; p < nparts; p += T) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i)
       if (i < nv) v[i] += partial[(size_t)p * nv + i];
   }
 }
 
-// Sum NV per-thread values over a OX_RED_THREADS-thread block; result valid in thread 0.
-template <int NV>
-__device__ __forceinline__ void ox_block_sum_wide(double (&v)[NV], double *lds /* [16*NV] */) {
-  constexpr int NW = OX_RED_THREADS / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Sum the first nv of the per-thread values over the block (blockDim.x = 64 * nwaves <= 1024);
+// the result is valid in thread 0.  Only nv slots are reduced (nv is wave-uniform).
+__device__ __forceinline__ void ox_block_sum_wide(double (&v)[OX_MAX_NV], int nv, double *lds /* [16*OX_MAX_NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double s = ox_wave_sum(v[i]);
-    if (lane == 0) lds[wave * NV + i] = s;
+  for (int i = 0; i < OX_MAX_NV; ++i) {
+    if (i < nv) {
+      const double s = ox_wave_sum(v[i]);
+      if (lane == 0) lds[i * 16 + wave] = s;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      double s = 0.0;
-      for (int w = 0; w < NW; ++w) s += lds[w * NV + i];
-      v[i] = s;
+    for (int i = 0; i < OX_MAX_NV; ++i) {
+      if (i < nv) {
+        double s = lane < nw ? lds[i * 16 + lane] : 0.0;
+        // fixed-order tree over <= 16 wave sums
+        s += __shfl_down(s, 8, 64);
+        s += __shfl_down(s, 4, 64);
+        s += __shfl_down(s, 2, 64);
+        s += __shfl_down(s, 1, 64);
+        v[i] = s;
+      }
     }
   }
 }

@@ -144,30 +144,57 @@ __device__ __forceinline__ void ksp_finish(KspState *S, int nc) {
   S->done = !any;
 }
 
-// Fused: reduce per-block partials (fixed order) + scalar logic.  One 256-thread block.
+// The state block is staged in LDS: one coalesced load, the (dependent, branchy) scalar logic at
+// LDS latency, one coalesced store -- instead of ~10 serialized global round trips per phase.
+static_assert(sizeof(KspState) % 8 == 0, "KspState is copied in 8-byte words");
+constexpr int KSP_STATE_WORDS = sizeof(KspState) / 8;
+
+__device__ __forceinline__ void ksp_state_load(KspState *sh, const KspState *S) {
+  if (threadIdx.x < KSP_STATE_WORDS)
+    reinterpret_cast<unsigned long long *>(sh)[threadIdx.x] =
+        reinterpret_cast<const unsigned long long *>(S)[threadIdx.x];
+}
+__device__ __forceinline__ void ksp_state_store(KspState *S, const KspState *sh) {
+  if (threadIdx.x < KSP_STATE_WORDS)
+    reinterpret_cast<unsigned long long *>(S)[threadIdx.x] =
+        reinterpret_cast<const unsigned long long *>(sh)[threadIdx.x];
+}
+
+// Fused: reduce per-block partials (fixed order) + scalar logic.  One wide block.
 template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
                                                                const double *__restrict__ partial,
                                                                int nparts, int nv, KspParams P) {
-  __shared__ double red[(OX_RED_THREADS / 64) * OX_MAX_NV];
+  __shared__ double red[16 * OX_MAX_NV];
+  __shared__ KspState sh;
   if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  ksp_state_load(&sh, S);
   double v[OX_MAX_NV];
   ox_gather_partials(partial, nparts, nv, v);
-  ox_block_sum_wide<OX_MAX_NV>(v, red);
+  ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
   if (threadIdx.x == 0) {
-    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, v, c, P);
-    ksp_finish(S, P.nc_total);
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
+    ksp_finish(&sh, P.nc_total);
   }
+  __syncthreads();
+  ksp_state_store(S, &sh);
 }
 
 // Logic only (distributed runs: the sums were all-reduced over the ranks first).
 template <int PH>
-__global__ void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspParams P) {
+__global__ __launch_bounds__(64) void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspParams P) {
+  __shared__ KspState sh;
+  __shared__ double sv[OX_MAX_NV];
   if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  ksp_state_load(&sh, S);
+  if (threadIdx.x < OX_MAX_NV) sv[threadIdx.x] = sums[threadIdx.x];
+  __syncthreads();
   if (threadIdx.x == 0) {
-    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(S, sums, c, P);
-    ksp_finish(S, P.nc_total);
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, sv, c, P);
+    ksp_finish(&sh, P.nc_total);
   }
+  __syncthreads();
+  ksp_state_store(S, &sh);
 }
 
 // ------------------------------- vector kernels ------------------------------------------
@@ -232,18 +259,54 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
   for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c0 + c];
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP {
-    const double d = dinv[row];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int64_t i = row * NC + c;
-      x[i] = fma(alpha[c], vp[i], x[i]);
-      const double ri = fma(-alpha[c], vq[i], vr[i]);
-      const double zi = d * ri;
+  if constexpr (NC == 1) {
+    // one column: two rows per thread, 16-B accesses (all vectors are 16-B aligned)
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const double a = alpha[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+      const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
+      const double2 p = reinterpret_cast<const double2 *>(vp)[i];
+      const double2 qq = reinterpret_cast<const double2 *>(vq)[i];
+      double2 xx = reinterpret_cast<double2 *>(x)[i];
+      double2 r = reinterpret_cast<double2 *>(vr)[i];
+      xx.x = fma(a, p.x, xx.x);
+      xx.y = fma(a, p.y, xx.y);
+      r.x = fma(-a, qq.x, r.x);
+      r.y = fma(-a, qq.y, r.y);
+      double2 z;
+      z.x = d.x * r.x;
+      z.y = d.y * r.y;
+      reinterpret_cast<double2 *>(x)[i] = xx;
+      reinterpret_cast<double2 *>(vr)[i] = r;
+      reinterpret_cast<double2 *>(vz)[i] = z;
+      s[0] = fma(r.y, z.y, fma(r.x, z.x, s[0]));
+      s[1] = fma(z.y, z.y, fma(z.x, z.x, s[1]));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const int64_t i = n - 1;
+      x[i] = fma(a, vp[i], x[i]);
+      const double ri = fma(-a, vq[i], vr[i]);
+      const double zi = dinv[i] * ri;
       vr[i] = ri;
       vz[i] = zi;
-      s[c] = fma(ri, zi, s[c]);
-      s[NC + c] = fma(zi, zi, s[NC + c]);
+      s[0] = fma(ri, zi, s[0]);
+      s[1] = fma(zi, zi, s[1]);
+    }
+  } else {
+    OX_ROW_LOOP {
+      const double d = dinv[row];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int64_t i = row * NC + c;
+        x[i] = fma(alpha[c], vp[i], x[i]);
+        const double ri = fma(-alpha[c], vq[i], vr[i]);
+        const double zi = d * ri;
+        vr[i] = ri;
+        vz[i] = zi;
+        s[c] = fma(ri, zi, s[c]);
+        s[NC + c] = fma(zi, zi, s[NC + c]);
+      }
     }
   }
   ksp_store_partial<2 * NC>(s, red, partial);
@@ -257,11 +320,24 @@ __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S
   double beta[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) beta[c] = S->beta[c0 + c];
-  OX_ROW_LOOP {
+  if constexpr (NC == 1) {
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+      const double2 z = reinterpret_cast<const double2 *>(vz)[i];
+      double2 p = reinterpret_cast<double2 *>(vp)[i];
+      p.x = fma(beta[0], p.x, z.x);
+      p.y = fma(beta[0], p.y, z.y);
+      reinterpret_cast<double2 *>(vp)[i] = p;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) vp[n - 1] = fma(beta[0], vp[n - 1], vz[n - 1]);
+  } else {
+    OX_ROW_LOOP {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int64_t i = row * NC + c;
-      vp[i] = fma(beta[c], vp[i], vz[i]);
+      for (int c = 0; c < NC; ++c) {
+        const int64_t i = row * NC + c;
+        vp[i] = fma(beta[c], vp[i], vz[i]);
+      }
     }
   }
 }
@@ -407,7 +483,7 @@ template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
                           const KspParams &P, const ox_dist *dist, hipStream_t st) {
   if (!dist) {
-    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(OX_RED_THREADS), 0, st, S, partial, nparts, nv, P);
+    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(ox_red_threads(nparts)), 0, st, S, partial, nparts, nv, P);
     OX_LAUNCH_CHECK();
     return 0;
   }

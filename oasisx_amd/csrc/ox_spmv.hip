@@ -186,16 +186,16 @@ extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OX_RED_THREADS) void k_reduce_partials(
     const double *__restrict__ partial, int nparts, int nv, double *__restrict__ sums) {
-  __shared__ double red[(OX_RED_THREADS / 64) * OX_MAX_NV];
+  __shared__ double red[16 * OX_MAX_NV];
   double v[OX_MAX_NV];
   ox_gather_partials(partial, nparts, nv, v);
-  ox_block_sum_wide<OX_MAX_NV>(v, red);
+  ox_block_sum_wide(v, nv, red);
   if (threadIdx.x == 0)
     for (int i = 0; i < nv; ++i) sums[i] = v[i];
 }
 
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(OX_RED_THREADS), 0, st, partial, nparts, nv, sums);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(ox_red_threads(nparts)), 0, st, partial, nparts, nv, sums);
   OX_LAUNCH_CHECK();
   return 0;
 }
@@ -464,12 +464,16 @@ struct ProfRec { int tag; long long key; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof;
 std::vector<float> g_prof_ms;
 size_t g_prof_used = 0, g_prof_n = 0;
-bool g_prof_open = false;
 constexpr int OX_PROF_NTAG = 256;
+long long g_prof_seen[OX_PROF_NTAG];
+int g_prof_every = 1;
+bool g_prof_open = false;
 }  // namespace
 
 void ox_prof_start(int tag, hipStream_t st, long long key) {
   g_prof_open = false;
+  // an event pair costs ~2 x 6 us of stream bubbles: time only every g_prof_every-th launch of a tag
+  if (tag >= 0 && tag < OX_PROF_NTAG && (g_prof_seen[tag]++ % g_prof_every) != 0) return;
   if (g_prof_used >= g_prof.size()) return;
   ProfRec &r = g_prof[g_prof_used];
   r.tag = tag;
@@ -483,8 +487,10 @@ void ox_prof_stop(hipStream_t st) {
   g_prof_open = false;
 }
 
-extern "C" int ox_profile_begin(int max_records) {
+extern "C" int ox_profile_begin(int max_records, int sample_every) {
   if (max_records < 1) max_records = 1;
+  g_prof_every = sample_every < 1 ? 1 : sample_every;
+  for (int i = 0; i < OX_PROF_NTAG; ++i) g_prof_seen[i] = 0;
   while ((int)g_prof.size() < max_records) {
     ProfRec r{};
     OX_HIP(hipEventCreate(&r.a));
