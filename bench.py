@@ -44,6 +44,10 @@ def parse():
                          "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); "
+                         "gloo = rehearsal of the same partitioned path through the library's host-staged "
+                         "callback transport (several ranks may then share one GPU)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -71,11 +75,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import oasisx_amd as ox
     from oasisx_amd import _lib
@@ -172,7 +180,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -234,6 +242,13 @@ def main():
         tr = pmc_traffic()
         if tr:
             roofline["traffic"], roofline["traffic_source"] = tr[0], "profiles/" + tr[1]
+    nnz_glob = [Pu.nnz, Pp.nnz]
+    if world > 1:
+        import torch.distributed as dist
+
+        tn = torch.tensor(nnz_glob, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tn)
+        nnz_glob = [int(v) for v in tn.tolist()]
     if rank == 0:
         mean_its = {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
         out = {
@@ -247,7 +262,8 @@ def main():
                                    f"initial_guess_nonzero={not args.zero_guess}, max_iter=1",
                        "cells": mesh.num_cells, "n_u_per_component": S._Vi[0][0].num_dofs_global,
                        "n_p": S._Q.num_dofs_global,
-                       "nnz_velocity": Pu.nnz, "nnz_pressure": Pp.nnz, "parallelism": f"mesh-partition x{world}"},
+                       "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}" + ("" if args.backend == "nccl" or world == 1
+                                                                       else " (gloo rehearsal transport)")},
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
             "kernels": kernels,
