@@ -261,7 +261,7 @@ class PressureBC:
         self._rows_b32 = self._rows_b.to(torch.int32)
         self._S = []
         if nrb > 0:
-            pat = build_sell(nrb, nq_loc, rinv, ucol, row_len, row_ptr)
+            pat = build_sell(nrb, nq_loc, rinv * nq_loc + ucol.to(torch.int64), row_len, row_ptr)
             k = torch.arange(ukey.shape[0], device=dev) - row_ptr[rinv]
             off = pat.slice_ptr[rinv // 64] + (k // 2) * 128 + (rinv % 64) * 2 + (k % 2)
             for i in range(d):

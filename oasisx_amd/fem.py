@@ -59,19 +59,31 @@ def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bit
     return key
 
 
-def cell_geometry(mesh: Mesh, cell_ids=None) -> torch.Tensor:
-    """[n_cells][gs] rows of grad(lambda_1..d) then |detJ| (gs = 6 in 2-D, 10 in 3-D)."""
+def cell_geometry(mesh: Mesh, cell_ids=None, chunk: int = 1 << 23) -> torch.Tensor:
+    """[n_cells][gs] rows of grad(lambda_1..d) then |detJ| (gs = 6 in 2-D, 10 in 3-D); closed-form
+    2x2 / 3x3 inverses, evaluated in chunks of cells."""
     d = mesh.gdim
-    cells = mesh.cells if cell_ids is None else mesh.cells[cell_ids]
-    x = mesh.coords[cells]  # (nc, d+1, d)
-    J = (x[:, 1:, :] - x[:, :1, :]).transpose(1, 2).contiguous()  # columns = edge vectors
-    det = torch.linalg.det(J)
-    Jinv = torch.linalg.inv(J)  # rows = grad lambda_a, a = 1..d
+    ids = torch.arange(mesh.num_cells, device=mesh.device) if cell_ids is None else cell_ids
+    ncl = int(ids.shape[0])
     gs = 6 if d == 2 else 10
-    ncl = int(cells.shape[0])
     geom = torch.zeros((ncl, gs), dtype=torch.float64, device=mesh.device)
-    geom[:, : d * d] = Jinv.reshape(ncl, d * d)
-    geom[:, d * d] = det.abs()
+    for c0 in range(0, ncl, chunk):
+        x = mesh.coords[mesh.cells[ids[c0:c0 + chunk]]]  # (m, d+1, d)
+        e = x[:, 1:, :] - x[:, :1, :]  # rows = edge vectors x_a - x_0; J = e^T
+        g = geom[c0:c0 + chunk]
+        if d == 2:
+            a, b, c, dd = e[:, 0, 0], e[:, 1, 0], e[:, 0, 1], e[:, 1, 1]  # J = [[a, b], [c, dd]]
+            det = a * dd - b * c
+            g[:, 0], g[:, 1], g[:, 2], g[:, 3] = dd / det, -b / det, -c / det, a / det
+        else:
+            # rows of J^-1 = cross products of the edge vectors / det
+            e1, e2, e3 = e[:, 0], e[:, 1], e[:, 2]
+            c23 = torch.linalg.cross(e2, e3)
+            det = (e1 * c23).sum(dim=1)
+            g[:, 0:3] = c23 / det.unsqueeze(1)
+            g[:, 3:6] = torch.linalg.cross(e3, e1) / det.unsqueeze(1)
+            g[:, 6:9] = torch.linalg.cross(e1, e2) / det.unsqueeze(1)
+        g[:, d * d] = det.abs()
     return geom
 
 
@@ -186,7 +198,7 @@ class FunctionSpace:
     an owned dof (own cells + one ghost layer), so that every owned row is assembled locally."""
 
     def __init__(self, mesh: Mesh, degree: int, window: int = 4096, part=None,
-                 chunk_cells: int = 1 << 21):
+                 block_pairs: int = 1 << 24, block_nnz: int = 1 << 27):
         if degree not in (1, 2):
             raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
         self.mesh = mesh
@@ -271,17 +283,35 @@ class FunctionSpace:
         self.n_owned, self.n_local = n_owned, nL
         self.num_dofs = nL  # DOLFINx convention: local arrays hold owned dofs, then ghosts
         cd1 = rank1[cdL]
-        # ---- 3. pattern of the owned rows (chunked unique of row*nL+col keys) ------------------
-        keys = None
-        for c0 in range(0, nc, chunk_cells):
-            blk = cd1[c0:c0 + chunk_cells]
-            kk = (blk.unsqueeze(2) * nL + blk.unsqueeze(1)).reshape(-1)
-            if n_owned < nL:
-                kk = kk[kk < n_owned * nL]
-            kk = torch.unique(kk)
-            keys = kk if keys is None else torch.unique(torch.cat([keys, kk]))
-        row1 = torch.div(keys, nL, rounding_mode="floor")
-        len1 = torch.bincount(row1, minlength=n_owned)[:n_owned]
+        # ---- 3. pattern of the owned rows, built in ROW BLOCKS -------------------------------------
+        # (dof, cell) pairs grouped by dof give, per block of rows, exactly the cells that touch
+        # them; the unique (row, col) keys of a block are final because row blocks are disjoint.
+        # No global sort/unique over all keys is needed (torch's CUB calls refuse > 2^31 elements;
+        # 256^3 P2 has 3.9 G keys) and the peak memory is one block.
+        dof = cd1.reshape(-1)
+        order = torch.argsort(dof, stable=True)
+        dof_s = dof[order]
+        keep = dof_s < n_owned
+        order, dof_s = order[keep], dof_s[keep]
+        cell_s = torch.div(order, nd, rounding_mode="floor")
+        del dof, order, keep
+        cnt1 = torch.bincount(dof_s, minlength=n_owned)[:n_owned]
+        start1 = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
+        start1[1:] = torch.cumsum(cnt1, 0)
+        start1_h = start1.cpu().numpy()
+        key_blocks, len_blocks = [], []
+        r0 = 0
+        while r0 < n_owned:
+            r1 = int(np.searchsorted(start1_h, start1_h[r0] + block_pairs, side="right")) - 1
+            r1 = min(n_owned, max(r1, r0 + 1))
+            a, b = int(start1_h[r0]), int(start1_h[r1])
+            kk = torch.unique((dof_s[a:b].unsqueeze(1) * nL + cd1[cell_s[a:b]]).reshape(-1))
+            key_blocks.append(kk)
+            len_blocks.append(torch.bincount(torch.div(kk, nL, rounding_mode="floor") - r0, minlength=r1 - r0))
+            r0 = r1
+        keys = torch.cat(key_blocks) if key_blocks else torch.zeros(0, dtype=torch.int64, device=dev)
+        len1 = torch.cat(len_blocks) if len_blocks else torch.zeros(0, dtype=torch.int64, device=dev)
+        del key_blocks, len_blocks, dof_s, cell_s, cnt1, start1
         # ---- 4. window sort of the owned rows by decreasing length (stable) --------------------
         lmax = int(len1.max().item()) if n_owned else 0
         wkey = (torch.arange(n_owned, device=dev) // window) * (lmax + 1) + (lmax - len1)
@@ -297,17 +327,28 @@ class FunctionSpace:
         self.x = xf  # (n_local, gdim) dof coordinates
         self._x3 = None
         self.dofmap = _DofMap(self)
-        # ---- 5. final pattern: relabel + sort ----------------------------------------------------
-        keys2 = torch.sort(rank2[row1] * nL + rank2[keys - row1 * nL]).values
-        del keys, row1
-        rowf = torch.div(keys2, nL, rounding_mode="floor")
-        colf = (keys2 - rowf * nL).to(torch.int32)
-        row_len = torch.bincount(rowf, minlength=n_owned)[:n_owned]
+        # ---- 5. final pattern: relabel + sort, in window-aligned row blocks (rows only move inside
+        #         their window, so a block's entries stay inside the block's slice of the array) --
+        rp1 = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
+        rp1[1:] = torch.cumsum(len1, 0)
+        rp1_h = rp1.cpu().numpy()
+        r0 = 0
+        while r0 < n_owned:
+            r1 = int(np.searchsorted(rp1_h, rp1_h[r0] + block_nnz, side="right")) - 1
+            r1 = max(r1, r0 + 1)
+            r1 = min(n_owned, ((r1 + window - 1) // window) * window)
+            a, b = int(rp1_h[r0]), int(rp1_h[r1])
+            seg = keys[a:b]
+            row = torch.div(seg, nL, rounding_mode="floor")
+            keys[a:b] = torch.sort(rank2[row] * nL + rank2[seg - row * nL]).values
+            r0 = r1
+        del rp1
+        row_len = len1[perm2]  # final row r is the old row perm2[r]
         row_ptr = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
         row_ptr[1:] = torch.cumsum(row_len, 0)
-        self.pattern = build_sell(n_owned, nL, rowf, colf, row_len, row_ptr)
-        self._build_adjacency(keys2, row_ptr)
-        del keys2
+        self.pattern = build_sell(n_owned, nL, keys, row_len, row_ptr)
+        self._build_adjacency(keys, row_ptr)
+        del keys
         # ---- 6. halo plan ---------------------------------------------------------------------------
         self.halo = None
         self.dist = None
@@ -461,9 +502,10 @@ class FunctionSpace:
         return np.unique(loc.cpu().numpy()).astype(np.int32)
 
 
-def build_sell(n_rows, n_cols, rowf, colf, row_len, row_ptr) -> SellPattern:
-    """SELL-64 layout from a row-sorted COO/CSR pattern (device tensors)."""
-    dev = colf.device
+def build_sell(n_rows, n_cols, keys, row_len, row_ptr, block: int = 1 << 27) -> SellPattern:
+    """SELL-64 layout from the sorted (row * n_cols + col) keys of a pattern (device tensors).
+    Built in blocks of slices / rows so that no temporary exceeds ``block`` elements."""
+    dev = keys.device
     n_slices = (n_rows + SLICE - 1) // SLICE
     lpad = torch.zeros(n_slices * SLICE, dtype=torch.int64, device=dev)
     lpad[:n_rows] = row_len
@@ -472,17 +514,33 @@ def build_sell(n_rows, n_cols, rowf, colf, row_len, row_ptr) -> SellPattern:
     width = torch.clamp(width, min=KV)
     slice_ptr = torch.zeros(n_slices + 1, dtype=torch.int64, device=dev)
     slice_ptr[1:] = torch.cumsum(width * SLICE, 0)
-    size = int(slice_ptr[-1].item())
+    sp_h = slice_ptr.cpu().numpy()
+    size = int(sp_h[-1])
+    cols = torch.empty(size, dtype=torch.int32, device=dev)
     # padding slots repeat the row's own index (value 0); rows past n_rows point at column 0
-    o = torch.arange(size, device=dev)
-    s = torch.searchsorted(slice_ptr, o, right=True) - 1
-    lane = ((o - slice_ptr[s]) % (SLICE * KV)) // KV
-    own = s * SLICE + lane
-    cols = torch.where(own < min(n_rows, n_cols), own, torch.zeros_like(own)).to(torch.int32)
-    del o, s, lane, own
-    k = torch.arange(rowf.shape[0], device=dev) - row_ptr[rowf]
-    off = slice_ptr[rowf // SLICE] + (k // KV) * (SLICE * KV) + (rowf % SLICE) * KV + (k % KV)
-    cols[off] = colf
+    nlim = min(n_rows, n_cols)
+    s0 = 0
+    while s0 < n_slices:
+        s1 = int(np.searchsorted(sp_h, sp_h[s0] + block, side="right")) - 1
+        s1 = min(n_slices, max(s1, s0 + 1))
+        a, b = int(sp_h[s0]), int(sp_h[s1])
+        o = torch.arange(a, b, device=dev)
+        sl = torch.searchsorted(slice_ptr[s0:s1 + 1], o, right=True) - 1 + s0
+        own = sl * SLICE + ((o - slice_ptr[sl]) % (SLICE * KV)) // KV
+        cols[a:b] = torch.where(own < nlim, own, torch.zeros_like(own)).to(torch.int32)
+        s0 = s1
+    rp_h = row_ptr.cpu().numpy()
+    r0 = 0
+    while r0 < n_rows:
+        r1 = int(np.searchsorted(rp_h, rp_h[r0] + block, side="right")) - 1
+        r1 = min(n_rows, max(r1, r0 + 1))
+        a, b = int(rp_h[r0]), int(rp_h[r1])
+        seg = keys[a:b]
+        rowf = torch.div(seg, n_cols, rounding_mode="floor")
+        k = torch.arange(a, b, device=dev) - row_ptr[rowf]
+        off = slice_ptr[rowf // SLICE] + (k // KV) * (SLICE * KV) + (rowf % SLICE) * KV + (k % KV)
+        cols[off] = (seg - rowf * n_cols).to(torch.int32)
+        r0 = r1
     return SellPattern(n_rows, n_cols, slice_ptr, cols, row_len.to(torch.int32),
                        width.cpu().numpy().astype(np.int32))
 
