@@ -8,8 +8,6 @@ the coordinates of the constrained dofs only -- the reference interpolates the w
 from __future__ import annotations
 
 from enum import Enum
-from typing import Callable
-
 import numpy as np
 import torch
 

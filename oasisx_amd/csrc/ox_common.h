@@ -36,7 +36,6 @@ struct ox_dist {
   const int32_t *send_idx;  // device [send_off[n_peers]] owned rows to pack
   int64_t n_owned, n_ghost;
   double *send_buf;      // device [send_off[n_peers] * OX_MAXC]
-  double *recv_buf;      // unused
   // user transport (ox_dist_create_custom): replaces the RCCL calls, same pack kernel / call sites
   int (*halo_cb)(void *user, const double *send_dev, double *ghost_dev, int ncomp);
   int (*allreduce_cb)(void *user, double *buf_dev, int n);

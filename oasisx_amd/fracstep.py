@@ -27,9 +27,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .bcs import DirichletBC, PressureBC
-from .fem import (FieldStorage, Function, FunctionSpace, VectorFunctionSpace, cell_geometry,
-                  functionspace)
+from .fem import FieldStorage, Function, FunctionSpace, VectorFunctionSpace, cell_geometry
 from .ksp import KSPSolver
 from .la import SellMatrix
 

@@ -18,7 +18,7 @@ import typing
 import torch
 
 from . import _lib
-from .fem import FieldStorage, Function, Vector
+from .fem import FieldStorage, Function
 from .la import SellMatrix
 
 __all__ = ["KSPSolver"]

@@ -1,6 +1,4 @@
 """Parity of the HIP path against the CPU oracle -- every call goes through the C ABI."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
