@@ -158,6 +158,20 @@ class Mesh:
         return hmax
 
 
+# ---- arbitrary simplicial meshes ---------------------------------------------------------------
+
+
+def from_arrays(coords, cells, comm=None, device=None) -> Mesh:
+    """Mesh from vertex coordinates (nv, gdim) and cell->vertex ids (nc, gdim+1): any conforming
+    triangle / tetrahedron mesh, in any cell order and vertex orientation (the stand-in for the
+    reference's stubbed ``import_mesh``, src/oasisx/mesh.py:13-15).  Locality of the kernel data is
+    recovered by the spatial ordering of dofs and cells, not assumed from the input."""
+    dev = default_device() if device is None else torch.device(device)
+    c = torch.as_tensor(np.asarray(coords, dtype=np.float64)).to(dev)
+    t = torch.as_tensor(np.asarray(cells, dtype=np.int64)).to(dev)
+    return Mesh(c, t, comm if comm is not None else COMM_WORLD)
+
+
 # ---- generators (DOLFINx layouts) --------------------------------------------------------
 
 
