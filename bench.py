@@ -44,6 +44,10 @@ def parse():
                          "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--matrix-free", action="store_true",
+                    help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
+                         "terms instead of the pre-assembled rectangular operators (reference "
+                         "fracstep.py:392-404; the demo's default is the pre-assembled form)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); "
                          "gloo = rehearsal of the same partitioned path through the library's host-staged "
@@ -140,7 +144,8 @@ def main():
     solver_options = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"),
                       "scalar": dict(ksp, ksp_type="cg")}
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", args.udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
-                                solver_options=solver_options)
+                                solver_options=solver_options,
+                                options={"low_memory_version": args.matrix_free})
     for i, f in enumerate(fns):
         S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
         S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
@@ -203,7 +208,8 @@ def main():
             ("velocity_bcgs_spmv_v_narrowed", 12, ku, b_u1), ("velocity_bcgs_spmv_t_narrowed", 13, ku, b_u1),
             ("mass_cg_spmv", 10 * gd + 1, ku, b_u), ("mass_cg_spmv_narrowed", 11, ku, b_u1),
             ("mass_spmv", 10 * gd + 0, ku, b_u), ("assemble_first", 100, -1, None),
-            ("grad_vector_p", 110, -1, None), ("grad_vector_dp", 111, -1, None), ("div_vector", 120, -1, None)):
+            ("grad_vector_p", 110, -1, None), ("grad_vector_dp", 111, -1, None), ("div_vector", 120, -1, None),
+            ("rect_spmv_p_and_gradp", 140, -1, None), ("rect_spmv_div", 141, -1, None)):
         if key == kp and ku == kp and name != "pressure_cg_spmv":
             continue  # P1-P1: both matrices have the same size; keep the pressure entry only
         cnt, ms = prof(tag, key)
@@ -259,7 +265,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Taylor-Green {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
                                    f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
-                                   f"initial_guess_nonzero={not args.zero_guess}, max_iter=1",
+                                   f"initial_guess_nonzero={not args.zero_guess}, max_iter=1, "
+                                   f"low_memory_version={args.matrix_free}",
                        "cells": mesh.num_cells, "n_u_per_component": S._Vi[0][0].num_dofs_global,
                        "n_p": S._Q.num_dofs_global,
                        "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}" + ("" if args.backend == "nccl" or world == 1

@@ -102,6 +102,21 @@ int ox_device_info(int *n_cu, char *name, int name_len);
 int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp, const ox_dist *dist,
             void *stream);
 
+/* ---- S2: Mat.mult of the pre-assembled rectangular operators (low_memory_version = False,
+ *      reference fracstep.py:499-502, 540-542, 642).  One SELL pattern, gdim values per entry
+ *      (A->vals holds [slot][gdim]).
+ *      v2s = 0: y[row][d] = base[row][d] + scale * sum_k vals[k][d] * x[col_k]     (P_i ps, G_i dp)
+ *      v2s = 1: y[row]    = base[row]    + scale * sum_k sum_d vals[k][d] * x[col_k][d]  (sum_i D_i u_i)
+ *      base may be NULL. */
+int ox_spmv_multi(int v2s, int gdim, const ox_sell *A, const double *x, const double *base, double scale,
+                  double *y, const ox_dist *dist, void *stream);
+/* A9: one-off assemble_matrix of those operators (fracstep.py:392-404) into zero-initialised
+ * [slot][gdim] values.  family 0: p*v.dx(i)*dx (rows V, cols Q); 1: p.dx(i)*v*dx (rows V, cols Q);
+ * 2: u.dx(i)*q*dx (rows Q, cols V).  adj/adj_pos: adjacency of the ROW space with the in-row
+ * positions of the COLUMN space's cell dofs. */
+int ox_assemble_rect(int family, int row_degree, int col_degree, const ox_cells *cells, const ox_adj *adj,
+                     const uint8_t *adj_pos, int pw, const ox_sell *A, void *stream);
+
 /* ---- V1: Vec axpy/copy/scale on .x.array (fracstep.py:432-434,456-458,506,604,622,690-693) */
 /* z = a*x + b*y elementwise over n doubles (x, y, z may alias). */
 int ox_axpby(int64_t n, double a, const double *x, double b, const double *y, double *z,

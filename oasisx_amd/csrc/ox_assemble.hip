@@ -516,3 +516,100 @@ extern "C" int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cel
   OX_FAIL("ox_assemble_div_vector: unsupported gdim=%d row_degree=%d u_degree=%d", g, row_degree,
           u_degree);
 }
+
+// ---------------------------------------------------------------------------------------
+// One-off assembly of the rectangular operators (reference fracstep.py:392-404), values stored
+// [slot][GDIM].  lane = row; the lane adds every element-matrix row it owns straight into its
+// SELL row (the caller passes zero-initialised values) -- plain read-modify-write, single owner.
+//   FAM 0 (rows V, cols Q): P[r][c][d] = int psi_c d_d(phi_r)        (p * v.dx(i) * dx, :311-315)
+//   FAM 1 (rows V, cols Q): G[r][c][d] = int d_d(psi_c) phi_r        (p.dx(i) * v * dx, :348-352)
+//   FAM 2 (rows Q, cols V): D[r][c][d] = int d_d(phi_c) psi_r        (u.dx(i) * q * dx, :332-336)
+// ---------------------------------------------------------------------------------------
+template <int GDIM, int RDEG, int CDEG, int FAM, int PW>
+__global__ __launch_bounds__(256) void k_assemble_rect(ox_cells cells, ox_adj adj,
+                                                       const uint8_t *__restrict__ adj_pos, ox_sell A) {
+  using ER = Elem<GDIM, RDEG>;
+  using EC = Elem<GDIM, CDEG>;
+  const auto &R = rt<GDIM, RDEG>();
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= adj.n_slices) return;
+  const int64_t base = A.slice_ptr[slice];
+  const int64_t abase = adj.adj_ptr[slice];
+  const int T = (int)((adj.adj_ptr[slice + 1] - abase) >> 6);
+  for (int t = 0; t < T; ++t) {
+    const int64_t pidx = abase + (int64_t)t * 64 + lane;
+    const int e = adj.adj_cell[pidx];
+    if (e < 0) continue;
+    const int i = adj.adj_loc[pidx];
+    double G[GDIM + 1][GDIM], adet;
+    load_geom<GDIM>(cells.geom + (size_t)e * ER::GS, G, adet);
+    double c[EC::ND][GDIM];
+#pragma unroll
+    for (int j = 0; j < EC::ND; ++j)
+#pragma unroll
+      for (int d = 0; d < GDIM; ++d) c[j][d] = 0.0;
+#pragma unroll
+    for (int q = 0; q < ER::NQ; ++q) {
+      if constexpr (FAM == 0) {  // w psi_j(q) * grad phi_i(q)
+        double gi[GDIM];
+#pragma unroll
+        for (int d = 0; d < GDIM; ++d) {
+          gi[d] = 0.0;
+#pragma unroll
+          for (int b = 0; b <= GDIM; ++b) gi[d] = fma(R.dphi[i][q][b], G[b][d], gi[d]);
+          gi[d] *= ER::w(q);
+        }
+#pragma unroll
+        for (int j = 0; j < EC::ND; ++j)
+          if (EC::phi(q, j) != 0.0) {
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) c[j][d] = fma(EC::phi(q, j), gi[d], c[j][d]);
+          }
+      } else {  // FAM 1, 2: w phi_i(q) * grad (col basis)_j(q)
+        const double wp = R.wphi[i][q];
+#pragma unroll
+        for (int j = 0; j < EC::ND; ++j)
+#pragma unroll
+          for (int b = 0; b <= GDIM; ++b)
+            if (EC::dphi(q, j, b) != 0.0) {
+              const double f = wp * EC::dphi(q, j, b);
+#pragma unroll
+              for (int d = 0; d < GDIM; ++d) c[j][d] = fma(f, G[b][d], c[j][d]);
+            }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EC::ND; ++j) {
+      const int kk = adj_pos[pidx * PW + j];
+      double *v = A.vals + ((size_t)base + (size_t)(kk >> 1) * 128 + lane * 2 + (kk & 1)) * GDIM;
+#pragma unroll
+      for (int d = 0; d < GDIM; ++d) v[d] += adet * c[j][d];
+    }
+  }
+}
+
+extern "C" int ox_assemble_rect(int family, int row_degree, int col_degree, const ox_cells *cells,
+                                const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                                void *stream) {
+  if (!cells || !adj || !adj_pos || !A) OX_FAIL("ox_assemble_rect: null argument");
+  const int nblk = (adj->n_slices + 3) / 4;
+  if (nblk == 0) return 0;
+  hipStream_t st = ox_stream(stream);
+  const int g = cells->gdim;
+#define OX_RECT_CASE(GD, RD, CD, FM, P)                                                              \
+  if (g == GD && row_degree == RD && col_degree == CD && family == FM) {                             \
+    if (pw != P) OX_FAIL("ox_assemble_rect: adj_pos stride %d, expected %d", pw, P);                 \
+    hipLaunchKernelGGL((k_assemble_rect<GD, RD, CD, FM, P>), dim3(nblk), dim3(256), 0, st, *cells, *adj, \
+                       adj_pos, *A);                                                                 \
+    OX_LAUNCH_CHECK();                                                                               \
+    return 0;                                                                                        \
+  }
+#define OX_RECT_DIM(GD, PV2)                                                      \
+  OX_RECT_CASE(GD, 1, 1, 0, 4) OX_RECT_CASE(GD, 1, 1, 1, 4) OX_RECT_CASE(GD, 1, 1, 2, 4) \
+  OX_RECT_CASE(GD, 2, 1, 0, 4) OX_RECT_CASE(GD, 2, 1, 1, 4) OX_RECT_CASE(GD, 1, 2, 2, PV2)
+  OX_RECT_DIM(2, 8) OX_RECT_DIM(3, 16)
+#undef OX_RECT_DIM
+#undef OX_RECT_CASE
+  OX_FAIL("ox_assemble_rect: unsupported gdim=%d row_degree=%d col_degree=%d family=%d", g, row_degree,
+          col_degree, family);
+}

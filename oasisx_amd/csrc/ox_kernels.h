@@ -98,6 +98,8 @@ int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, 
 #define OX_TAG_GRAD_VECTOR 110
 #define OX_TAG_DIV_VECTOR 120
 #define OX_TAG_ASSEMBLE_MATRIX 130
+#define OX_TAG_RECT_S2V 140
+#define OX_TAG_RECT_V2S 141
 extern bool ox_prof_on;
 void ox_prof_start(int tag, hipStream_t st, long long key = 0);
 void ox_prof_stop(hipStream_t st);

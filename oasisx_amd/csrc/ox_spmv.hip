@@ -181,6 +181,75 @@ extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
 }
 
 // ---------------------------------------------------------------------------------------
+// Pre-assembled rectangular operators (reference low_memory_version = False,
+// fracstep.py:499-502, 540-542, 642): one SELL pattern, GD values per entry ([slot][GD]).
+//   S2V: y[row][d] = base[row][d] + scale * sum_k vals[k][d] * x[col_k]        (P_i ps, G_i dp)
+//   V2S: y[row]    = base[row] + scale * sum_k sum_d vals[k][d] * x[col_k][d]  (sum_i D_i u_i)
+// One pass reads the columns once for all GD components (4 + 8 GD bytes per entry).
+// (Nontemporal 16-B loads + unroll 4, which help k_spmv, measured 30 % SLOWER here.)
+// ---------------------------------------------------------------------------------------
+template <int GD, int V2S>
+__global__ __launch_bounds__(256) void k_spmv_multi(ox_sell A, const double *__restrict__ x,
+                                                    const double *__restrict__ base, double scale,
+                                                    double *__restrict__ y) {
+  const int ngroups = (A.n_slices + 3) >> 2;
+  const int chunk = (ngroups + 7) >> 3;
+  const int g = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);  // XCD-chunked, as k_spmv
+  if ((int)(blockIdx.x >> 3) >= chunk || g >= ngroups) return;
+  const int slice = g * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= A.n_slices) return;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const int64_t sbase = A.slice_ptr[slice];
+  const int npair = (int)((A.slice_ptr[slice + 1] - sbase) >> 7);
+  const double *__restrict__ vp = A.vals + (size_t)sbase * GD + (size_t)lane * 2 * GD;
+  const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + sbase) + lane;
+  double acc[GD];
+#pragma unroll
+  for (int d = 0; d < GD; ++d) acc[d] = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < npair; ++k) {
+    const int2 c = cp[(size_t)k * 64];
+    const double *v = vp + (size_t)k * 128 * GD;  // 2 slots x GD values, contiguous per lane
+    if (V2S) {
+      const double *x0 = x + (size_t)c.x * GD, *x1 = x + (size_t)c.y * GD;
+#pragma unroll
+      for (int d = 0; d < GD; ++d) acc[0] = fma(v[GD + d], x1[d], fma(v[d], x0[d], acc[0]));
+    } else {
+      const double x0 = x[c.x], x1 = x[c.y];
+#pragma unroll
+      for (int d = 0; d < GD; ++d) acc[d] = fma(v[GD + d], x1, fma(v[d], x0, acc[d]));
+    }
+  }
+  if (row < A.n_rows) {
+    if (V2S) {
+      y[row] = scale * acc[0] + (base ? base[row] : 0.0);
+    } else {
+#pragma unroll
+      for (int d = 0; d < GD; ++d) y[row * GD + d] = fma(scale, acc[d], base ? base[row * GD + d] : 0.0);
+    }
+  }
+}
+
+extern "C" int ox_spmv_multi(int v2s, int gdim, const ox_sell *A, const double *x, const double *base,
+                             double scale, double *y, const ox_dist *dist, void *stream) {
+  if (!A || !x || !y) OX_FAIL("ox_spmv_multi: null argument");
+  if (gdim != 2 && gdim != 3) OX_FAIL("ox_spmv_multi: gdim=%d", gdim);
+  hipStream_t st = ox_stream(stream);
+  if (dist && ox_halo_forward_impl(dist, const_cast<double *>(x), v2s ? gdim : 1, st)) return -1;
+  const int nblk = ox_spmv_blocks(A);
+  if (nblk == 0) return 0;
+  const int tag = v2s ? OX_TAG_RECT_V2S : OX_TAG_RECT_S2V;
+  if (ox_prof_on) ox_prof_start(tag, st, A->n_rows);
+  if (gdim == 2 && v2s) hipLaunchKernelGGL((k_spmv_multi<2, 1>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
+  if (gdim == 2 && !v2s) hipLaunchKernelGGL((k_spmv_multi<2, 0>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
+  if (gdim == 3 && v2s) hipLaunchKernelGGL((k_spmv_multi<3, 1>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
+  if (gdim == 3 && !v2s) hipLaunchKernelGGL((k_spmv_multi<3, 0>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
+  if (ox_prof_on) ox_prof_stop(st);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // Deterministic final reduction of per-block partials: sums[i] = sum_p partial[p*nv+i],
 // always in the same order (no float atomics anywhere on the path).
 // ---------------------------------------------------------------------------------------

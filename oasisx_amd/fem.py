@@ -545,6 +545,68 @@ def build_sell(n_rows, n_cols, keys, row_len, row_ptr, block: int = 1 << 27) -> 
                        width.cpu().numpy().astype(np.int32))
 
 
+def build_rect_pattern(R: "FunctionSpace", Cs: "FunctionSpace", block_pairs: int = 1 << 24):
+    """SELL-64 pattern of a rectangular operator (rows = owned dofs of R, columns = local dofs of
+    Cs) on the same mesh / partition, plus the position bytes [pairs of R.adj][pw] that give, per
+    (row, cell) pair, the in-row index of every Cs dof of the cell (reference fracstep.py:315,336,352:
+    ``create_matrix`` of the mixed forms)."""
+    dev = R.mesh.device
+    assert R.mesh is Cs.mesh and R.local_cells.shape == Cs.local_cells.shape
+    n_rows, n_cols, nd_r, nd_c = R.n_owned, Cs.n_local, R.nd, Cs.nd
+    dof = R.cell_dofs.reshape(-1).to(torch.int64)
+    order = torch.argsort(dof, stable=True)
+    dof_s = dof[order]
+    keep = dof_s < n_rows
+    order, dof_s = order[keep], dof_s[keep]
+    cell_s = torch.div(order, nd_r, rounding_mode="floor")
+    del dof, order, keep
+    cnt = torch.bincount(dof_s, minlength=n_rows)[:n_rows]
+    start = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    start[1:] = torch.cumsum(cnt, 0)
+    start_h = start.cpu().numpy()
+    cdofs = Cs.cell_dofs.to(torch.int64)
+    key_blocks, len_blocks = [], []
+    r0 = 0
+    while r0 < n_rows:
+        r1 = int(np.searchsorted(start_h, start_h[r0] + block_pairs, side="right")) - 1
+        r1 = min(n_rows, max(r1, r0 + 1))
+        a, b = int(start_h[r0]), int(start_h[r1])
+        kk = torch.unique((dof_s[a:b].unsqueeze(1) * n_cols + cdofs[cell_s[a:b]]).reshape(-1))
+        key_blocks.append(kk)
+        len_blocks.append(torch.bincount(torch.div(kk, n_cols, rounding_mode="floor") - r0, minlength=r1 - r0))
+        r0 = r1
+    keys = torch.cat(key_blocks)
+    row_len = torch.cat(len_blocks)
+    del key_blocks, len_blocks
+    row_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    row_ptr[1:] = torch.cumsum(row_len, 0)
+    pattern = build_sell(n_rows, n_cols, keys, row_len, row_ptr)
+    if int(pattern.widths.max()) > 255:
+        raise ValueError("row longer than 255 entries: position bytes overflow")
+    # positions, in the (padded) order of R's adjacency table
+    adj = R.adj
+    pw = 4 if nd_c <= 4 else (8 if nd_c <= 8 else 16)
+    npairs = int(adj.adj_cell.shape[0])
+    pos = torch.zeros((npairs, pw), dtype=torch.uint8, device=dev)
+    ap_h = adj.adj_ptr.cpu().numpy()
+    s0 = 0
+    while s0 < adj.n_slices:
+        s1 = int(np.searchsorted(ap_h, ap_h[s0] + block_pairs, side="right")) - 1
+        s1 = min(adj.n_slices, max(s1, s0 + 1))
+        a, b = int(ap_h[s0]), int(ap_h[s1])
+        pidx = torch.arange(a, b, device=dev)
+        cell = adj.adj_cell[a:b].to(torch.int64)
+        ok = cell >= 0
+        sl = torch.searchsorted(adj.adj_ptr[s0:s1 + 1], pidx, right=True) - 1 + s0
+        row = sl * SLICE + (pidx - adj.adj_ptr[sl]) % SLICE
+        pidx, cell, row = pidx[ok], cell[ok], row[ok]
+        g = torch.searchsorted(keys, (row.unsqueeze(1) * n_cols + cdofs[cell]).reshape(-1))
+        pos[pidx, :nd_c] = (g.reshape(-1, nd_c) - row_ptr[row].unsqueeze(1)).to(torch.uint8)
+        s0 = s1
+    pattern.dist = Cs.dist
+    return pattern, pos, pw
+
+
 def functionspace(mesh: Mesh, element, **kwargs):
     """``dolfinx.fem.functionspace(mesh, ("Lagrange", k))`` (also with a shape tuple)."""
     if isinstance(element, FunctionSpace):

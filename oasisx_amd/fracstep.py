@@ -7,10 +7,10 @@ Data layout on the device
     which share one matrix (reference fracstep.py:274,521,634), are multiplied and solved
     together: one pass over the matrix per SpMV instead of gdim;
   * M, K, A share one SELL-64 pattern (reference fracstep.py:293-294), Ap has its own;
-  * the p*-, div(u)- and grad(phi)-terms are always evaluated matrix-free (the reference's
-    ``low_memory_version=True`` path, fracstep.py:485-497,537-538,612-634); the option is
-    accepted and both settings give the same numbers (they differ in the reference only by
-    round-off, too).
+  * ``low_memory_version=True`` evaluates the p*-, div(u)- and grad(phi)-terms matrix-free
+    (fracstep.py:485-497,537-538,612-634); ``False`` pre-assembles the 3*gdim rectangular
+    operators (fracstep.py:311-315,332-336,348-352,392-404) as two SELL patterns with gdim values
+    per entry and applies them with one SpMV pass each (fracstep.py:499-502,540-542,642).
 
 Deviations from the reference, by necessity of the platform:
   * ``preonly``+``lu`` is mapped to a tightly converged Krylov solve (ksp.py);
@@ -29,7 +29,7 @@ import torch
 from . import _lib
 from .fem import FieldStorage, Function, FunctionSpace, VectorFunctionSpace, cell_geometry
 from .ksp import KSPSolver
-from .la import SellMatrix
+from .la import MultiSellMatrix, SellMatrix
 
 __all__ = ["FractionalStep_AB_CN"]
 
@@ -199,6 +199,14 @@ class FractionalStep_AB_CN:
         self._cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
         self._adj_u = Vi.adj.struct()
         self._adj_q = Q.adj.struct()
+        if not self._low_memory:
+            from .fem import build_rect_pattern
+
+            self._pat_vq, self._pos_vq, self._pw_vq = build_rect_pattern(Vi, Q)
+            self._pat_qv, self._pos_qv, self._pw_qv = build_rect_pattern(Q, Vi)
+            self._p_vdxi_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "p_vdxi")
+            self._grad_p_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "grad_p")
+            self._divu_Mat = MultiSellMatrix(self._pat_qv, mesh.gdim, "divu")
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
         self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")
         self._A = SellMatrix(Vi.pattern, symmetric=False, name="A")
@@ -226,6 +234,12 @@ class FractionalStep_AB_CN:
                 is_bc[bcp._dofs_dev.to(torch.int64)] = 1
             _lib.check(lib.ox_zero_rows_cols(self._Ap.ref(), _lib.ptr(is_bc), 1.0, st), "ox_zero_rows_cols")
             self._Ap.version += 1
+        if not self._low_memory:  # the rectangular operators (:392-404)
+            for fam, Mat, R_, C_, adj_, pos_, pw_ in ((0, self._p_vdxi_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
+                                                    (1, self._grad_p_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
+                                                    (2, self._divu_Mat, Q, Vi, self._adj_q, self._pos_qv, self._pw_qv)):
+                _lib.check(lib.ox_assemble_rect(fam, R_.degree, C_.degree, C.byref(self._cells), C.byref(adj_),
+                                                _lib.ptr(pos_), pw_, Mat.ref(), st), "ox_assemble_rect")
         # int phi_r dx on both spaces: body force vector (:387-390), mean of phi (:585-590)
         self._wV = torch.zeros(Vi.n_owned, dtype=torch.float64, device=dev)
         self._wQ = torch.zeros(Q.n_owned, dtype=torch.float64, device=dev)
@@ -265,6 +279,9 @@ class FractionalStep_AB_CN:
     def velocity_tentative_assemble(self):
         """rhs1_k = b_first_k + int p* dv/dx_k (reference fracstep.py:474-506)."""
         Vi, Q = self._Vi[0][0], self._Q
+        if not self._low_memory:  # P_i.mult(ps) (:499-502)
+            self._p_vdxi_Mat.mult(False, self._PS.ptr(), self._BFIRST.ptr(), 1.0, self._RHS1.ptr())
+            return
         _lib.check(self._lib.ox_assemble_grad_vector(0, Vi.degree, Q.degree, C.byref(self._cells),
                                                      _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
                                                      self._PS.ptr(), self._BFIRST.ptr(), 1.0, self._RHS1.ptr(),
@@ -291,10 +308,13 @@ class FractionalStep_AB_CN:
     def pressure_assemble(self, dt: float):
         """b2 = -(1/dt) int div(u) q (reference fracstep.py:527-551)."""
         Vi, Q = self._Vi[0][0], self._Q
-        _lib.check(self._lib.ox_assemble_div_vector(Q.degree, Vi.degree, C.byref(self._cells),
-                                                    _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.n_owned,
-                                                    self._U.ptr(), -1.0 / float(dt), self._B2.ptr(),
-                                                    _lib.current_stream()), "ox_assemble_div_vector")
+        if not self._low_memory:  # sum_i D_i.mult(u_i), scaled (:540-546)
+            self._divu_Mat.mult(True, self._U.ptr(), None, -1.0 / float(dt), self._B2.ptr())
+        else:
+            _lib.check(self._lib.ox_assemble_div_vector(Q.degree, Vi.degree, C.byref(self._cells),
+                                                        _lib.ptr(Vi.cell_dofs), C.byref(self._adj_q), Q.n_owned,
+                                                        self._U.ptr(), -1.0 / float(dt), self._B2.ptr(),
+                                                        _lib.current_stream()), "ox_assemble_div_vector")
         for bcp in self._bcs_p:  # homogeneous Dirichlet condition on the correction (:549-550)
             bcp.apply_homogeneous(self._b2.x)
 
@@ -332,10 +352,13 @@ class FractionalStep_AB_CN:
         Vi, Q = self._Vi[0][0], self._Q
         gdim = self._gdim
         self._M.mult(self._U.dev(), self._B3.dev(), gdim)
-        _lib.check(lib.ox_assemble_grad_vector(1, Vi.degree, Q.degree, C.byref(self._cells),
-                                               _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
-                                               self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr(), st),
-                   "ox_assemble_grad_vector")
+        if not self._low_memory:  # b3 -= dt * G_i.mult(dp) (:642-645)
+            self._grad_p_Mat.mult(False, self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr())
+        else:
+            _lib.check(lib.ox_assemble_grad_vector(1, Vi.degree, Q.degree, C.byref(self._cells),
+                                                   _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
+                                                   self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr(), st),
+                       "ox_assemble_grad_vector")
         return np.asarray(self._solver_c.solve_block(self._B3, self._U), dtype=np.int32)
 
     def solve(self, dt: float, nu: float, max_error: float = 1e-12, max_iter: int = 10):

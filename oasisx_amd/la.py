@@ -47,3 +47,28 @@ class SellMatrix:
         _lib.check(lib.ox_zero_rows(self.ref(), _lib.ptr(rows_dev), int(rows_dev.shape[0]), float(diag),
                                     _lib.current_stream()), "ox_zero_rows")
         self.version += 1
+
+
+class MultiSellMatrix:
+    """Rectangular operator with ``gdim`` values per entry on one SELL-64 pattern: the reference's
+    pre-assembled ``p*v.dx(i)*dx`` / ``p.dx(i)*v*dx`` / ``u.dx(i)*q*dx`` matrices for all i
+    (fracstep.py:311-315,332-336,348-352) stored together so one pass serves every component."""
+
+    def __init__(self, pattern: SellPattern, gdim: int, name: str = "R"):
+        self.pattern, self.gdim, self.name = pattern, gdim, name
+        self.vals = torch.zeros(pattern.size * gdim, dtype=torch.float64, device=pattern.device)
+        self._struct = _lib.ox_sell(pattern.n_rows, pattern.n_cols, pattern.n_slices, 0,
+                                    pattern.slice_ptr.data_ptr(), pattern.cols.data_ptr(), self.vals.data_ptr())
+
+    def ref(self):
+        return C.byref(self._struct)
+
+    def mult(self, v2s: bool, x, base, scale: float, y):
+        """y = base + scale * (A applied to x); x, base, y are device pointers (c_void_p)."""
+        lib = _lib.load()
+        _lib.check(lib.ox_spmv_multi(int(v2s), self.gdim, self.ref(), x, base, float(scale), y,
+                                     self.pattern.dist, _lib.current_stream()), "ox_spmv_multi")
+
+    def to_scipy(self, d: int):
+        """Component ``d`` as scipy CSR (tests)."""
+        return self.pattern.to_csr(self.vals.reshape(-1, self.gdim)[:, d].contiguous())

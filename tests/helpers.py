@@ -33,7 +33,7 @@ def on_boundary3(x):
 
 
 def make_hip_problem(dim, N, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=None, window=256,
-                     body_force=None, rotational=False):
+                     body_force=None, rotational=False, low_memory=True):
     """FractionalStep_AB_CN on the HIP path with the demo's set-up
     (reference demo/taylor_green.py:104-182)."""
     import oasisx_amd as ox
@@ -46,7 +46,8 @@ def make_hip_problem(dim, N, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_options=
              for f in fns]
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", u_deg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                 solver_options=solver_options or KRYLOV, body_force=body_force,
-                                options={"sell_window": window}, rotational=rotational)
+                                options={"sell_window": window, "low_memory_version": low_memory},
+                                rotational=rotational)
     for i, f in enumerate(fns):
         S._u2[i].interpolate(lambda x, f=f: f(x, t0 - dt, nu))
         S._u1[i].interpolate(lambda x, f=f: f(x, t0, nu))
@@ -65,8 +66,9 @@ def make_oracle_twin(S, mesh, dim, u_deg=2, nu=0.01, dt=0.005, t0=0.0, solver_op
 
 
 def run_tg_pair(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, hip_options=None, oracle_options=None,
-                rotational=False):
-    S, clock, mesh = make_hip_problem(dim, N, u_deg, nu, dt, solver_options=hip_options, rotational=rotational)
+                rotational=False, low_memory=True):
+    S, clock, mesh = make_hip_problem(dim, N, u_deg, nu, dt, solver_options=hip_options, rotational=rotational,
+                                      low_memory=low_memory)
     R, rclock = make_oracle_twin(S, mesh, dim, u_deg, nu, dt, solver_options=oracle_options, rotational=rotational)
     t = 0.0
     for _ in range(steps):

@@ -29,7 +29,7 @@ def _key(c):
     return k
 
 
-def _run(dim, N, deg, comm, steps):
+def _run(dim, N, deg, comm, steps, low_memory=True):
     import oasisx_amd as ox
     from oasisx_amd import mesh as M
     from oracle import ipcs_oracle as O
@@ -44,7 +44,7 @@ def _run(dim, N, deg, comm, steps):
     bcs = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"], nu), ox.LocatorMethod.GEOMETRICAL, marker)] for f in fns]
     opts = {k: dict(v, ksp_initial_guess_nonzero=True) for k, v in KRYLOV.items()}
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", deg), ("Lagrange", 1), bcs_u=bcs, bcs_p=[], solver_options=opts,
-                                options={"sell_window": 128})
+                                options={"sell_window": 128, "low_memory_version": low_memory})
     for i, f in enumerate(fns):
         S._u2[i].interpolate(lambda x, f=f: f(x, -dt, nu))
         S._u1[i].interpolate(lambda x, f=f: f(x, 0.0, nu))
@@ -56,7 +56,7 @@ def _run(dim, N, deg, comm, steps):
     return S, diffs
 
 
-def _worker(rank, world, port, dim, N, deg, out):
+def _worker(rank, world, port, dim, N, deg, low_memory, out):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -68,8 +68,8 @@ def _worker(rank, world, port, dim, N, deg, out):
 
         comm = init_comm()
         assert comm.size == world and comm.handle is None
-        S, diffs = _run(dim, N, deg, comm, steps=2)
-        G, gdiffs = _run(dim, N, deg, None, steps=2)
+        S, diffs = _run(dim, N, deg, comm, steps=2, low_memory=low_memory)
+        G, gdiffs = _run(dim, N, deg, None, steps=2, low_memory=low_memory)
         Vi, Q = S._Vi[0][0], S._Q
         assert Vi.dist is not None and Vi.n_local > Vi.n_owned
         kg = _key(G._Vi[0][0].x.cpu().numpy())
@@ -93,11 +93,12 @@ def _worker(rank, world, port, dim, N, deg, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dim,N,deg,world", [(3, 6, 2, 2), (2, 12, 2, 3), (3, 6, 1, 2)])
-def test_partitioned_steps_match_serial(hip, dim, N, deg, world):
+@pytest.mark.parametrize("dim,N,deg,world,low_memory", [(3, 6, 2, 2, True), (2, 12, 2, 3, True), (3, 6, 1, 2, True),
+                                                        (3, 6, 2, 2, False)])
+def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory):
     import torch.multiprocessing as mp
 
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, low_memory, out), nprocs=world, join=True)
     assert len(out) == world, dict(out)

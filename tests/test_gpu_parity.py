@@ -257,3 +257,25 @@ def test_lockstep_solve_narrows_to_the_last_live_column(hip, ksp, guess):
         assert abs(its[c] - it_ref) <= 1, (c, its, it_ref)
         assert np.abs(X.host()[:, c] - xr).max() <= 1e-8 * max(1e-3, np.abs(xr).max())
     assert its[2] > its[0] + 8 and its[1] == 0  # the narrowing path was taken
+
+
+@pytest.mark.parametrize("dim,N,deg", [(2, 6, 1), (2, 5, 2), (3, 3, 1), (3, 3, 2)])
+def test_preassembled_rectangular_operators(hip, dim, N, deg):
+    """low_memory_version=False (reference fracstep.py:311-315,332-336,348-352,392-404): the
+    3*gdim rectangular operators equal the oracle's, and steps run through them."""
+    from tests.helpers import make_hip_problem, make_oracle_twin, run_tg_pair
+
+    S, clock, mesh = make_hip_problem(dim, N, deg, low_memory=False)
+    R, _ = make_oracle_twin(S, mesh, dim, deg)
+    for i in range(dim):
+        for mine, ref in ((S._p_vdxi_Mat, R.F.p_vdxi_mat(i)), (S._grad_p_Mat, R.F.grad_p_mat(i)),
+                          (S._divu_Mat, R.F.divu_mat(i))):
+            d = abs(mine.to_scipy(i) - ref).max()
+            assert d <= 1e-13 * max(1.0, abs(ref).max()), (mine.name, i, d)
+    r = run_tg_pair(dim, N, deg, steps=2, low_memory=False)
+    assert r["du"] < 1e-8 and r["dp"] < 1e-7, (r["du"], r["dp"])
+    # and the two variants of the HIP path agree with each other to round-off x solver tolerance
+    r2 = run_tg_pair(dim, N, deg, steps=2, low_memory=True)
+    u1 = r["S"].u.x.array
+    u2 = r2["S"].u.x.array
+    assert np.abs(u1 - u2).max() < 1e-8
