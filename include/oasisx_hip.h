@@ -197,8 +197,11 @@ int ox_jacobi_setup(const ox_sell *A, double *dinv, void *stream);
 size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type);
 int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                  int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
-                 int check_every, void *work, size_t work_bytes, ox_ksp_result *result,
-                 const ox_dist *dist, void *stream);
+                 int check_every, int max_restarts, void *work, size_t work_bytes,
+                 ox_ksp_result *result, const ox_dist *dist, void *stream);
+/* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
+ * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
+ * continue, at most that many times per component (used when a direct solver was asked for). */
 
 /* ---- V3 + A10: nullspace.remove and mean shift (fracstep.py:573-574, 579-591) -------- */
 /* m = (sum_{i<n} w[i]*x[i], all ranks) / wsum;  x[i] -= m for i < n_apply (owned + ghost rows);

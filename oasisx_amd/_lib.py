@@ -93,7 +93,7 @@ SIGNATURES = {
                                     _P, _P]),
     "ox_jacobi_setup": (_I, [C.POINTER(ox_sell), _P, _P]),
     "ox_ksp_work_bytes": (C.c_size_t, [_L, _L, _I, _I]),
-    "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _P,
+    "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
                           C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),

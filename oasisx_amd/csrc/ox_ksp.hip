@@ -13,6 +13,8 @@ struct KspState {
   double rz[OX_MAXC], alpha[OX_MAXC], beta[OX_MAXC], omega[OX_MAXC], rho[OX_MAXC];
   double bn[OX_MAXC], rn[OX_MAXC];
   int active[OX_MAXC], reason[OX_MAXC], its[OX_MAXC];
+  int restart[OX_MAXC];   // BiCGStab: next k_bcgs_p re-seeds rhat <- r for this column
+  int nrestart[OX_MAXC];
   int done;  // all components finished
   int pad[2];
 };
@@ -23,6 +25,7 @@ struct KspParams {
   int nc;        // columns of THIS launch (sums are indexed 0..nc-1)
   int c0;        // state column of launch column 0 (narrowed continuation: the one live column)
   int nc_total;  // columns of the solve
+  int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
 };
 
 enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3 };
@@ -87,6 +90,8 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
     S->its[c] = 0;
     S->alpha[c] = 1.0;
     S->omega[c] = 1.0;
+    S->restart[c] = 0;
+    S->nrestart[c] = 0;
     const int r = ksp_test(S->rn[c], S->bn[c], P);
     S->reason[c] = r;
     S->active[c] = (r == 0);
@@ -98,6 +103,7 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
       S->active[c] = 0;
     }
   } else if (PH == PH_BCGS_1) {  // s = {rhat.v}
+    S->restart[c] = 0;  // consumed by the k_bcgs_p that ran just before
     if (S->active[c]) {
       const double rv = s[c];
       if (rv == 0.0 || !(rv == rv)) {
@@ -122,12 +128,25 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
       S->its[c] += 1;
       S->rn[c] = sqrt(s[c]);
       int r = ksp_test(S->rn[c], S->bn[c], P);
-      if (r == 0 && (S->omega[c] == 0.0 || s[NC + c] == 0.0)) r = OX_DIVERGED_BREAKDOWN;
+      bool reseed = false;
+      if (r == 0 && (S->omega[c] == 0.0 || s[NC + c] == 0.0)) {
+        // rho = rhat.r = 0 (or omega = 0) with an unconverged residual: PETSc stops here.  With
+        // restarts allowed, re-seed the shadow residual (rhat <- r, p <- r) and carry on.
+        if (S->nrestart[c] < P.max_restarts && s[c] > 0.0) reseed = true;
+        else r = OX_DIVERGED_BREAKDOWN;
+      }
       if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
       if (r) {
         S->reason[c] = r;
         S->active[c] = 0;
         S->beta[c] = 0.0;
+      } else if (reseed) {
+        S->restart[c] = 1;
+        S->nrestart[c] += 1;
+        S->rho[c] = s[c];  // rhat.r with rhat = r
+        S->beta[c] = 0.0;  // p = r
+        S->alpha[c] = 1.0;
+        S->omega[c] = 1.0;
       } else {
         S->beta[c] = (s[NC + c] / S->rho[c]) * (S->alpha[c] / S->omega[c]);
         S->rho[c] = s[NC + c];
@@ -380,19 +399,27 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
 template <int NC>
 __global__ __launch_bounds__(256) void k_bcgs_p(int64_t n, const KspState *S, int c0,
                                                 const double *__restrict__ vr, double *vp,
-                                                const double *__restrict__ vv) {
+                                                const double *__restrict__ vv, double *vrhat) {
   if (S->done) return;
   double beta[NC], omega[NC];
+  bool reseed[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     beta[c] = S->beta[c0 + c];
     omega[c] = S->omega[c0 + c];
+    reseed[c] = S->restart[c0 + c] != 0;
   }
   OX_ROW_LOOP {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int64_t i = row * NC + c;
-      vp[i] = fma(beta[c], fma(-omega[c], vv[i], vp[i]), vr[i]);
+      const double ri = vr[i];
+      if (reseed[c]) {  // restart after a breakdown: rhat <- r, p <- r
+        vrhat[i] = ri;
+        vp[i] = ri;
+      } else {
+        vp[i] = fma(beta[c], fma(-omega[c], vv[i], vp[i]), ri);
+      }
     }
   }
 }
@@ -544,7 +571,7 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v);
+    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
     if (C.dist && ox_halo_forward_impl(C.dist, V.p, NC, C.st)) return -1;
     if (ox_spmv_launch(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.st)) return -1;
@@ -663,8 +690,8 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
 
 extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
                             double *x, int ncomp, double rtol, double atol, int max_it,
-                            int nonzero_guess, int check_every, void *work, size_t work_bytes,
-                            ox_ksp_result *result, const ox_dist *dist, void *stream) {
+                            int nonzero_guess, int check_every, int max_restarts, void *work,
+                            size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
   if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS) OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
@@ -674,7 +701,7 @@ extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, 
   if (max_it < 1) max_it = 1;
   if (check_every < 1) check_every = 1;
   memset(result, 0, sizeof(*result));
-  KspParams P{rtol, atol, max_it, ncomp, 0, ncomp};
+  KspParams P{rtol, atol, max_it, ncomp, 0, ncomp, max_restarts < 0 ? 0 : max_restarts};
   hipStream_t st = ox_stream(stream);
   char *w = static_cast<char *>(work);
   switch (ncomp) {

@@ -9,6 +9,10 @@ Option mapping (PETSc string keys, as the reference passes them):
   pc_type   jacobi (also what lu/ilu/none/unset map to: the only preconditioner on the device)
   ksp_rtol, ksp_atol, ksp_max_it, ksp_initial_guess_nonzero: as in PETSc (defaults 1e-5,
             1e-50, 10000, false -> the solution vector is zeroed before the solve)
+  ksp_bcgs_restarts (extension): BiCGStab restarts allowed after a rho/omega breakdown; default 0
+            for an explicit "bcgs" (PETSc's KSPBCGS stops with DIVERGED_BREAKDOWN), 5 when the
+            method stands in for a direct solver, which cannot break down (e.g. a cold start with
+            identity-row Dirichlet conditions makes rho = 0 after one iteration)
 """
 from __future__ import annotations
 
@@ -110,8 +114,11 @@ class KSPSolver:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
         res = _lib.ox_ksp_result()
         every = self.check_every or (16 if (meth == _lib.KSP_CG and nc == 1) else 4)
+        # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
+        # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
+        restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
         _lib.check(lib.ox_ksp_solve(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
-                                    max_it, int(guess), int(every), _lib.ptr(self._work),
+                                    max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
                                     int(self._work.shape[0]), C.byref(res), A.pattern.dist, st),
                    "ox_ksp_solve")
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)

@@ -85,3 +85,44 @@ def test_cold_start_bicgstab_breakdown_is_reported_like_petsc(hip):
     assert errors[0] == _lib.DIVERGED_BREAKDOWN and errors[1] == _lib.CONVERGED_ATOL
     with pytest.raises(AssertionError):
         S.solve(0.05, 0.01)
+
+
+@pytest.mark.parametrize("dim,N", [(2, 8), (3, 4)])
+def test_cold_start_with_direct_solver_options(hip, dim, N):
+    """The reference demo's options (preonly + lu everywhere) from rest: a direct solver cannot break
+    down, so its Krylov stand-in restarts instead (ksp_bcgs_restarts) and matches the oracle's LU."""
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+    from oracle import ipcs_oracle as O
+    from tests.helpers import LU
+
+    nu, dt = 1e-2, 0.05
+    mesh = (M.create_unit_square(None, N, N) if dim == 2 else M.create_unit_cube(None, N, N, N))
+    top = dim - 1
+    lid = lambda x: np.isclose(x[top], 1.0)  # noqa: E731
+
+    def allb(x):
+        on = np.zeros(x.shape[1], dtype=bool)
+        for k in range(dim):
+            on |= np.isclose(x[k], 0.0) | np.isclose(x[k], 1.0)
+        return on
+
+    G = ox.LocatorMethod.GEOMETRICAL
+    bcs = [[ox.DirichletBC(0.0, G, allb), ox.DirichletBC(1.0, G, lid)]] + [[ox.DirichletBC(0.0, G, allb)] for _ in range(dim - 1)]
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, bcs_p=[], solver_options=LU,
+                                options={"sell_window": 128})
+    Vi, Q = S._Vi[0][0], S._Q
+    F = O.Forms(mesh.coords.cpu().numpy(), Vi.cells_in_kernel_order(), 2, 1, vd=Vi.cell_dofs.cpu().numpy(),
+                qd=Q.cell_dofs.cpu().numpy(), nv_dofs=Vi.num_dofs, nq_dofs=Q.num_dofs)
+    xv = Vi.x.cpu().numpy()
+    X = np.zeros((3, xv.shape[0]))
+    X[:dim] = xv.T
+    da, dl = np.nonzero(allb(X))[0], np.nonzero(lid(X))[0]
+    obcs = [[O.DirichletData(da, 0.0), O.DirichletData(dl, 1.0)]] + [[O.DirichletData(da, 0.0)] for _ in range(dim - 1)]
+    R = O.OracleFractionalStep(F, xv, Q.x.cpu().numpy(), obcs, solver_options=LU)
+    for _ in range(2):
+        S.solve(dt, nu, max_iter=1)
+        R.solve(dt, nu, max_iter=1)
+    assert np.abs(R.u1).max() > 0.5
+    assert np.abs(S.u.x.array.reshape(-1, dim) - R.u1).max() < 1e-7
+    assert np.abs(S._p.x.array - R.p).max() < 1e-5 * max(1.0, np.abs(R.p).max())
