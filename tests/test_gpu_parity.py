@@ -279,3 +279,40 @@ def test_preassembled_rectangular_operators(hip, dim, N, deg):
     u1 = r["S"].u.x.array
     u2 = r2["S"].u.x.array
     assert np.abs(u1 - u2).max() < 1e-8
+
+
+def test_kspsolver_public_solve_api(hip):
+    """KSPSolver(comm, options, prefix).setOperators(A); solve(b.x.petsc_vec, x) -> reason, on a
+    stand-alone field and on one column of an interleaved block (reference ksp.py:14-78)."""
+    from oasisx_amd import _lib, fem
+    from oasisx_amd.ksp import KSPSolver
+    from oasisx_amd.la import SellMatrix
+    from oracle import ipcs_oracle as O
+
+    mesh, V = _spaces(2, 8, 2)
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), 2, 1, vd=V.cell_dofs.cpu().numpy(),
+                qd=V.cells_in_kernel_order(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
+    Amat = (F.mass_v() * 10 + F.stiffness_v()).tocsr()
+    A = SellMatrix(V.pattern, symmetric=True)
+    A.vals.copy_(V.pattern.values_from_csr(Amat))
+    import scipy.sparse.linalg as spla
+
+    rng = np.random.default_rng(7)
+    bvec = rng.standard_normal(V.num_dofs)
+    ref = spla.spsolve(Amat.tocsc(), bvec)
+    s = KSPSolver(mesh.comm, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-12}, prefix="mine")
+    s.setOperators(A)
+    s.setOptions(A)
+    b, x = fem.Function(V), fem.Function(V)
+    b.x.array[:] = bvec
+    assert s.solve(b.x.petsc_vec, x) == _lib.CONVERGED_RTOL
+    assert np.abs(x.x.array - ref).max() < 1e-9
+    # one column of a 2-component block
+    S = fem.FieldStorage(V.num_dofs, 2, "cuda")
+    B = fem.FieldStorage(V.num_dofs, 2, "cuda")
+    x1, b1 = fem.Function(V, "x1", S, 1), fem.Function(V, "b1", B, 1)
+    b1.x.array[:] = bvec
+    s.updateOptions({"ksp_type": "preonly", "pc_type": "lu"})
+    assert s.solve(b1.x.petsc_vec, x1) == _lib.CONVERGED_ITS
+    assert np.abs(S.host()[:, 1] - ref).max() < 1e-9 and np.abs(S.host()[:, 0]).max() == 0.0
+    assert len(s.iterations) == 4
