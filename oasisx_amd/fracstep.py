@@ -138,6 +138,8 @@ class FractionalStep_AB_CN:
         self._b0 = [Function(Vi, f"b0_{i}", self._B0, i) for i in comp]
         self._b_first = [Function(Vi, f"b_first_{i}", self._BFIRST, i) for i in comp]
         self._wrk_vel = [Function(Vi, f"wrk_{i}", self._WRK, i) for i in comp]
+        self._wrk_comp = self._wrk_vel[0]  # reference fracstep.py:204 (work vector of one component)
+        self._b3 = Function(Vi, "b3", self._B3, 0)  # reference fracstep.py:341
 
         self._PS, self._P, self._DP, self._B2 = (FieldStorage(nq_, 1, dev) for _ in range(4))
         self._ps = Function(Q, "ps", self._PS, 0)
