@@ -408,6 +408,7 @@ class FunctionSpace:
             if getattr(comm, "make_transport", None) is not None and torch.cuda.is_available():
                 self.dist = comm.make_transport(self)
                 self.pattern.dist = self.dist
+                self.check_halo()
             return
         lib = _lib.load()
         h = self.halo
@@ -419,6 +420,25 @@ class FunctionSpace:
                                       self.n_local - self.n_owned, C.byref(out)), "ox_dist_create")
         self.dist = out
         self.pattern.dist = out
+        self.check_halo()
+
+    def check_halo(self):
+        """Self-test of the attached halo plan + transport: exchange the dof coordinates and require
+        every ghost entry to receive exactly its own coordinate (run once per space at set-up; a
+        wrong plan or a broken transport fails here, loudly, not as wrong physics later)."""
+        if self.dist is None:
+            return
+        lib = _lib.load()
+        d = self.mesh.gdim
+        X = self.x.clone().contiguous()
+        X[self.n_owned:] = float("nan")
+        _lib.check(lib.ox_halo_forward(self.dist, _lib.ptr(X), d, _lib.current_stream()), "ox_halo_forward")
+        if self.mesh.device.type == "cuda":
+            torch.cuda.synchronize()
+        if not torch.equal(X, self.x):
+            bad = int((X != self.x).any(dim=1).sum().item())
+            raise RuntimeError(f"halo exchange self-test failed: {bad} of {self.n_local - self.n_owned} ghost "
+                               f"dofs of the P{self.degree} space received a wrong value")
 
     # ---------------------------------------------------------------------------------
     def _build_adjacency(self, keys_sorted, row_ptr, chunk_pairs: int = 1 << 24):
