@@ -271,6 +271,7 @@ def main():
                        "n_p": S._Q.num_dofs_global,
                        "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}" + ("" if args.backend == "nccl" or world == 1
                                                                        else " (gloo rehearsal transport)")},
+            "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the metric's second figure
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
             "kernels": kernels,

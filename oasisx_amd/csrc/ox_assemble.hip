@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int3
       }
     }
 #pragma unroll
-    for (int j = 0; j < ND; ++j) acc[(int)pos[j] * 64 + lane] += adet * c[j];
+    for (int j = 0; j < ND; ++j)  // the slot is private to this lane: a no-return ds_add_f64 replaces read+add+write
+      __hip_atomic_fetch_add(&acc[(int)pos[j] * 64 + lane], adet * c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   // epilogue: stream the slice (coalesced 16-B values, 8-B columns)
   const int64_t row = (int64_t)slice * 64 + lane;
