@@ -22,6 +22,10 @@ def load():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libipcs_cpu.so")
+        if not os.path.exists(path):  # normally built by __graft_entry__.build(); gcc is on every box
+            import subprocess
+
+            subprocess.run(["make", "-s", "-C", _HERE], check=False)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not built: run `make -C oracle`")
         _LIB = C.CDLL(path)
