@@ -823,13 +823,18 @@ def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
         cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
         cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
         phi = np.stack(cols, axis=1)
-    cells = mesh.cells.cpu().numpy()[V.local_cells.cpu().numpy()]
+    lc = V.local_cells
+    cd = V.cell_dofs
+    if V.part is not None:  # integrate over the cells this rank owns (the ghost layer belongs to others)
+        mine = V.part.cell_rank[lc] == V.part.rank
+        lc, cd = lc[mine], cd[mine]
+    cells = mesh.cells[lc].cpu().numpy()
     xc = mesh.coords.cpu().numpy()[cells]
     xq = np.einsum("qa,cak->cqk", bary, xc)
     X = np.zeros((3, xq.shape[0] * xq.shape[1]))
     X[:d] = xq.reshape(-1, d).T
     ex = np.asarray(exact(X)).reshape(xq.shape[0], xq.shape[1])
-    uh = u.x.array[V.cell_dofs.cpu().numpy()] @ phi.T
+    uh = u.x.array[cd.cpu().numpy()] @ phi.T
     J = np.moveaxis(xc[:, 1:, :] - xc[:, :1, :], 1, 2)
     adet = np.abs(np.linalg.det(J))
     return float(np.einsum("q,cq,c->", w, (uh - ex) ** 2, adet))
