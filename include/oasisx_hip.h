@@ -212,8 +212,8 @@ int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, doubl
 /* ---- measurement: per-kernel HIP-event timing on the launching stream (bench.py) ------- */
 /* tags: 10*ncomp+epi for SpMV (epi 0 plain, 1 CG p.q, 2/3 BiCGStab), 100 assemble_first,
  * 110/111 grad vectors, 120 div vector. */
-int ox_set_spmv_variant(int v); /* kernel-variant switch of the SpMV micro-benchmark (bit0 nontemporal
-                                   matrix loads, bit1 unroll 8, bit2 unroll 16) */
+int ox_set_spmv_variant(int v); /* A/B switch of the SpMV micro-benchmark (tools/spmv_bench.py):
+                                   1 = nontemporal matrix loads (default), 0 = plain loads */
 int ox_profile_begin(int max_records, int sample_every); /* time every sample_every-th launch per tag */
 int ox_profile_end(void);
 int ox_profile_get(int tag, long long key, long long *count, double *total_ms); /* key: the matrix's

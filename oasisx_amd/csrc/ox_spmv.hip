@@ -86,16 +86,8 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
     };
-    if (VAR & 4) {
-#pragma unroll 16
-      for (int k = 0; k < npair; ++k) body(k);
-    } else if (VAR & 2) {
-#pragma unroll 8
-      for (int k = 0; k < npair; ++k) body(k);
-    } else {
-#pragma unroll 4
-      for (int k = 0; k < npair; ++k) body(k);
-    }
+#pragma unroll 4  // unroll 8 / 16 measured neutral to 17 % slower (tools/spmv_bench.py, round 1)
+    for (int k = 0; k < npair; ++k) body(k);
     if (row < A.n_rows) {
       if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
         const double d = dinv[row];  // one matrix, one diagonal
@@ -127,7 +119,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 #define OX_SPMV_DEFAULT_VARIANT 1  // nontemporal matrix stream (measured: tools/spmv_bench.py)
 static int g_spmv_variant = -1;
 extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 7;
+  g_spmv_variant = v & 1;
   return 0;
 }
 
@@ -138,7 +130,7 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 7 : OX_SPMV_DEFAULT_VARIANT;
+    g_spmv_variant = e ? atoi(e) & 1 : OX_SPMV_DEFAULT_VARIANT;
   }
   const int var = g_spmv_variant;
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
@@ -146,13 +138,8 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
-    switch (var) {                                                                              \
-      case 1: OX_SPMV_LAUNCH(NC, E, 1); break;                                                  \
-      case 2: OX_SPMV_LAUNCH(NC, E, 2); break;                                                  \
-      case 3: OX_SPMV_LAUNCH(NC, E, 3); break;                                                  \
-      case 5: OX_SPMV_LAUNCH(NC, E, 5); break;                                                  \
-      default: OX_SPMV_LAUNCH(NC, E, 0); break;                                                 \
-    }                                                                                           \
+    if (var) OX_SPMV_LAUNCH(NC, E, 1);                                                          \
+    else OX_SPMV_LAUNCH(NC, E, 0);                                                              \
     if (ox_prof_on) ox_prof_stop(st);                                                           \
     OX_LAUNCH_CHECK();                                                                          \
     return 0;                                                                                   \
