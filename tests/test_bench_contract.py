@@ -1,0 +1,49 @@
+"""bench.py's output contract: ONE JSON line with the driver's keys plus `roofline` and
+`cpu_baseline`.  CPU: the committed line of the last profiled run; GPU: a live small run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _check(d, live_cpu=True):
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d["unit"] == "steps/s" and d["higher_is_better"] is True and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] in ("strong", "weak")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (1e3 * r["avg_launch_us"])) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    if live_cpu:
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(c), c
+        assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1
+        assert c["gpu_vs_cpu_rel_l2_u"] < 1e-8 and c["gpu_vs_cpu_rel_l2_p"] < 1e-6
+
+
+def test_committed_bench_line_meets_the_contract():
+    path = os.path.join(ROOT, "profiles", "r01_bench_default_with_cpu_baseline.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    _check(d)
+    assert d["n_gpus"] == 1 and "128^3" in d["config"]["workload"]
+    assert d["roofline"]["traffic"] is not None  # PMC pass of the same command, profiles/*_pmc_hbm.csv
+
+
+@pytest.mark.gpu
+def test_bench_runs_and_prints_one_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "-N", "16", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    _check(d)
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
