@@ -48,6 +48,8 @@ def parse():
                     help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
                          "terms instead of the pre-assembled rectangular operators (reference "
                          "fracstep.py:392-404; the demo's default is the pre-assembled form)")
+    ap.add_argument("--profile-setup", action="store_true",
+                    help="cProfile the set-up phase and print rank 0's top entries to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); "
                          "gloo = rehearsal of the same partitioned path through the library's host-staged "
@@ -124,6 +126,12 @@ def main():
     def on_boundary(x):
         return (np.isclose(np.abs(x[0]), 1.0) | np.isclose(np.abs(x[1]), 1.0) | np.isclose(np.abs(x[2]), 1.0))
 
+    prof = None
+    if args.profile_setup:
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t_setup = time.perf_counter()
     comm = None
     if world > 1:
@@ -152,6 +160,12 @@ def main():
     S._p.interpolate(lambda x: tg_p(x, -dt / 2.0))
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        if rank == 0:
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     log(f"setup {t_setup:.1f} s; n_u={S._n_u} n_p={S._n_q} nnz_u={S._M.pattern.nnz} nnz_p={S._Ap.pattern.nnz}; "
         f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 

@@ -59,6 +59,11 @@ typedef struct {
   const int64_t *slice_ptr;  /* device [n_slices+1], entry offsets, multiples of 64*OX_KV */
   const int32_t *cols;       /* device [slice_ptr[n_slices]] (padding: own row, value 0) */
   double *vals;              /* device [slice_ptr[n_slices]]                             */
+  /* optional 16-bit column stream (ox_sell_compress_cols); both NULL = int32 columns only */
+  const uint16_t *cols16;    /* device [slice_ptr[n_slices]] codes: cols[e] =
+                                cbase[e / (64*OX_KV)][code >> 15] + (code & 0x7fff)         */
+  const int32_t *cbase;      /* device [slice_ptr[n_slices] / (64*OX_KV)][2]; [0] < 0 at the
+                                first pair of a slice: that slice is read from cols         */
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */
@@ -101,6 +106,13 @@ int ox_device_info(int *n_cu, char *name, int name_len);
 /* y[row*ncomp+c] = sum_k A[row,k] * x[col_k*ncomp+c]; ncomp in 1..3. */
 int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp, const ox_dist *dist,
             void *stream);
+
+/* Set-up: 16-bit column stream of a pattern for ox_spmv / ox_ksp_solve (10 instead of 12 bytes
+ * per stored entry; results are bit-identical).  cols16: [slice_ptr[n_slices]] uint16, cbase:
+ * [slice_ptr[n_slices] / (64*OX_KV)][2] int32, both caller-allocated device arrays that the caller then
+ * sets in ox_sell.  n_compressed (host, may be NULL): stored entries now read as 16 bit. */
+int ox_sell_compress_cols(const ox_sell *A, uint16_t *cols16, int32_t *cbase, int64_t *n_compressed,
+                          void *stream);
 
 /* ---- S2: Mat.mult of the pre-assembled rectangular operators (low_memory_version = False,
  *      reference fracstep.py:499-502, 540-542, 642).  One SELL pattern, gdim values per entry

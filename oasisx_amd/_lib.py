@@ -30,6 +30,8 @@ class ox_sell(C.Structure):
         ("slice_ptr", C.c_void_p),
         ("cols", C.c_void_p),
         ("vals", C.c_void_p),
+        ("cols16", C.c_void_p),
+        ("cbase", C.c_void_p),
     ]
 
 
@@ -73,6 +75,7 @@ SIGNATURES = {
     "ox_sell_kv": (_I, []),
     "ox_device_info": (_I, [C.POINTER(_I), C.c_char_p, _I]),
     "ox_spmv": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
+    "ox_sell_compress_cols": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _P]),
     "ox_spmv_multi": (_I, [_I, _I, C.POINTER(ox_sell), _P, _P, _D, _P, _P, _P]),
     "ox_assemble_rect": (_I, [_I, _I, _I, C.POINTER(ox_cells), C.POINTER(ox_adj), _P, _I, C.POINTER(ox_sell), _P]),
     "ox_axpby": (_I, [_L, _D, _P, _D, _P, _P, _P]),

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 #pragma unroll
   for (int i = 0; i < NV; ++i) s[i] = 0.0;
   for (int g = g_begin + (blockIdx.x >> 3); g < g_end; g += per) {
-    const int slice = g * 4 + wave;
+    const int slice = __builtin_amdgcn_readfirstlane(g * 4 + wave);  // wave-uniform: scalar loads below
     if (slice >= A.n_slices) continue;
     const int64_t row = (int64_t)slice * 64 + lane;
     double acc[NC];
@@ -62,32 +62,59 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
     const int64_t base = A.slice_ptr[slice];
     const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);  // width / OX_KV
     const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
-    const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
-    auto body = [&](int k) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+    auto load_vals = [&](int k) {
       double2 v;
-      int2 c;
       if (VAR & 1) {
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        typedef int v2i __attribute__((ext_vector_type(2)));
         const v2d vv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(vp + (size_t)k * 64));
-        const v2i ci = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(cp + (size_t)k * 64));
         v.x = vv.x;
         v.y = vv.y;
-        c.x = ci.x;
-        c.y = ci.y;
       } else {
         v = vp[(size_t)k * 64];
-        c = cp[(size_t)k * 64];
       }
-      const double *x0 = x + (size_t)c.x * NC;
-      const double *x1 = x + (size_t)c.y * NC;
+      return v;
+    };
+    auto mac = [&](double2 v, int c0, int c1) {
+      const double *x0 = x + (size_t)c0 * NC;
+      const double *x1 = x + (size_t)c1 * NC;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.x, x0[cc], acc[cc]);
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
     };
+    // 16-bit column stream (ox_sell_compress_cols): col = cbase[pair][bit 15 of the code] + low 15
+    // bits, 10 B per entry instead of 12.  cbase[first pair of the slice][0] < 0: this slice keeps
+    // its int32 columns.
+    const int2 *__restrict__ cb =
+        (VAR & 2) ? reinterpret_cast<const int2 *>(A.cbase) + (base >> 7) : nullptr;
+    if ((VAR & 2) && cb[0].x >= 0) {
+      const v2h *__restrict__ hp = reinterpret_cast<const v2h *>(A.cols16 + base) + lane;
+#pragma unroll 4
+      for (int k = 0; k < npair; ++k) {
+        const double2 v = load_vals(k);
+        const v2h d = __builtin_nontemporal_load(hp + (size_t)k * 64);
+        const int2 b = cb[k];
+        const int dx = d.x, dy = d.y;
+        mac(v, ((dx & 0x8000) ? b.y : b.x) + (dx & 0x7fff), ((dy & 0x8000) ? b.y : b.x) + (dy & 0x7fff));
+      }
+    } else {
+      const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
 #pragma unroll 4  // unroll 8 / 16 measured neutral to 17 % slower (tools/spmv_bench.py, round 1)
-    for (int k = 0; k < npair; ++k) body(k);
+      for (int k = 0; k < npair; ++k) {
+        const double2 v = load_vals(k);
+        int2 c;
+        if (VAR & 1) {
+          const v2i ci = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(cp + (size_t)k * 64));
+          c.x = ci.x;
+          c.y = ci.y;
+        } else {
+          c = cp[(size_t)k * 64];
+        }
+        mac(v, c.x, c.y);
+      }
+    }
     if (row < A.n_rows) {
       if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
         const double d = dinv[row];  // one matrix, one diagonal
@@ -116,10 +143,12 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   }
 }
 
-#define OX_SPMV_DEFAULT_VARIANT 1  // nontemporal matrix stream (measured: tools/spmv_bench.py)
+// bit 0: nontemporal matrix stream; bit 1: 16-bit column stream where the matrix carries one
+// (measured: tools/spmv_bench.py)
+#define OX_SPMV_DEFAULT_VARIANT 3
 static int g_spmv_variant = -1;
 extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 1;
+  g_spmv_variant = v & 3;
   return 0;
 }
 
@@ -130,15 +159,17 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 1 : OX_SPMV_DEFAULT_VARIANT;
+    g_spmv_variant = e ? atoi(e) & 3 : OX_SPMV_DEFAULT_VARIANT;
   }
-  const int var = g_spmv_variant;
+  const int var = (A->cols16 && A->cbase) ? g_spmv_variant : (g_spmv_variant & 1);
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
   hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
-    if (var) OX_SPMV_LAUNCH(NC, E, 1);                                                          \
+    if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                     \
+    else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \
+    else if (var == 1) OX_SPMV_LAUNCH(NC, E, 1);                                                \
     else OX_SPMV_LAUNCH(NC, E, 0);                                                              \
     if (ox_prof_on) ox_prof_stop(st);                                                           \
     OX_LAUNCH_CHECK();                                                                          \
@@ -165,6 +196,81 @@ extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
     if (rc) return rc;
   }
   return ox_spmv_launch(A, x, y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// 16-bit column stream.  In SELL-64 row order the k-th entries of a slice's 64 rows lie close
+// together (same stencil offset of neighbouring rows), or in two such groups where the slice mixes
+// rows next to a far block of the numbering with rows that are not.  Per pair of storage columns
+// (128 entries) two int32 bases + 16-bit codes (bit 15 = which base, low 15 bits = offset)
+// reproduce the int32 columns exactly.  A slice with a pair that needs a third base keeps its
+// int32 columns (cbase[first pair][0] = -1).  One wave per slice; set-up time only.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int ox_wave_min_all(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int ox_wave_max_all(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_compress_cols(ox_sell A, uint16_t *__restrict__ cols16,
+                                                       int32_t *__restrict__ cbase,
+                                                       unsigned long long *n_ok) {
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= A.n_slices) return;
+  const int64_t base = A.slice_ptr[slice];
+  const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
+  const int2 *cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+  ushort2 *hp = reinterpret_cast<ushort2 *>(cols16 + base) + lane;
+  int2 *bp = reinterpret_cast<int2 *>(cbase) + (base >> 7);
+  const int BIG = 0x7fffffff;
+  bool ok = true;
+  for (int k = 0; k < npair; ++k) {
+    const int2 c = cp[(size_t)k * 64];
+    const int lo = ox_wave_min_all(min(c.x, c.y));
+    // second group: everything the first base cannot reach
+    const bool fx = c.x - lo >= 32768, fy = c.y - lo >= 32768;
+    const int lo2 = ox_wave_min_all(min(fx ? c.x : BIG, fy ? c.y : BIG));
+    const int hi2 = ox_wave_max_all(max(fx ? c.x : -1, fy ? c.y : -1));
+    const bool fits = (lo2 == BIG) || (hi2 - lo2 < 32768);
+    ok = ok && fits;
+    ushort2 d;
+    d.x = !fits ? 0 : (unsigned short)(fx ? (0x8000 | (c.x - lo2)) : (c.x - lo));
+    d.y = !fits ? 0 : (unsigned short)(fy ? (0x8000 | (c.y - lo2)) : (c.y - lo));
+    hp[(size_t)k * 64] = d;
+    if (lane == 0) bp[k] = make_int2(lo, lo2 == BIG ? lo : lo2);
+  }
+  if (lane == 0 && npair > 0) {
+    if (!ok) bp[0].x = -1;
+    else if (n_ok) atomicAdd(n_ok, (unsigned long long)npair * 128ull);
+  }
+}
+
+extern "C" int ox_sell_compress_cols(const ox_sell *A, uint16_t *cols16, int32_t *cbase,
+                                     int64_t *n_compressed, void *stream) {
+  if (!A || !cols16 || !cbase) OX_FAIL("ox_sell_compress_cols: null argument");
+  hipStream_t st = ox_stream(stream);
+  if (n_compressed) *n_compressed = 0;
+  if (A->n_slices == 0) return 0;
+  unsigned long long *cnt = nullptr;
+  if (n_compressed) {
+    OX_HIP(hipMalloc(&cnt, sizeof(*cnt)));
+    OX_HIP(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
+  }
+  hipLaunchKernelGGL(k_compress_cols, dim3((A->n_slices + 3) / 4), dim3(256), 0, st, *A, cols16, cbase, cnt);
+  OX_LAUNCH_CHECK();
+  if (n_compressed) {
+    unsigned long long h = 0;
+    OX_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    OX_HIP(hipStreamSynchronize(st));
+    OX_HIP(hipFree(cnt));
+    *n_compressed = (int64_t)h;
+  }
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -101,6 +101,8 @@ class SellPattern:
         self.nnz = int(row_len.sum().item())
         self.device = cols.device
         self.dist = None  # ox_dist* (halo plan) of the column space, mesh-partitioned runs
+        self.cols16 = self.cbase = None  # 16-bit column stream, built by struct() on the GPU
+        self.frac16 = 0.0
         # width bins for the LDS-accumulating row kernels
         w = torch.from_numpy(widths.astype(np.int64))
         order = torch.argsort(w, stable=True)
@@ -113,10 +115,25 @@ class SellPattern:
     def new_values(self) -> torch.Tensor:
         return torch.zeros(self.size, dtype=torch.float64, device=self.device)
 
-    def struct(self, vals: torch.Tensor) -> _lib.ox_sell:
-        assert vals.shape[0] == self.size and vals.dtype == torch.float64
+    def struct(self, vals: torch.Tensor, compress: bool = True) -> _lib.ox_sell:
+        """ox_sell of a value array on this pattern.  On the GPU the pattern's 16-bit column stream
+        is built on first use (``ox_sell_compress_cols``) and shared by all its matrices."""
+        assert vals.shape[0] % self.size == 0 and vals.dtype == torch.float64
+        c16 = cb = None
+        if compress and self.device.type == "cuda" and self.size > 0:
+            if self.cols16 is None:
+                self.cols16 = torch.empty(self.size, dtype=torch.int16, device=self.device)
+                self.cbase = torch.empty(2 * (self.size // (SLICE * KV)), dtype=torch.int32, device=self.device)
+                plain = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
+                                     self.cols.data_ptr(), None, None, None)
+                n16 = C.c_int64(0)
+                _lib.check(_lib.load().ox_sell_compress_cols(C.byref(plain), _lib.ptr(self.cols16),
+                                                             _lib.ptr(self.cbase), C.byref(n16),
+                                                             _lib.current_stream()), "ox_sell_compress_cols")
+                self.frac16 = n16.value / self.size  # share of the stored entries read as 16 bit
+            c16, cb = self.cols16.data_ptr(), self.cbase.data_ptr()
         return _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                            self.cols.data_ptr(), vals.data_ptr())
+                            self.cols.data_ptr(), vals.data_ptr(), c16, cb)
 
     def bins_args(self):
         return (int(self.bin_width.shape[0]), self.bin_ptr.ctypes.data_as(C.POINTER(C.c_int64)),

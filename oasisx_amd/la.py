@@ -57,8 +57,7 @@ class MultiSellMatrix:
     def __init__(self, pattern: SellPattern, gdim: int, name: str = "R"):
         self.pattern, self.gdim, self.name = pattern, gdim, name
         self.vals = torch.zeros(pattern.size * gdim, dtype=torch.float64, device=pattern.device)
-        self._struct = _lib.ox_sell(pattern.n_rows, pattern.n_cols, pattern.n_slices, 0,
-                                    pattern.slice_ptr.data_ptr(), pattern.cols.data_ptr(), self.vals.data_ptr())
+        self._struct = pattern.struct(self.vals, compress=False)
 
     def ref(self):
         return C.byref(self._struct)
