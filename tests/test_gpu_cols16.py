@@ -1,0 +1,107 @@
+"""16-bit column stream of the SELL-64 SpMV (ox_sell_compress_cols): the codes decode to the
+int32 columns exactly, the SpMV is bit-identical with and without them, and slices that need a
+third base fall back to their int32 columns."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode(P):
+    """Host decode of (cols16, cbase); returns (cols, compressed mask per slot)."""
+    code = P.cols16.cpu().numpy().view(np.uint16).astype(np.int64)
+    cb = P.cbase.cpu().numpy().reshape(-1, 2).astype(np.int64)
+    pair = np.arange(P.size) // 128
+    sp = P.slice_ptr.cpu().numpy()
+    first = cb[sp[:-1] // 128, 0]  # < 0: the slice keeps its int32 columns
+    slot_slice = np.searchsorted(sp, np.arange(P.size), side="right") - 1
+    comp = first[slot_slice] >= 0
+    dec = np.where(code >= 32768, cb[pair, 1], cb[pair, 0]) + (code & 0x7FFF)
+    return dec, comp
+
+
+@pytest.mark.parametrize("dim,N,deg", [(2, 24, 2), (3, 10, 2), (3, 20, 1)])
+def test_codes_decode_to_the_int32_columns(dim, N, deg):
+    from oasisx_amd import fem
+    from oasisx_amd.la import SellMatrix
+    from tests.helpers import tg_mesh
+
+    V = fem.FunctionSpace(tg_mesh(dim, N), deg)
+    P = V.pattern
+    SellMatrix(P)  # builds the stream
+    assert P.cols16 is not None and 0.0 < P.frac16 <= 1.0
+    dec, comp = _decode(P)
+    cols = P.cols.cpu().numpy().astype(np.int64)
+    assert comp.mean() == pytest.approx(P.frac16)
+    np.testing.assert_array_equal(dec[comp], cols[comp])
+
+
+def _random_pattern(n, row_cols, device):
+    """SELL pattern from explicit per-row column lists."""
+    from oasisx_amd import fem
+
+    keys, lens = [], []
+    for r, cs in enumerate(row_cols):
+        cs = np.unique(np.asarray(cs, dtype=np.int64))
+        keys.append(r * n + cs)
+        lens.append(len(cs))
+    tail = np.arange(len(row_cols), n, dtype=np.int64)  # remaining rows: diagonal only
+    keys = torch.as_tensor(np.concatenate(keys + [tail * n + tail]), device=device)
+    row_len = torch.as_tensor(np.concatenate([np.asarray(lens, dtype=np.int64), np.ones(len(tail), dtype=np.int64)]),
+                              device=device)
+    row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(row_len, 0)
+    return fem.build_sell(n, n, keys, row_len, row_ptr)
+
+
+def test_three_groups_fall_back_and_spmv_is_bit_identical():
+    from oasisx_amd import _lib
+    from oasisx_amd.la import SellMatrix
+
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(7)
+    n = 64 * 6
+    big = 400000
+    nn = big + n
+    rows = []
+    for r in range(n):
+        s = r // 64
+        cs = [r, (r + 1) % n]
+        if s == 1:  # two groups: near + one far block -> still 16 bit
+            cs += [100000 + r]
+        if s == 2:  # three groups in one storage pair for some lanes -> int32 fallback
+            cs += [100000 + r] if r % 2 else [300000 + r]
+            cs += [200000 + r]
+        if s == 3:  # one group wider than 15 bits but narrower than two -> second base
+            cs += [r + 40000]
+        rows.append(cs)
+    P = _random_pattern(nn, rows, dev)
+    A = SellMatrix(P)
+    slot_row, slot_k = P.slot_rows_k()
+    rl = np.zeros(P.n_slices * 64, dtype=np.int64)
+    rl[:nn] = P.row_len.cpu().numpy()
+    vals = np.where(slot_k < rl[slot_row], rng.uniform(0.5, 1.5, P.size), 0.0)  # padding slots hold 0
+    A.vals.copy_(torch.as_tensor(vals, device=dev))
+    dec, comp = _decode(P)
+    cols = P.cols.cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(dec[comp], cols[comp])
+    sp = P.slice_ptr.cpu().numpy()
+    first = P.cbase.cpu().numpy().reshape(-1, 2)[sp[:-1] // 128, 0]
+    assert first[2] < 0, "the three-group slice must keep its int32 columns"
+    assert (first[[0, 1, 3, 4, 5]] >= 0).all()
+    lib = _lib.load()
+    for nc in (1, 3):
+        x = torch.as_tensor(rng.standard_normal((nn, nc)), device=dev).contiguous()
+        ys = []
+        for var in (1, 3):
+            lib.ox_set_spmv_variant(var)
+            y = torch.zeros_like(x)
+            A.mult(x, y, nc)
+            ys.append(y.cpu().numpy())
+        lib.ox_set_spmv_variant(3)
+        np.testing.assert_array_equal(ys[0], ys[1])
+        ref = P.to_csr(A.vals) @ x.cpu().numpy()
+        np.testing.assert_allclose(ys[1], ref, rtol=1e-13, atol=1e-13)
