@@ -242,6 +242,22 @@ int ox_comm_destroy(void *comm);
 int ox_dist_create(void *comm, int rank, int nranks, int n_peers, const int32_t *peers,
                    const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
                    int64_t n_owned, int64_t n_ghost, ox_dist **out);
+/* Direct xGMI transport for a plan (alternative to the RCCL calls; `comm` of ox_dist_create may then
+ * be NULL).  Every rank creates one uncached window of ox_p2p_window_bytes(nranks, its n_ghost)
+ * bytes, hands the 64-byte IPC handle to all ranks out of band, opens theirs, and enables the
+ * transport with: rank_wins[nranks] (own window at [rank]), and per peer of the plan the dof offset
+ * of THIS rank's block inside the peer's ghost block (the peer's recv_off for this rank) and the
+ * peer's n_ghost.  The plan then owns the window and the mappings.  Exchanges wait at most
+ * timeout_s for a peer; ox_dist_status reports a time-out (sticky). */
+size_t ox_p2p_window_bytes(int nranks, int64_t n_ghost);
+int ox_p2p_window_create(size_t bytes, void **win_dev, char *handle64);
+int ox_p2p_window_open(const char *handle64, void **win_dev);
+int ox_p2p_window_close(void *win_dev);
+int ox_p2p_window_free(void *win_dev);
+int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wins, const int64_t *peer_recv_off,
+                       const int64_t *peer_n_ghost, double timeout_s);
+int ox_dist_disable_p2p(ox_dist *d);
+int ox_dist_status(const ox_dist *d);
 /* Same plan on a caller-supplied transport instead of RCCL (rehearsals on one GPU, other
  * fabrics): halo_cb(user, packed_send_values_dev, ghost_block_dev, ncomp) and
  * allreduce_cb(user, buf_dev, n) are called at the points where ncclSend/ncclRecv and

@@ -108,6 +108,14 @@ SIGNATURES = {
     "ox_comm_destroy": (_I, [_P]),
     "ox_dist_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
                             C.POINTER(_L), _L, _L, C.POINTER(_P)]),
+    "ox_p2p_window_bytes": (C.c_size_t, [_I, _L]),
+    "ox_p2p_window_create": (_I, [C.c_size_t, C.POINTER(_P), C.c_char_p]),
+    "ox_p2p_window_open": (_I, [C.c_char_p, C.POINTER(_P)]),
+    "ox_p2p_window_close": (_I, [_P]),
+    "ox_p2p_window_free": (_I, [_P]),
+    "ox_dist_enable_p2p": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_L), C.POINTER(_L), _D]),
+    "ox_dist_disable_p2p": (_I, [_P]),
+    "ox_dist_status": (_I, [_P]),
     "ox_dist_create_custom": (_I, [_I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P, C.POINTER(_L), _L, _L,
                                    _P, _P, _P, C.POINTER(_P)]),
     "ox_memcpy": (_I, [_P, _P, C.c_size_t, _I, _P]),

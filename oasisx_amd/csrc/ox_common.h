@@ -26,6 +26,27 @@ extern thread_local char ox_err_buf[512];
 
 #define OX_LAUNCH_CHECK() OX_HIP(hipGetLastError())
 
+// Direct xGMI transport of a halo plan (ox_dist.hip): every rank owns one uncached window that
+// its peers map through HIP IPC and write into (halo values, all-reduce contributions, sequence
+// flags).  Host-side sequence counters advance with every enqueued exchange.
+struct ox_p2p {
+  char *win;             // this rank's window (device, uncached)
+  size_t win_bytes;
+  int64_t n_ghost;       // ghost dofs of this rank (staging = 2 x n_ghost x OX_MAXC doubles)
+  int32_t *peers_dev;    // device [n_peers]
+  int64_t *send_off_dev; // device [n_peers+1]
+  double **r_stage;      // device [n_peers*2]: peer's staging base for parity 0/1
+  int64_t *r_off;        // device [n_peers]: dof offset of this rank's block in the peer's ghosts
+  unsigned long long **r_hflag;  // device [n_peers*2]: this rank's halo flag in the peer's window
+  char **r_slot;         // device [nranks*2]: this rank's all-reduce slot in rank r's window
+  unsigned *ticket;      // device: last-block detection of the push kernel
+  int *err_host;         // pinned host: sticky time-out flag, written by the kernels
+  unsigned long long hseq, aseq;  // exchanges enqueued so far
+  long long timeout_ticks;        // wall_clock64 ticks a kernel waits for a peer
+  void **opened;         // host [n_opened]: IPC mappings to close
+  int n_opened;
+};
+
 // Halo plan + RCCL communicator (ox_dist.hip).  NULL everywhere = single GPU.
 struct ox_dist {
   void *comm;  // ncclComm_t
@@ -40,6 +61,7 @@ struct ox_dist {
   int (*halo_cb)(void *user, const double *send_dev, double *ghost_dev, int ncomp);
   int (*allreduce_cb)(void *user, double *buf_dev, int n);
   void *user;
+  ox_p2p *p2p;  // non-NULL: halo exchange and all-reduce go over the xGMI windows
 };
 
 // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give every XCD a

@@ -1,7 +1,16 @@
-// Mesh-partitioned runs: one process per GPU, RCCL over xGMI.  The halo exchange
-// (DOLFINx scatter_forward, reference fracstep.py:453,497,502,551,632,655; ksp.py:77) is a
-// pack kernel + one grouped ncclSend/ncclRecv per neighbour straight into the ghost block of
-// the vector; Krylov scalars are merged into one small ncclAllReduce per synchronisation point.
+// Mesh-partitioned runs: one process per GPU over xGMI.  The halo exchange (DOLFINx
+// scatter_forward, reference fracstep.py:453,497,502,551,632,655; ksp.py:77) and the all-reduce
+// of the Krylov scalars have two transports behind the same call sites:
+//  * RCCL: a pack kernel + one grouped ncclSend/ncclRecv per neighbour straight into the ghost
+//    block of the vector; one small ncclAllReduce per synchronisation point;
+//  * direct xGMI stores ("p2p"): every rank owns an uncached window that its peers map through HIP
+//    IPC.  The push kernel gathers the interface values and stores them straight into the
+//    neighbours' windows, followed by a sequence flag; the receiver's copy kernel waits for the
+//    flags and moves the staged values into the ghost block.  The all-reduce is one single-block
+//    kernel: store the contribution into every rank's window, wait for everybody's, sum in rank
+//    order (bit-identical on all ranks).  No library call and ~2 small kernels per exchange: the
+//    exchanges of a strong-scaled Krylov iteration are latency-, not bandwidth-bound.
+//    Every wait is bounded (time-out -> sticky error flag -> the host call fails).
 #include <rccl/rccl.h>
 
 #include <stdlib.h>
@@ -41,7 +50,7 @@ extern "C" int ox_dist_create(void *comm, int rank, int nranks, int n_peers, con
                               const int64_t *send_off, const int32_t *send_idx_dev,
                               const int64_t *recv_off, int64_t n_owned, int64_t n_ghost,
                               ox_dist **out) {
-  if (!comm || !out || nranks < 1 || rank < 0 || rank >= nranks) OX_FAIL("ox_dist_create: bad argument");
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks) OX_FAIL("ox_dist_create: bad argument");
   ox_dist *d = static_cast<ox_dist *>(calloc(1, sizeof(ox_dist)));
   if (!d) OX_FAIL("ox_dist_create: out of memory");
   d->comm = comm;
@@ -92,8 +101,269 @@ extern "C" int ox_memcpy(void *dst, const void *src, size_t bytes, int to_device
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// direct xGMI transport
+// ---------------------------------------------------------------------------------------------
+#define OX_P2P_SLOT 128  // bytes of one all-reduce slot: 15 doubles + the sequence flag
+#define OX_P2P_MAXV 15
+
+struct P2pLayout {
+  size_t ar, hf, st, st_stride, total;
+};
+static P2pLayout p2p_layout(int nranks, int64_t n_ghost) {
+  P2pLayout L;
+  L.ar = 0;
+  L.hf = (size_t)2 * nranks * OX_P2P_SLOT;
+  L.st = (L.hf + (size_t)2 * nranks * 8 + 255) & ~(size_t)255;
+  L.st_stride = (((size_t)n_ghost * OX_MAXC * 8) + 255) & ~(size_t)255;
+  L.total = L.st + 2 * L.st_stride;
+  if (L.total < 256) L.total = 256;
+  return L;
+}
+
+extern "C" size_t ox_p2p_window_bytes(int nranks, int64_t n_ghost) { return p2p_layout(nranks, n_ghost).total; }
+
+extern "C" int ox_p2p_window_create(size_t bytes, void **win_dev, char *handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+  if (!win_dev || !handle64 || bytes == 0) OX_FAIL("ox_p2p_window_create: bad argument");
+  void *p = nullptr;
+  // uncached: stores of a peer become visible without any cache maintenance on this side
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    OX_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+  }
+  OX_HIP(hipMemset(p, 0, bytes));
+  OX_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  OX_HIP(hipIpcGetMemHandle(&h, p));
+  memcpy(handle64, &h, sizeof(h));
+  *win_dev = p;
+  return 0;
+}
+
+extern "C" int ox_p2p_window_open(const char *handle64, void **win_dev) {
+  if (!handle64 || !win_dev) OX_FAIL("ox_p2p_window_open: bad argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  void *p = nullptr;
+  OX_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *win_dev = p;
+  return 0;
+}
+
+extern "C" int ox_p2p_window_close(void *win_dev) {
+  if (win_dev) OX_HIP(hipIpcCloseMemHandle(win_dev));
+  return 0;
+}
+
+extern "C" int ox_p2p_window_free(void *win_dev) {
+  if (win_dev) OX_HIP(hipFree(win_dev));
+  return 0;
+}
+
+template <class T>
+static int p2p_upload(T **dst, const T *src, size_t n) {
+  OX_HIP(hipMalloc(dst, sizeof(T) * (n ? n : 1)));
+  if (n) OX_HIP(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ox_dist_disable_p2p(ox_dist *d) {
+  if (!d || !d->p2p) return 0;
+  ox_p2p *q = d->p2p;
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < q->n_opened; ++i) (void)hipIpcCloseMemHandle(q->opened[i]);
+  free(q->opened);
+  (void)hipFree(q->peers_dev);
+  (void)hipFree(q->send_off_dev);
+  (void)hipFree(q->r_stage);
+  (void)hipFree(q->r_off);
+  (void)hipFree(q->r_hflag);
+  (void)hipFree(q->r_slot);
+  (void)hipFree(q->ticket);
+  if (q->err_host) (void)hipHostFree(q->err_host);
+  if (q->win) (void)hipFree(q->win);
+  free(q);
+  d->p2p = nullptr;
+  return 0;
+}
+
+extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wins,
+                                  const int64_t *peer_recv_off, const int64_t *peer_n_ghost,
+                                  double timeout_s) {
+  if (!d || !my_win || !rank_wins) OX_FAIL("ox_dist_enable_p2p: null argument");
+  if (d->p2p) OX_FAIL("ox_dist_enable_p2p: already enabled");
+  if (d->nranks > 64) OX_FAIL("ox_dist_enable_p2p: at most 64 ranks");
+  if (rank_wins[d->rank] != my_win) OX_FAIL("ox_dist_enable_p2p: rank_wins[rank] must be this rank's window");
+  ox_p2p *q = static_cast<ox_p2p *>(calloc(1, sizeof(ox_p2p)));
+  if (!q) OX_FAIL("ox_dist_enable_p2p: out of memory");
+  const int np = d->n_peers, nr = d->nranks;
+  q->win = static_cast<char *>(my_win);
+  q->n_ghost = d->n_ghost;
+  q->win_bytes = p2p_layout(nr, d->n_ghost).total;
+  q->opened = static_cast<void **>(calloc(nr, sizeof(void *)));
+  for (int r = 0; r < nr; ++r)
+    if (r != d->rank && rank_wins[r]) q->opened[q->n_opened++] = rank_wins[r];
+  // remote addresses: where THIS rank writes in its peers' windows
+  double *r_stage[2 * 64];
+  unsigned long long *r_hflag[2 * 64];
+  char *r_slot[2 * 64];
+  for (int p = 0; p < np; ++p) {
+    const int pr = d->peers[p];
+    if (pr < 0 || pr >= nr || !rank_wins[pr]) OX_FAIL("ox_dist_enable_p2p: window of peer %d missing", pr);
+    const P2pLayout L = p2p_layout(nr, peer_n_ghost[p]);
+    char *w = static_cast<char *>(rank_wins[pr]);
+    for (int par = 0; par < 2; ++par) {
+      r_stage[p * 2 + par] = reinterpret_cast<double *>(w + L.st + par * L.st_stride);
+      r_hflag[p * 2 + par] = reinterpret_cast<unsigned long long *>(w + L.hf) + (size_t)par * nr + d->rank;
+    }
+  }
+  for (int r = 0; r < nr; ++r) {
+    if (!rank_wins[r]) OX_FAIL("ox_dist_enable_p2p: window of rank %d missing", r);
+    char *w = static_cast<char *>(rank_wins[r]);
+    for (int par = 0; par < 2; ++par) r_slot[r * 2 + par] = w + ((size_t)par * nr + d->rank) * OX_P2P_SLOT;
+  }
+  if (p2p_upload(&q->peers_dev, d->peers, np)) return -1;
+  if (p2p_upload(&q->send_off_dev, d->send_off, np + 1)) return -1;
+  if (p2p_upload(&q->r_stage, r_stage, 2 * np)) return -1;
+  if (p2p_upload(&q->r_off, peer_recv_off, np)) return -1;
+  if (p2p_upload(&q->r_hflag, r_hflag, 2 * np)) return -1;
+  if (p2p_upload(&q->r_slot, r_slot, 2 * nr)) return -1;
+  OX_HIP(hipMalloc(&q->ticket, sizeof(unsigned)));
+  OX_HIP(hipMemset(q->ticket, 0, sizeof(unsigned)));
+  OX_HIP(hipHostMalloc(&q->err_host, sizeof(int), hipHostMallocMapped));
+  *q->err_host = 0;
+  q->timeout_ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);  // wall_clock64: 100 MHz
+  OX_HIP(hipDeviceSynchronize());
+  d->p2p = q;
+  return 0;
+}
+
+extern "C" int ox_dist_status(const ox_dist *d) {
+  if (d && d->p2p && *(volatile int *)d->p2p->err_host)
+    OX_FAIL("xGMI transport: a wait for a peer rank timed out (rank %d)", d->rank);
+  return 0;
+}
+
+#define OX_SYS __HIP_MEMORY_SCOPE_SYSTEM
+
+// wait until *flag >= seq; false on time-out (and the sticky error is raised)
+__device__ __forceinline__ bool p2p_wait(const unsigned long long *flag, unsigned long long seq,
+                                         long long timeout_ticks, int *err) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, OX_SYS)) return false;  // a peer is gone: do not wait again
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, OX_SYS) < seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, OX_SYS);
+      return false;
+    }
+  }
+  return true;
+}
+
+// gather the interface values and store them into the neighbours' windows; the last block to
+// finish raises this rank's flag in every neighbour's window
+__global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
+                                                   const int32_t *__restrict__ idx, int64_t ns, int nc,
+                                                   const int64_t *__restrict__ send_off, int n_peers,
+                                                   double *const *__restrict__ r_stage,
+                                                   const int64_t *__restrict__ r_off,
+                                                   unsigned long long *const *__restrict__ r_hflag,
+                                                   int parity, unsigned long long seq, unsigned *ticket) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < ns * nc) {
+    const int64_t k = i / nc;
+    const int c = (int)(i - k * nc);
+    int p = 0;
+    while (p + 1 < n_peers && k >= send_off[p + 1]) ++p;
+    const double v = x[(int64_t)idx[k] * nc + c];
+    double *dst = r_stage[p * 2 + parity] + (r_off[p] + (k - send_off[p])) * nc + c;
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, OX_SYS);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELEASE, OX_SYS);
+    }
+  }
+}
+
+// wait for every neighbour's flag, then move the staged values into the ghost block
+__global__ __launch_bounds__(256) void k_halo_pull(double *__restrict__ ghost, int64_t n, const double *stage,
+                                                   const unsigned long long *hflag,
+                                                   const int32_t *__restrict__ peers, int n_peers,
+                                                   unsigned long long seq, long long timeout_ticks, int *err) {
+  if ((int)threadIdx.x < n_peers) p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err);
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    ghost[i] = __hip_atomic_load(stage + i, __ATOMIC_RELAXED, OX_SYS);
+}
+
+// all-reduce (sum) of n <= 15 doubles: thread r talks to rank r
+__global__ __launch_bounds__(64) void k_allreduce_p2p(double *buf, int n, int nranks, char *const *__restrict__ r_slot,
+                                                      const char *my_slots, int parity, unsigned long long seq,
+                                                      long long timeout_ticks, int *err) {
+  __shared__ double sh[64][OX_P2P_MAXV + 1];
+  const int r = threadIdx.x;
+  if (r < nranks) {
+    char *dst = r_slot[r * 2 + parity];
+    for (int i = 0; i < n; ++i) __hip_atomic_store(reinterpret_cast<double *>(dst) + i, buf[i], __ATOMIC_RELAXED, OX_SYS);
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), seq, __ATOMIC_RELEASE, OX_SYS);
+    const char *src = my_slots + ((size_t)parity * nranks + r) * OX_P2P_SLOT;
+    p2p_wait(reinterpret_cast<const unsigned long long *>(src + OX_P2P_SLOT - 8), seq, timeout_ticks, err);
+    for (int i = 0; i < n; ++i) sh[r][i] = __hip_atomic_load(reinterpret_cast<const double *>(src) + i, __ATOMIC_RELAXED, OX_SYS);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    double s = 0.0;
+    for (int q = 0; q < nranks; ++q) s += sh[q][threadIdx.x];  // rank order: the same bits on every rank
+    buf[threadIdx.x] = s;
+  }
+}
+
+static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
+  ox_p2p *q = d->p2p;
+  const unsigned long long seq = ++q->hseq;
+  const int parity = (int)(seq & 1);
+  const int64_t ns = d->send_off[d->n_peers];
+  const int64_t tot = ns * ncomp;
+  const unsigned nblk = (unsigned)(tot > 0 ? (tot + 255) / 256 : 1);
+  hipLaunchKernelGGL(k_halo_push, dim3(nblk), dim3(256), 0, st, x, d->send_idx, ns, ncomp, q->send_off_dev,
+                     d->n_peers, q->r_stage, q->r_off, q->r_hflag, parity, seq, q->ticket);
+  OX_LAUNCH_CHECK();
+  const P2pLayout L = p2p_layout(d->nranks, d->n_ghost);
+  const int64_t ng = d->n_ghost * ncomp;
+  unsigned nb2 = (unsigned)((ng + 255) / 256);
+  if (nb2 < 1) nb2 = 1;
+  if (nb2 > 1024) nb2 = 1024;
+  hipLaunchKernelGGL(k_halo_pull, dim3(nb2), dim3(256), 0, st, x + d->n_owned * ncomp, ng,
+                     reinterpret_cast<const double *>(q->win + L.st + parity * L.st_stride),
+                     reinterpret_cast<const unsigned long long *>(q->win + L.hf) + (size_t)parity * d->nranks,
+                     q->peers_dev, d->n_peers, seq, q->timeout_ticks, q->err_host);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
+static int p2p_allreduce(const ox_dist *d, double *buf, int n, hipStream_t st) {
+  ox_p2p *q = d->p2p;
+  const unsigned long long seq = ++q->aseq;
+  const int parity = (int)(seq & 1);
+  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(64), 0, st, buf, n, d->nranks, q->r_slot, q->win, parity, seq,
+                     q->timeout_ticks, q->err_host);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ox_dist_destroy(ox_dist *d) {
   if (!d) return 0;
+  ox_dist_disable_p2p(d);
   if (d->send_buf) (void)hipFree(d->send_buf);
   free(d->peers);
   free(d->send_off);
@@ -113,6 +383,8 @@ __global__ void k_pack(const double *__restrict__ x, const int32_t *__restrict__
 
 int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
   if (!d || d->n_peers == 0) return 0;
+  if (d->p2p) return p2p_halo_forward(d, x, ncomp, st);
+  if (!d->comm && !d->halo_cb) OX_FAIL("ox_halo_forward: the plan has no transport (RCCL communicator, xGMI windows or callbacks)");
   ncclComm_t comm = static_cast<ncclComm_t>(d->comm);
   const int64_t ns = d->send_off[d->n_peers];
   if (ns > 0) {
@@ -143,6 +415,8 @@ int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st)
 
 int ox_allreduce_impl(const ox_dist *d, double *buf, int n, hipStream_t st) {
   if (!d || d->nranks == 1) return 0;
+  if (d->p2p && n <= OX_P2P_MAXV) return p2p_allreduce(d, buf, n, st);
+  if (!d->comm && !d->allreduce_cb) OX_FAIL("ox_allreduce_sum: the plan has no transport for %d values", n);
   if (d->allreduce_cb) {
     OX_HIP(hipStreamSynchronize(st));
     if (d->allreduce_cb(d->user, buf, n)) OX_FAIL("allreduce callback failed");

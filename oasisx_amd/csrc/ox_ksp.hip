@@ -607,7 +607,7 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
 static int ksp_read_state(const KspCtx &C) {
   OX_HIP(hipMemcpyAsync(g_state_host, C.S, sizeof(KspState), hipMemcpyDeviceToHost, C.st));
   OX_HIP(hipStreamSynchronize(C.st));
-  return 0;
+  return C.dist ? ox_dist_status(C.dist) : 0;  // a timed-out peer wait fails the solve
 }
 
 template <int NC>

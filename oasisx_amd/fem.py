@@ -417,27 +417,51 @@ class FunctionSpace:
                 "send_idx": send_idx}
 
     def attach_comm(self, comm):
-        """Create the device halo plan (ox_dist) of this space on an RCCL communicator (or on the
-        communicator's host-staged rehearsal transport when it has no RCCL handle)."""
+        """Create the device halo plan (ox_dist) of this space and give it a transport according to
+        ``comm.transport``: the direct xGMI windows (self-tested, collectively agreed), the RCCL
+        communicator, or the host-staged rehearsal transport (see oasisx_amd.parallel)."""
         if self.halo is None or comm is None:
             return
-        if comm.handle is None:
-            if getattr(comm, "make_transport", None) is not None and torch.cuda.is_available():
-                self.dist = comm.make_transport(self)
-                self.pattern.dist = self.dist
-                self.check_halo()
-            return
+        want = getattr(comm, "transport", "auto")
+        on_gpu = self.mesh.device.type == "cuda"
+        if not on_gpu:
+            return  # CPU: partition logic only, no device plan
         lib = _lib.load()
         h = self.halo
+
+        def host_transport():
+            self.dist = comm.make_transport(self)
+            self.pattern.dist = self.dist
+            self.check_halo()
+            comm.active[self.degree] = "host"
+
+        if want == "host" or (want == "rccl" and comm.handle is None):
+            if getattr(comm, "make_transport", None) is not None:
+                host_transport()
+            return
         out = C.c_void_p()
         _lib.check(lib.ox_dist_create(comm.handle, comm.rank, comm.size, int(h["peers"].shape[0]),
                                       h["peers"].ctypes.data_as(C.POINTER(C.c_int32)),
                                       h["send_off"].ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(h["send_idx"]),
                                       h["recv_off"].ctypes.data_as(C.POINTER(C.c_int64)), self.n_owned,
                                       self.n_local - self.n_owned, C.byref(out)), "ox_dist_create")
+        if want in ("auto", "p2p") and comm.enable_p2p(self, out):
+            self.dist = out
+            self.pattern.dist = out
+            comm.active[self.degree] = "p2p"
+            return
+        if want == "p2p":
+            raise RuntimeError("OX_TRANSPORT=p2p: the xGMI transport could not be enabled: "
+                               + getattr(comm, "p2p_error", "a peer rank failed"))
+        if comm.handle is None:  # no RCCL communicator (gloo job): rehearsal transport
+            lib.ox_dist_destroy(out)
+            self.dist = None
+            host_transport()
+            return
         self.dist = out
         self.pattern.dist = out
         self.check_halo()
+        comm.active[self.degree] = "rccl"
 
     def check_halo(self):
         """Self-test of the attached halo plan + transport: exchange the dof coordinates and require

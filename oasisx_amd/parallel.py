@@ -13,8 +13,11 @@ ksp.py:77).  Here:
   assembled locally and no matrix entries are ever communicated (PETSc's ``Mat.assemble``
   stash exchange disappears);
 * per SpMV the owner sends its interface values straight into the neighbour's ghost block
-  (grouped ncclSend/ncclRecv, ``ox_halo_forward``); per Krylov synchronisation point one small
-  ncclAllReduce merges all dot products.
+  (``ox_halo_forward``); per Krylov synchronisation point one small all-reduce merges all dot
+  products.  Two device transports sit behind those call sites: direct xGMI stores into
+  IPC-mapped windows (``p2p``, two small kernels per exchange) and RCCL (grouped
+  ncclSend/ncclRecv, ncclAllReduce).  ``OX_TRANSPORT=auto`` (default) enables p2p, self-tests it
+  collectively and keeps RCCL when any rank fails; ``p2p`` / ``rccl`` / ``host`` force one.
 """
 from __future__ import annotations
 
@@ -28,10 +31,108 @@ from .mesh import Mesh
 
 
 class Comm:
-    """Rank/size plus (on GPUs) the RCCL communicator handle used by liboasisx_hip.so."""
+    """Rank/size plus (on GPUs) the RCCL communicator handle used by liboasisx_hip.so and the
+    transport policy (see the module docstring)."""
 
-    def __init__(self, rank=0, size=1, handle=None):
+    def __init__(self, rank=0, size=1, handle=None, transport=None):
+        import os
+
         self.rank, self.size, self.handle = rank, size, handle
+        self.transport = (transport or os.environ.get("OX_TRANSPORT", "auto")).lower()
+        if self.transport not in ("auto", "p2p", "rccl", "host"):
+            raise ValueError(f"OX_TRANSPORT={self.transport!r}: expected auto, p2p, rccl or host")
+        self.active = {}  # space degree -> transport that ended up serving its plan
+
+    def _all_ok(self, ok: bool) -> bool:
+        """Collective AND over the ranks."""
+        import torch.distributed as dist
+
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def enable_p2p(self, V, plan) -> bool:
+        """Switch the halo plan ``plan`` of space ``V`` to the direct xGMI transport: create this
+        rank's window, swap IPC handles and ghost offsets over torch.distributed, map the peers'
+        windows, then self-test halo exchange and all-reduce.  Collective; returns the ranks'
+        common verdict (False leaves the plan on its previous transport)."""
+        import os
+
+        import numpy as np
+        import torch.distributed as dist
+
+        lib = _lib.load()
+        h = V.halo
+        ng = V.n_local - V.n_owned
+        win, handle = C.c_void_p(), C.create_string_buffer(64)
+        ok = True
+        try:
+            nbytes = lib.ox_p2p_window_bytes(self.size, ng)
+            _lib.check(lib.ox_p2p_window_create(nbytes, C.byref(win), handle), "ox_p2p_window_create")
+        except _lib.OasisxHipError as e:
+            ok, self.p2p_error = False, str(e)
+        info = {"ok": ok, "handle": handle.raw, "n_ghost": ng,
+                "recv_off": {int(q): int(h["recv_off"][i]) for i, q in enumerate(h["peers"])}}
+        infos = [None] * self.size
+        dist.all_gather_object(infos, info)
+        wins = (C.c_void_p * self.size)()
+        opened = []
+        if all(i["ok"] for i in infos):
+            for r in range(self.size):
+                if r == self.rank:
+                    wins[r] = win.value
+                    continue
+                w = C.c_void_p()
+                try:
+                    _lib.check(lib.ox_p2p_window_open(infos[r]["handle"], C.byref(w)), "ox_p2p_window_open")
+                    wins[r] = w.value
+                    opened.append(w)
+                except _lib.OasisxHipError as e:
+                    ok, self.p2p_error = False, str(e)
+                    break
+        else:
+            ok = False
+        if ok:
+            try:
+                peers = [int(q) for q in h["peers"]]
+                off = np.asarray([infos[q]["recv_off"].get(self.rank, 0) for q in peers] or [0], dtype=np.int64)
+                png = np.asarray([infos[q]["n_ghost"] for q in peers] or [0], dtype=np.int64)
+                _lib.check(lib.ox_dist_enable_p2p(plan, win, wins, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  png.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  float(os.environ.get("OX_P2P_TIMEOUT_S", "120"))),
+                           "ox_dist_enable_p2p")
+            except _lib.OasisxHipError as e:
+                ok, self.p2p_error = False, str(e)
+        if not self._all_ok(ok):
+            if ok:
+                lib.ox_dist_disable_p2p(plan)  # frees the window and the mappings
+            else:
+                for w in opened:
+                    lib.ox_p2p_window_close(w)
+                if win.value:
+                    lib.ox_p2p_window_free(win)
+            return False
+        # self-test (the plan now owns window and mappings)
+        try:
+            V.dist = plan
+            V.check_halo()
+            for k in range(3):  # both parities of the mailboxes
+                buf = torch.ones(9, dtype=torch.float64, device=V.mesh.device)
+                buf[0] = self.rank + 1.0 + k
+                _lib.check(lib.ox_allreduce_sum(plan, _lib.ptr(buf), 9, _lib.current_stream()), "ox_allreduce_sum")
+                torch.cuda.synchronize()
+                _lib.check(lib.ox_dist_status(plan), "ox_dist_status")
+                want = torch.full((9,), float(self.size), dtype=torch.float64)
+                want[0] = self.size * (self.size + 1) / 2.0 + k * self.size
+                if not torch.equal(buf.cpu(), want):
+                    raise RuntimeError(f"p2p all-reduce self-test: got {buf.tolist()}")
+        except (RuntimeError, _lib.OasisxHipError) as e:
+            ok, self.p2p_error = False, str(e)
+        if not self._all_ok(ok):
+            lib.ox_dist_disable_p2p(plan)
+            return False
+        return True
 
     def allreduce(self, v, op=None):
         import torch.distributed as dist
@@ -126,7 +227,9 @@ def init_comm() -> Comm:
         return Comm(0, 1, None)
     rank, size = dist.get_rank(), dist.get_world_size()
     if dist.get_backend() != "nccl":
-        return Comm(rank, size, None)  # CPU rehearsal (gloo): partition logic only
+        # gloo: partition logic on the CPU; on a GPU the plans use the xGMI windows (several ranks
+        # may share one device there) or, with OX_TRANSPORT=host, the host-staged rehearsal transport
+        return Comm(rank, size, None)
     lib = _lib.load()
     buf = C.create_string_buffer(128)
     if rank == 0:

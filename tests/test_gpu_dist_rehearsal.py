@@ -1,8 +1,10 @@
 """GPU, 2 (and 3) processes on ONE device: the whole mesh-partitioned step -- partitioned assembly,
 the C Krylov loops with their halo exchanges and merged all-reduces, ghost-consistency of every
 field -- against the serial run.  RCCL refuses several ranks on one GPU, so the exchange points go
-through the library's callback transport (gloo, host staged) instead of ncclSend/Recv/AllReduce;
-everything else (pack kernel, call sites, kernels, host logic) is the production path."""
+through (a) the direct xGMI transport -- the ranks' uncached windows mapped into each other through
+HIP IPC, exactly as between GPUs, the "remote" stores landing on the same device -- and (b) the
+library's callback transport (gloo, host staged); everything else (call sites, kernels, host
+logic) is the production path."""
 import os
 import socket
 
@@ -56,9 +58,11 @@ def _run(dim, N, deg, comm, steps, low_memory=True):
     return S, diffs
 
 
-def _worker(rank, world, port, dim, N, deg, low_memory, out):
+def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
     import torch.distributed as dist
 
+    os.environ["OX_TRANSPORT"] = transport
+    os.environ["OX_P2P_TIMEOUT_S"] = "30"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -72,6 +76,7 @@ def _worker(rank, world, port, dim, N, deg, low_memory, out):
         G, gdiffs = _run(dim, N, deg, None, steps=2, low_memory=low_memory)
         Vi, Q = S._Vi[0][0], S._Q
         assert Vi.dist is not None and Vi.n_local > Vi.n_owned
+        assert comm.active == {deg: transport, 1: transport}, comm.active
         kg = _key(G._Vi[0][0].x.cpu().numpy())
         og = np.argsort(kg)
         iu = og[np.searchsorted(kg[og], _key(Vi.x.cpu().numpy()))]
@@ -93,12 +98,13 @@ def _worker(rank, world, port, dim, N, deg, low_memory, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["p2p", "host"])
 @pytest.mark.parametrize("dim,N,deg,world,low_memory", [(3, 6, 2, 2, True), (2, 12, 2, 3, True), (3, 6, 1, 2, True),
                                                         (3, 6, 2, 2, False)])
-def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory):
+def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory, transport):
     import torch.multiprocessing as mp
 
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, low_memory, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, low_memory, transport, out), nprocs=world, join=True)
     assert len(out) == world, dict(out)
