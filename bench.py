@@ -296,8 +296,11 @@ def main():
                                    f"low_memory_version={args.matrix_free}",
                        "cells": mesh.num_cells, "n_u_per_component": S._Vi[0][0].num_dofs_global,
                        "n_p": S._Q.num_dofs_global,
-                       "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}" + ("" if args.backend == "nccl" or world == 1
-                                                                       else " (gloo rehearsal transport)")},
+                       "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}",
+                       "transport": (None if world == 1 else
+                                     "/".join(sorted(set(comm.active.values()))) or "none")
+                       + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
+                       if world > 1 else None},
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the metric's second figure
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,

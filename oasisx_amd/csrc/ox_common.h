@@ -40,7 +40,7 @@ struct ox_p2p {
   unsigned long long **r_hflag;  // device [n_peers*2]: this rank's halo flag in the peer's window
   char **r_slot;         // device [nranks*2]: this rank's all-reduce slot in rank r's window
   unsigned *ticket;      // device: last-block detection of the push kernel
-  int *err_host;         // pinned host: sticky time-out flag, written by the kernels
+  int *err_dev;          // device: sticky time-out flag, written by the kernels (ox_dist_status)
   unsigned long long hseq, aseq;  // exchanges enqueued so far
   long long timeout_ticks;        // wall_clock64 ticks a kernel waits for a peer
   void **opened;         // host [n_opened]: IPC mappings to close

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "ox_kernels.h"
+#include "ox_p2p.h"
 
 #define OX_NCCL(call)                                                                       \
   do {                                                                                      \
@@ -104,9 +105,6 @@ extern "C" int ox_memcpy(void *dst, const void *src, size_t bytes, int to_device
 // ---------------------------------------------------------------------------------------------
 // direct xGMI transport
 // ---------------------------------------------------------------------------------------------
-#define OX_P2P_SLOT 128  // bytes of one all-reduce slot: 15 doubles + the sequence flag
-#define OX_P2P_MAXV 15
-
 struct P2pLayout {
   size_t ar, hf, st, st_stride, total;
 };
@@ -181,7 +179,7 @@ extern "C" int ox_dist_disable_p2p(ox_dist *d) {
   (void)hipFree(q->r_hflag);
   (void)hipFree(q->r_slot);
   (void)hipFree(q->ticket);
-  if (q->err_host) (void)hipHostFree(q->err_host);
+  (void)hipFree(q->err_dev);
   if (q->win) (void)hipFree(q->win);
   free(q);
   d->p2p = nullptr;
@@ -231,8 +229,8 @@ extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wi
   if (p2p_upload(&q->r_slot, r_slot, 2 * nr)) return -1;
   OX_HIP(hipMalloc(&q->ticket, sizeof(unsigned)));
   OX_HIP(hipMemset(q->ticket, 0, sizeof(unsigned)));
-  OX_HIP(hipHostMalloc(&q->err_host, sizeof(int), hipHostMallocMapped));
-  *q->err_host = 0;
+  OX_HIP(hipMalloc(&q->err_dev, sizeof(int)));  // device memory: the kernels poll it on every wait
+  OX_HIP(hipMemset(q->err_dev, 0, sizeof(int)));
   q->timeout_ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);  // wall_clock64: 100 MHz
   OX_HIP(hipDeviceSynchronize());
   d->p2p = q;
@@ -240,26 +238,11 @@ extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wi
 }
 
 extern "C" int ox_dist_status(const ox_dist *d) {
-  if (d && d->p2p && *(volatile int *)d->p2p->err_host)
-    OX_FAIL("xGMI transport: a wait for a peer rank timed out (rank %d)", d->rank);
+  if (!d || !d->p2p) return 0;
+  int e = 0;  // callers have drained the stream: a blocking 4-byte copy
+  OX_HIP(hipMemcpy(&e, d->p2p->err_dev, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) OX_FAIL("xGMI transport: a wait for a peer rank timed out (rank %d)", d->rank);
   return 0;
-}
-
-#define OX_SYS __HIP_MEMORY_SCOPE_SYSTEM
-
-// wait until *flag >= seq; false on time-out (and the sticky error is raised)
-__device__ __forceinline__ bool p2p_wait(const unsigned long long *flag, unsigned long long seq,
-                                         long long timeout_ticks, int *err) {
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, OX_SYS)) return false;  // a peer is gone: do not wait again
-  const long long t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, OX_SYS) < seq) {
-    __builtin_amdgcn_s_sleep(2);
-    if (wall_clock64() - t0 > timeout_ticks) {
-      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, OX_SYS);
-      return false;
-    }
-  }
-  return true;
 }
 
 // gather the interface values and store them into the neighbours' windows; the last block to
@@ -298,7 +281,7 @@ __global__ __launch_bounds__(256) void k_halo_pull(double *__restrict__ ghost, i
                                                    const unsigned long long *hflag,
                                                    const int32_t *__restrict__ peers, int n_peers,
                                                    unsigned long long seq, long long timeout_ticks, int *err) {
-  if ((int)threadIdx.x < n_peers) p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err);
+  if ((int)threadIdx.x < n_peers) ox_p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err);
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
@@ -306,26 +289,26 @@ __global__ __launch_bounds__(256) void k_halo_pull(double *__restrict__ ghost, i
 }
 
 // all-reduce (sum) of n <= 15 doubles: thread r talks to rank r
-__global__ __launch_bounds__(64) void k_allreduce_p2p(double *buf, int n, int nranks, char *const *__restrict__ r_slot,
-                                                      const char *my_slots, int parity, unsigned long long seq,
-                                                      long long timeout_ticks, int *err) {
-  __shared__ double sh[64][OX_P2P_MAXV + 1];
-  const int r = threadIdx.x;
-  if (r < nranks) {
-    char *dst = r_slot[r * 2 + parity];
-    for (int i = 0; i < n; ++i) __hip_atomic_store(reinterpret_cast<double *>(dst) + i, buf[i], __ATOMIC_RELAXED, OX_SYS);
-    __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), seq, __ATOMIC_RELEASE, OX_SYS);
-    const char *src = my_slots + ((size_t)parity * nranks + r) * OX_P2P_SLOT;
-    p2p_wait(reinterpret_cast<const unsigned long long *>(src + OX_P2P_SLOT - 8), seq, timeout_ticks, err);
-    for (int i = 0; i < n; ++i) sh[r][i] = __hip_atomic_load(reinterpret_cast<const double *>(src) + i, __ATOMIC_RELAXED, OX_SYS);
-  }
+__global__ __launch_bounds__(64) void k_allreduce_p2p(double *buf, int n, ox_p2p_ar a) {
+  __shared__ double stage[64][OX_P2P_MAXV + 1];
+  __shared__ double vals[OX_P2P_MAXV + 1];
+  if ((int)threadIdx.x < n) vals[threadIdx.x] = buf[threadIdx.x];
   __syncthreads();
-  if ((int)threadIdx.x < n) {
-    double s = 0.0;
-    for (int q = 0; q < nranks; ++q) s += sh[q][threadIdx.x];  // rank order: the same bits on every rank
-    buf[threadIdx.x] = s;
-  }
+  ox_p2p_allreduce_block(vals, n, a, stage);
+  if ((int)threadIdx.x < n) buf[threadIdx.x] = vals[threadIdx.x];
+}
+
+ox_p2p_ar ox_p2p_next_allreduce(const ox_dist *d) {
+  ox_p2p *q = d->p2p;
+  ox_p2p_ar a;
+  a.seq = ++q->aseq;
+  a.parity = (int)(a.seq & 1);
+  a.r_slot = q->r_slot;
+  a.my_slots = q->win;
+  a.nranks = d->nranks;
+  a.timeout_ticks = q->timeout_ticks;
+  a.err = q->err_dev;
+  return a;
 }
 
 static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
@@ -346,17 +329,13 @@ static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t 
   hipLaunchKernelGGL(k_halo_pull, dim3(nb2), dim3(256), 0, st, x + d->n_owned * ncomp, ng,
                      reinterpret_cast<const double *>(q->win + L.st + parity * L.st_stride),
                      reinterpret_cast<const unsigned long long *>(q->win + L.hf) + (size_t)parity * d->nranks,
-                     q->peers_dev, d->n_peers, seq, q->timeout_ticks, q->err_host);
+                     q->peers_dev, d->n_peers, seq, q->timeout_ticks, q->err_dev);
   OX_LAUNCH_CHECK();
   return 0;
 }
 
 static int p2p_allreduce(const ox_dist *d, double *buf, int n, hipStream_t st) {
-  ox_p2p *q = d->p2p;
-  const unsigned long long seq = ++q->aseq;
-  const int parity = (int)(seq & 1);
-  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(64), 0, st, buf, n, d->nranks, q->r_slot, q->win, parity, seq,
-                     q->timeout_ticks, q->err_host);
+  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(64), 0, st, buf, n, ox_p2p_next_allreduce(d));
   OX_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,7 @@
 // every-iteration check would give.  Reductions are two-stage and ordered (no float
 // atomics): results are bit-reproducible run to run.
 #include "ox_kernels.h"
+#include "ox_p2p.h"
 
 struct KspState {
   double rz[OX_MAXC], alpha[OX_MAXC], beta[OX_MAXC], omega[OX_MAXC], rho[OX_MAXC];
@@ -192,6 +193,39 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   ox_gather_partials(partial, nparts, nv, v);
   ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
   if (threadIdx.x == 0) {
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
+    ksp_finish(&sh, P.nc_total);
+  }
+  __syncthreads();
+  ksp_state_store(S, &sh);
+}
+
+// The same on the direct xGMI transport: the block's sums are all-reduced over the ranks' windows
+// inside the kernel (rank order: identical bits, hence identical decisions, on every rank), so a
+// distributed synchronisation point stays ONE kernel.
+template <int PH>
+__global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
+                                                                   const double *__restrict__ partial,
+                                                                   int nparts, int nv, KspParams P, ox_p2p_ar ar) {
+  __shared__ double red[16 * OX_MAX_NV];
+  __shared__ KspState sh;
+  __shared__ double vals[OX_P2P_MAXV + 1];
+  __shared__ double stage[64][OX_P2P_MAXV + 1];
+  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;  // every rank skips this exchange
+  ksp_state_load(&sh, S);
+  double v[OX_MAX_NV];
+  ox_gather_partials(partial, nparts, nv, v);
+  ox_block_sum_wide(v, nv, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < OX_MAX_NV; ++i)
+      if (i < nv) vals[i] = v[i];
+  }
+  __syncthreads();
+  ox_p2p_allreduce_block(vals, nv, ar, stage);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < OX_MAX_NV; ++i) v[i] = i < nv ? vals[i] : 0.0;
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
     ksp_finish(&sh, P.nc_total);
   }
@@ -526,6 +560,14 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
                           const KspParams &P, const ox_dist *dist, hipStream_t st) {
   if (!dist) {
     hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(ox_red_threads(nparts)), 0, st, S, partial, nparts, nv, P);
+    OX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dist->p2p && dist->nranks > 1 && dist->nranks <= 64) {
+    int threads = ox_red_threads(nparts);
+    if (threads < 64) threads = 64;
+    hipLaunchKernelGGL((k_ksp_scalar_p2p<PH>), dim3(1), dim3(threads), 0, st, S, partial, nparts, nv, P,
+                       ox_p2p_next_allreduce(dist));
     OX_LAUNCH_CHECK();
     return 0;
   }
