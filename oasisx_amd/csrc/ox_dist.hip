@@ -181,6 +181,7 @@ extern "C" int ox_dist_disable_p2p(ox_dist *d) {
   (void)hipFree(q->ticket);
   (void)hipFree(q->err_dev);
   if (q->win) (void)hipFree(q->win);
+  (void)hipGetLastError();  // tear-down is best effort: leave no stale error for the caller's next HIP call
   free(q);
   d->p2p = nullptr;
   return 0;

@@ -426,6 +426,8 @@ class FunctionSpace:
         on_gpu = self.mesh.device.type == "cuda"
         if not on_gpu:
             return  # CPU: partition logic only, no device plan
+        if comm.handle is None and getattr(comm, "enable_p2p", None) is None:
+            return  # a bare rank/size object (tests of rank-local data): nothing to exchange with
         lib = _lib.load()
         h = self.halo
 
