@@ -55,7 +55,7 @@ typedef struct {
   int64_t n_rows;            /* rows owned by this rank                                  */
   int64_t n_cols;            /* local columns (owned + ghost)                            */
   int32_t n_slices;          /* ceil(n_rows / 64)                                        */
-  int32_t reserved;
+  int32_t n_dict;            /* entries of vdict (0: no value dictionary)                   */
   const int64_t *slice_ptr;  /* device [n_slices+1], entry offsets, multiples of 64*OX_KV */
   const int32_t *cols;       /* device [slice_ptr[n_slices]] (padding: own row, value 0) */
   double *vals;              /* device [slice_ptr[n_slices]]                             */
@@ -64,6 +64,10 @@ typedef struct {
                                 cbase[e / (64*OX_KV)][code >> 15] + (code & 0x7fff)         */
   const int32_t *cbase;      /* device [slice_ptr[n_slices] / (64*OX_KV)][2]; [0] < 0 at the
                                 first pair of a slice: that slice is read from cols         */
+  /* optional value dictionary for matrices with <= 256 distinct values (mass / stiffness on
+   * meshes of congruent cells): vals[e] == vdict[vcode[e]] bit for bit; used with cols16 */
+  const uint8_t *vcode;      /* device [slice_ptr[n_slices]]                                */
+  const double *vdict;       /* device [n_dict]                                             */
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */

@@ -26,12 +26,14 @@ class ox_sell(C.Structure):
         ("n_rows", C.c_int64),
         ("n_cols", C.c_int64),
         ("n_slices", C.c_int32),
-        ("reserved", C.c_int32),
+        ("n_dict", C.c_int32),
         ("slice_ptr", C.c_void_p),
         ("cols", C.c_void_p),
         ("vals", C.c_void_p),
         ("cols16", C.c_void_p),
         ("cbase", C.c_void_p),
+        ("vcode", C.c_void_p),
+        ("vdict", C.c_void_p),
     ]
 
 

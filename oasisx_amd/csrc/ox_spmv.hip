@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
                                               const int *__restrict__ done_flag) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
   __shared__ double red[4 * NV];
+  __shared__ double dict[(VAR & 4) ? 256 : 1];
   if (done_flag && *done_flag) return;
+  if (VAR & 4) {  // value dictionary (<= 256 distinct values in the whole matrix): 1 B per entry
+    if ((int)threadIdx.x < A.n_dict) dict[threadIdx.x] = A.vdict[threadIdx.x];
+    __syncthreads();
+  }
   // Persistent grid (<= OX_SPMV_MAX_BLOCKS blocks, a multiple of 8): the blocks that share an XCD
   // (equal blockIdx % 8) stride together over ONE contiguous eighth of the slice groups, so
   // at any time an XCD's L2 serves a compact window of rows and of x.
@@ -65,9 +70,15 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
     typedef double v2d __attribute__((ext_vector_type(2)));
     typedef int v2i __attribute__((ext_vector_type(2)));
     typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+    const unsigned short *__restrict__ vcp =
+        (VAR & 4) ? reinterpret_cast<const unsigned short *>(A.vcode + base) + lane : nullptr;
     auto load_vals = [&](int k) {
       double2 v;
-      if (VAR & 1) {
+      if (VAR & 4) {
+        const unsigned cc = __builtin_nontemporal_load(vcp + (size_t)k * 64);  // two 1-byte codes
+        v.x = dict[cc & 0xff];
+        v.y = dict[cc >> 8];
+      } else if (VAR & 1) {
         const v2d vv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(vp + (size_t)k * 64));
         v.x = vv.x;
         v.y = vv.y;
@@ -143,12 +154,12 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   }
 }
 
-// bit 0: nontemporal matrix stream; bit 1: 16-bit column stream where the matrix carries one
-// (measured: tools/spmv_bench.py)
-#define OX_SPMV_DEFAULT_VARIANT 3
+// bit 0: nontemporal matrix stream; bit 1: 16-bit column stream, bit 2: 1-byte value codes, each
+// where the matrix carries them (measured: tools/spmv_bench.py)
+#define OX_SPMV_DEFAULT_VARIANT 7
 static int g_spmv_variant = -1;
 extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 3;
+  g_spmv_variant = v & 7;
   return 0;
 }
 
@@ -159,15 +170,19 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 3 : OX_SPMV_DEFAULT_VARIANT;
+    g_spmv_variant = e ? atoi(e) & 7 : OX_SPMV_DEFAULT_VARIANT;
   }
-  const int var = (A->cols16 && A->cbase) ? g_spmv_variant : (g_spmv_variant & 1);
+  int var = (A->cols16 && A->cbase) ? g_spmv_variant : (g_spmv_variant & 1);
+  // value codes ride on the 16-bit column stream (one kernel family: 7 = all three)
+  if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
+  else var = 7;
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
   hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
-    if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                     \
+    if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                                     \
+    else if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                \
     else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \
     else if (var == 1) OX_SPMV_LAUNCH(NC, E, 1);                                                \
     else OX_SPMV_LAUNCH(NC, E, 0);                                                              \

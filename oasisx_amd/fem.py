@@ -125,7 +125,7 @@ class SellPattern:
                 self.cols16 = torch.empty(self.size, dtype=torch.int16, device=self.device)
                 self.cbase = torch.empty(2 * (self.size // (SLICE * KV)), dtype=torch.int32, device=self.device)
                 plain = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                                     self.cols.data_ptr(), None, None, None)
+                                     self.cols.data_ptr(), None, None, None, None, None)
                 n16 = C.c_int64(0)
                 _lib.check(_lib.load().ox_sell_compress_cols(C.byref(plain), _lib.ptr(self.cols16),
                                                              _lib.ptr(self.cbase), C.byref(n16),
@@ -133,7 +133,7 @@ class SellPattern:
                 self.frac16 = n16.value / self.size  # share of the stored entries read as 16 bit
             c16, cb = self.cols16.data_ptr(), self.cbase.data_ptr()
         return _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                            self.cols.data_ptr(), vals.data_ptr(), c16, cb)
+                            self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
 
     def bins_args(self):
         return (int(self.bin_width.shape[0]), self.bin_ptr.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -171,6 +171,7 @@ class FractionalStep_AB_CN:
         if options is None:
             options = {}
         self._low_memory = options.get("low_memory_version", True)
+        self._options = dict(options)
         if body_force is None:
             body_force = (0.0,) * gdim
         self._body_force = [float(f) for f in body_force]
@@ -236,6 +237,10 @@ class FractionalStep_AB_CN:
                 is_bc[bcp._dofs_dev.to(torch.int64)] = 1
             _lib.check(lib.ox_zero_rows_cols(self._Ap.ref(), _lib.ptr(is_bc), 1.0, st), "ox_zero_rows_cols")
             self._Ap.version += 1
+        if self._options.get("value_dictionary", True):
+            # M and Ap never change again: 1-byte value codes where <= 256 distinct values (la.freeze)
+            self._M.freeze()
+            self._Ap.freeze()
         if not self._low_memory:  # the rectangular operators (:392-404)
             for fam, Mat, R_, C_, adj_, pos_, pw_ in ((0, self._p_vdxi_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
                                                     (1, self._grad_p_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),

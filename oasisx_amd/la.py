@@ -18,6 +18,7 @@ class SellMatrix:
         self.symmetric = symmetric
         self.name = name
         self.version = 0  # bumped whenever the values change (Jacobi setup is cached on it)
+        self.vcode = self.vdict = self._vc_version = None  # value dictionary, see freeze()
         self._struct = pattern.struct(self.vals)
 
     @property
@@ -25,7 +26,40 @@ class SellMatrix:
         return self._struct
 
     def ref(self):
+        if self._vc_version is not None and self._vc_version != self.version:
+            self._drop_codes()  # the values changed after freeze(): the codes no longer describe them
         return C.byref(self._struct)
+
+    def _drop_codes(self):
+        self.vcode = self.vdict = self._vc_version = None
+        self._struct.vcode = self._struct.vdict = None
+        self._struct.n_dict = 0
+
+    def freeze(self, block: int = 1 << 27) -> bool:
+        """Value dictionary for a matrix whose values will not change any more (M, Ap: assembled
+        once, reference fracstep.py:373-380): if the stored values take at most 256 distinct bit
+        patterns -- mass and stiffness matrices on meshes of congruent cells do: 49 / 14 on the box
+        meshes -- the SpMV streams one code byte per entry instead of the 8-byte value and looks the
+        value up in an LDS copy of the dictionary.  Same values, same order of sums: bit-identical
+        results.  Returns whether a dictionary was built (False: nothing changes)."""
+        P = self.pattern
+        if P.device.type != "cuda" or P.cols16 is None or P.size == 0:
+            return False
+        bits = self.vals.view(torch.int64)
+        u = None
+        for a in range(0, P.size, block):
+            ub = torch.unique(bits[a:a + block])
+            u = ub if u is None else torch.unique(torch.cat([u, ub]))
+            if u.numel() > 256:
+                return False
+        code = torch.empty(P.size, dtype=torch.uint8, device=P.device)
+        for a in range(0, P.size, block):
+            code[a:a + block] = torch.searchsorted(u, bits[a:a + block]).to(torch.uint8)
+        self.vcode, self.vdict = code, u.view(torch.float64).contiguous()
+        self._vc_version = self.version
+        self._struct.vcode, self._struct.vdict = self.vcode.data_ptr(), self.vdict.data_ptr()
+        self._struct.n_dict = int(u.numel())
+        return True
 
     def getSize(self):
         return (self.pattern.n_rows, self.pattern.n_cols)

@@ -105,3 +105,44 @@ def test_three_groups_fall_back_and_spmv_is_bit_identical():
         np.testing.assert_array_equal(ys[0], ys[1])
         ref = P.to_csr(A.vals) @ x.cpu().numpy()
         np.testing.assert_allclose(ys[1], ref, rtol=1e-13, atol=1e-13)
+
+
+def test_value_dictionary_is_bit_identical_and_drops_when_values_change():
+    """la.SellMatrix.freeze: <= 256 distinct values -> 1-byte codes; the SpMV and the Krylov solve are
+    bit-identical with and without them; changing the values afterwards drops the codes."""
+    import ctypes as C
+
+    from oasisx_amd import _lib
+    from oasisx_amd.ksp import KSPSolver
+    from tests.helpers import make_hip_problem
+
+    S, clock, mesh = make_hip_problem(3, 8, u_deg=2)
+    lib = _lib.load()
+    for A in (S._M, S._Ap):
+        assert A.vcode is not None and 1 <= A._struct.n_dict <= 256, "box meshes have few distinct values"
+        np.testing.assert_array_equal(A.vdict[A.vcode.long()].cpu().numpy().view(np.int64),
+                                      A.vals.cpu().numpy().view(np.int64))
+        n = A.pattern.n_cols
+        for nc in (1, 3):
+            x = torch.randn(n, nc, dtype=torch.float64, device="cuda").contiguous()
+            ys = []
+            for var in (3, 7):
+                lib.ox_set_spmv_variant(var)
+                y = torch.zeros(A.pattern.n_rows, nc, dtype=torch.float64, device="cuda")
+                A.mult(x, y, nc)
+                ys.append(y.cpu().numpy())
+            lib.ox_set_spmv_variant(7)
+            np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
+    # the assembled convective matrix has no small dictionary
+    S.assemble_first(0.005, 0.01)
+    assert not S._A.freeze()
+    # values change after freeze(): the codes must not be used any more
+    M = S._M
+    rows = torch.tensor([0, 5], dtype=torch.int32, device="cuda")
+    M.zero_rows(rows, 1.0)
+    M.ref()
+    assert M.vcode is None and M._struct.n_dict == 0 and not M._struct.vcode
+    x = torch.randn(M.pattern.n_cols, 1, dtype=torch.float64, device="cuda")
+    y = torch.zeros(M.pattern.n_rows, 1, dtype=torch.float64, device="cuda")
+    M.mult(x, y, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), M.to_scipy() @ x.cpu().numpy(), rtol=1e-13, atol=1e-15)

@@ -1,6 +1,7 @@
 """SpMV micro-benchmark on the bench workload's matrices (x_j = sin(j*1e-3)+1,
 200 repetitions after 20 warm-up), HIP-event timed.  VARIANTS=1,3 lists the kernel variants to compare
-(bit 0 nontemporal matrix stream, bit 1 16-bit column stream)."""
+(bit 0 nontemporal matrix stream, bit 1 16-bit column stream, bit 2 1-byte value codes; PALETTE=49
+draws the values from 49 distinct numbers so that a dictionary exists)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,12 +13,17 @@ mesh = M.create_box(None, [[-1.,-1.,-1.],[1.,1.,1.]], [N,N,N])
 deg, nc = (1, 1) if which == "p" else (2, 3)
 V = fem.FunctionSpace(mesh, deg)
 A = SellMatrix(V.pattern); A.vals.uniform_(0.5, 1.5)
+npal = int(os.environ.get("PALETTE", "0"))  # > 0: values drawn from that many distinct numbers (mass /
+if npal:                                   # stiffness matrices on box meshes have 49 / 14)
+    pal = torch.rand(npal, device="cuda", dtype=torch.float64) + 0.5
+    A.vals.copy_(pal[torch.randint(0, npal, (A.vals.numel(),), device="cuda")])
+    print("value dictionary built:", A.freeze(), "entries", A._struct.n_dict)
 P = V.pattern
 x = (torch.sin(torch.arange(P.n_cols*nc, device="cuda", dtype=torch.float64)*1e-3)+1).reshape(P.n_cols, nc).contiguous()
 y = torch.zeros_like(x)
 lib = _lib.load()
 B = 12*P.nnz + 4*(P.n_rows+1) + nc*8*(P.n_cols+P.n_rows)
-variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "1,3,7" if npal else "1,3").split(",")]
 print(f"16-bit column stream covers {P.frac16:.4f} of the stored entries")
 res = {v: [] for v in variants}
 for rnd in range(7):
