@@ -45,6 +45,8 @@ parser.add_argument("-u", dest="u_deg", type=int, default=2, help="Degree of vel
 parser.add_argument("-p", dest="p_deg", type=int, default=1, help="Degree of pressure space")
 parser.add_argument("-lm", "--low-memory", dest="lm", action="store_true", default=False)
 parser.add_argument("-r", "--rotational", dest="rot", action="store_true", default=False)
+parser.add_argument("-o", "--output-dir", dest="outdir", default=None,
+                    help="write u and p every step (VTK series, the stand-in for the reference's u.bp / p.bp)")
 inputs = parser.parse_args()
 logger = logging.getLogger("Oasisx")
 logger.setLevel(logging.INFO)
@@ -90,6 +92,12 @@ for n, N in enumerate(inputs.Ns):
             -4 * np.pi ** 2 * nu * float(p_time))
 
     solver._p.interpolate(man_p)
+    vtxu = vtxp = None
+    if inputs.outdir:  # reference: VTXWriter(mesh.comm, "u.bp", [solver.u], engine="BP4")
+        from oasisx_amd import io
+
+        vtxu = io.VTXWriter(mesh.comm, os.path.join(inputs.outdir, f"u_{N}.bp"), [solver.u], engine="BP4")
+        vtxp = io.VTXWriter(mesh.comm, os.path.join(inputs.outdir, f"p_{N}.bp"), [solver._p], engine="BP4")
     error_space_time = np.zeros((2, num_steps))
     u_time.value = T_start
     for i in range(num_steps):
@@ -99,7 +107,13 @@ for n, N in enumerate(inputs.Ns):
         error_u = (fem.assemble_l2_error_sq(solver._u[0], u_ex.eval_x)
                    + fem.assemble_l2_error_sq(solver._u[1], u_ex.eval_y))
         error_p = fem.assemble_l2_error_sq(solver._p, man_p)
+        if vtxu is not None:
+            vtxp.write(float(p_time.value))
+            vtxu.write(float(u_time.value))
         error_space_time[:, i] = [error_u, error_p]
+    if vtxu is not None:
+        vtxu.close()
+        vtxp.close()
     hmax = float(np.max(mesh.h(mesh.topology.dim, np.arange(mesh.topology.index_map(mesh.topology.dim).size_local))))
     space_time_u_L2 = np.sqrt(dt * np.sum(error_space_time[0, :]))
     space_time_p_L2 = np.sqrt(dt * np.sum(error_space_time[1, :]))

@@ -5,7 +5,7 @@ Same names as reference src/oasisx/__init__.py:12-18; the compute path is the HI
 """
 import logging
 
-from . import fem, mesh  # noqa: F401
+from . import fem, io, mesh  # noqa: F401
 from .bcs import DirichletBC, LocatorMethod, PressureBC
 from .fracstep import FractionalStep_AB_CN
 from .function import Projector

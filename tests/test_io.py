@@ -1,0 +1,61 @@
+"""Field output (oasisx_amd.io.VTXWriter, the stand-in for dolfinx.io.VTXWriter in the reference
+demo, demo/taylor_green.py:183-184,211-215): files parse, values and times round-trip, and the
+quadratic cells use VTK's node order."""
+import os
+
+import numpy as np
+import pytest
+
+from oasisx_amd import fem, io
+from oasisx_amd import mesh as M
+
+_EDGES = {22: [(0, 1), (1, 2), (2, 0)], 24: [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]}
+
+
+@pytest.mark.parametrize("dim,N,deg", [(2, 4, 2), (3, 2, 2), (3, 3, 1), (2, 5, 1)])
+def test_vtu_series_round_trip(tmp_path, dim, N, deg):
+    mesh = (M.create_rectangle(None, [[-1.0, -1.0], [1.0, 1.0]], [N, N], device="cpu") if dim == 2
+            else M.create_box(None, [[0.0, 0.0, 0.0], [1.0, 2.0, 3.0]], [N, N, N], device="cpu"))
+    V = fem.functionspace(mesh, ("Lagrange", deg))
+    W = fem.VectorFunctionSpace(V, dim)
+    p = fem.Function(V, name="p")
+    u = fem.Function(W, name="u")
+    w = io.VTXWriter(mesh.comm, str(tmp_path / "out" / "fields.bp"), [u, p], engine="BP4")
+    times = [0.5, 0.75, 1.0]
+    for t in times:
+        p.interpolate(lambda x: t * (x[0] + 2 * x[1] - 3 * x[2]))
+        u.interpolate(lambda x: np.stack([t + x[k] for k in range(dim)]))
+        w.write(t)
+    w.close()
+    with pytest.raises(RuntimeError):
+        w.write(2.0)
+    pvd = (tmp_path / "out" / "fields.pvd").read_text()
+    X = V.tabulate_dof_coordinates()
+    for k, t in enumerate(times):
+        name = f"fields_{k:06d}.vtu"
+        assert name in pvd and repr(t) in pvd
+        d = io.read_vtu(str(tmp_path / "out" / name))
+        assert d["time"] == t
+        np.testing.assert_array_equal(d["points"][:, :dim], X[:, :dim])
+        np.testing.assert_allclose(d["point_data"]["p"], t * (X[:, 0] + 2 * X[:, 1] - 3 * X[:, 2]), atol=1e-14)
+        np.testing.assert_allclose(d["point_data"]["u"][:, :dim], t + X[:, :dim], atol=1e-14)
+        assert (d["point_data"]["u"][:, dim:] == 0).all()
+        nper = {(2, 1): 3, (3, 1): 4, (2, 2): 6, (3, 2): 10}[(dim, deg)]
+        conn = d["connectivity"].reshape(-1, nper)
+        assert conn.shape[0] == mesh.num_cells and (d["offsets"] == nper * (1 + np.arange(mesh.num_cells))).all()
+        vt = int(d["types"][0])
+        assert vt == {(2, 1): 5, (3, 1): 10, (2, 2): 22, (3, 2): 24}[(dim, deg)]
+        if deg == 2:  # mid-edge nodes sit between the end points VTK prescribes
+            nv = dim + 1
+            for j, (a, b) in enumerate(_EDGES[vt]):
+                mid = 0.5 * (d["points"][conn[:, a]] + d["points"][conn[:, b]])
+                np.testing.assert_allclose(d["points"][conn[:, nv + j]], mid, atol=1e-14)
+        # every point is used, cells have positive size
+        assert np.unique(conn).shape[0] == V.num_dofs
+
+
+def test_functions_on_different_spaces_are_refused(tmp_path):
+    mesh = M.create_unit_square(None, 3, 3, device="cpu")
+    V1, V2 = fem.functionspace(mesh, ("Lagrange", 1)), fem.functionspace(mesh, ("Lagrange", 2))
+    with pytest.raises(RuntimeError):
+        io.VTXWriter(mesh.comm, str(tmp_path / "x.bp"), [fem.Function(V1), fem.Function(V2)])
