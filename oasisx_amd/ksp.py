@@ -40,7 +40,8 @@ class KSPSolver:
         self._dinv_version = -1
         self._work = None
         self.last_result = None
-        self.check_every = None
+        self.check_every = None  # override of the automatic check interval (see solve_block)
+        self._every = None
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -56,6 +57,7 @@ class KSPSolver:
     def setOperators(self, A: SellMatrix, P: typing.Optional[SellMatrix] = None):
         self._A = A
         self._dinv_version = -1
+        self._every = None
 
     def solve(self, b, x: Function) -> int:
         """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
@@ -113,7 +115,15 @@ class KSPSolver:
         if self._work is None or self._work.shape[0] < need:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
         res = _lib.ox_ksp_result()
-        every = self.check_every or (16 if (meth == _lib.KSP_CG and nc == 1) else 4)
+        # iterations enqueued between two host reads of the device state: a read costs ~30 us, so
+        # short iterations (pressure: ~80 us) are checked every 16, long ones (velocity matrix:
+        # 2-4 ms) every time -- converged columns then leave the lockstep at once (narrowing)
+        if self._every is None:
+            self._every = max(1, min(16, int(5e8 // max(A.pattern.nnz, 1))))
+            if A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
+                # every rank must enqueue the same number of iterations (each carries exchanges)
+                self._every = int(self._comm.allreduce(self._every, op="max"))
+        every = self.check_every or self._every
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
