@@ -223,7 +223,10 @@ def main():
             ("mass_cg_spmv", 10 * gd + 1, ku, b_u), ("mass_cg_spmv_narrowed", 11, ku, b_u1),
             ("mass_spmv", 10 * gd + 0, ku, b_u), ("assemble_first", 100, -1, None),
             ("grad_vector_p", 110, -1, None), ("grad_vector_dp", 111, -1, None), ("div_vector", 120, -1, None),
-            ("rect_spmv_p_and_gradp", 140, -1, None), ("rect_spmv_div", 141, -1, None)):
+            ("rect_spmv_p_and_gradp", 140, -1, None), ("rect_spmv_div", 141, -1, None),
+            # mesh-partitioned runs: exchanges on rank 0 (both include the wait for the peers)
+            ("halo_exchange_1comp", 150, 1, None), ("halo_exchange_3comp", 150, 3, None),
+            ("krylov_sync_point", 151, -1, None)):
         if key == kp and ku == kp and name != "pressure_cg_spmv":
             continue  # P1-P1: both matrices have the same size; keep the pressure entry only
         cnt, ms = prof(tag, key)

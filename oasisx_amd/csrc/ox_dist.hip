@@ -361,9 +361,17 @@ __global__ void k_pack(const double *__restrict__ x, const int32_t *__restrict__
   buf[i] = x[(int64_t)idx[k] * nc + c];
 }
 
+static int halo_forward_rccl_or_cb(const ox_dist *d, double *x, int ncomp, hipStream_t st);
+
 int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
   if (!d || d->n_peers == 0) return 0;
-  if (d->p2p) return p2p_halo_forward(d, x, ncomp, st);
+  if (ox_prof_on) ox_prof_start(OX_TAG_HALO, st, ncomp);
+  const int rc = d->p2p ? p2p_halo_forward(d, x, ncomp, st) : halo_forward_rccl_or_cb(d, x, ncomp, st);
+  if (ox_prof_on) ox_prof_stop(st);
+  return rc;
+}
+
+static int halo_forward_rccl_or_cb(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
   if (!d->comm && !d->halo_cb) OX_FAIL("ox_halo_forward: the plan has no transport (RCCL communicator, xGMI windows or callbacks)");
   ncclComm_t comm = static_cast<ncclComm_t>(d->comm);
   const int64_t ns = d->send_off[d->n_peers];

@@ -100,6 +100,8 @@ int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, 
 #define OX_TAG_ASSEMBLE_MATRIX 130
 #define OX_TAG_RECT_S2V 140
 #define OX_TAG_RECT_V2S 141
+#define OX_TAG_HALO 150       // one halo exchange (key = components); includes waiting for the peers
+#define OX_TAG_SYNC_POINT 151 // one distributed Krylov synchronisation point (reduce + all-reduce + logic)
 extern bool ox_prof_on;
 void ox_prof_start(int tag, hipStream_t st, long long key = 0);
 void ox_prof_stop(hipStream_t st);

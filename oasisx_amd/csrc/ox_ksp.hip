@@ -563,17 +563,20 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
     OX_LAUNCH_CHECK();
     return 0;
   }
+  if (ox_prof_on) ox_prof_start(OX_TAG_SYNC_POINT, st, nv);
   if (dist->p2p && dist->nranks > 1 && dist->nranks <= 64) {
     int threads = ox_red_threads(nparts);
     if (threads < 64) threads = 64;
     hipLaunchKernelGGL((k_ksp_scalar_p2p<PH>), dim3(1), dim3(threads), 0, st, S, partial, nparts, nv, P,
                        ox_p2p_next_allreduce(dist));
+    if (ox_prof_on) ox_prof_stop(st);
     OX_LAUNCH_CHECK();
     return 0;
   }
   if (ox_reduce_partials(partial, nparts, nv, sums, st)) return -1;
   if (ox_allreduce_impl(dist, sums, nv, st)) return -1;
   hipLaunchKernelGGL((k_ksp_logic<PH>), dim3(1), dim3(64), 0, st, S, sums, P);
+  if (ox_prof_on) ox_prof_stop(st);
   OX_LAUNCH_CHECK();
   return 0;
 }
