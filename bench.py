@@ -48,6 +48,8 @@ def parse():
                     help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
                          "terms instead of the pre-assembled rectangular operators (reference "
                          "fracstep.py:392-404; the demo's default is the pre-assembled form)")
+    ap.add_argument("--window", type=int, default=None,
+                    help="rows per length-sorting window of the SELL-64 numbering (tuning; default: the library's)")
     ap.add_argument("--profile-setup", action="store_true",
                     help="cProfile the set-up phase and print rank 0's top entries to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -153,7 +155,8 @@ def main():
                       "scalar": dict(ksp, ksp_type="cg")}
     S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", args.udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                 solver_options=solver_options,
-                                options={"low_memory_version": args.matrix_free})
+                                options=dict({"low_memory_version": args.matrix_free},
+                                             **({"sell_window": args.window} if args.window else {})))
     for i, f in enumerate(fns):
         S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
         S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
