@@ -183,7 +183,7 @@ int ox_assemble_weights(int degree, const ox_cells *cells, const ox_adj *adj, in
  * LDS accumulator for the widest row of the bin. */
 int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dofs,
                       const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
-                      const double *Mvals, const double *Kvals, const double *uab,
+                      const ox_sell *M, const ox_sell *K, const double *uab,
                       const double *u1, const double *b0, double *b_first, double dt, double nu,
                       int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
                       const int32_t *bin_width_host, void *stream);

@@ -90,8 +90,8 @@ SIGNATURES = {
                                 C.POINTER(ox_sell), _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
     "ox_assemble_weights": (_I, [_I, C.POINTER(ox_cells), C.POINTER(ox_adj), _L, _P, _P]),
     "ox_assemble_first": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
-                               C.POINTER(ox_sell), _P, _P, _P, _P, _P, _P, _D, _D, _I,
-                               C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
+                               C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
+                               _D, _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
     "ox_assemble_grad_vector": (_I, [_I, _I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P,
                                      _P, _D, _P, _P]),
     "ox_assemble_div_vector": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P, _D,

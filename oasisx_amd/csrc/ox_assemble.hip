@@ -92,9 +92,13 @@ struct FirstArgs {
   const double *Mv, *Kv, *uab, *u1, *b0;
   double *b_first;
   double idt, nu;
+  // value dictionaries of M and K (la.SellMatrix.freeze): 1-byte codes instead of the f64 values
+  const uint8_t *Mc, *Kc;
+  const double *Md, *Kd;
+  int nMd, nKd;
 };
 
-template <int GDIM, int DEG, int KIND, int PW>
+template <int GDIM, int DEG, int KIND, int PW, bool DICT = false>
 __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
                                                       ox_adj adj, const uint8_t *__restrict__ adj_pos,
                                                       ox_sell A, FirstArgs F,
@@ -102,7 +106,13 @@ __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int3
   using E = Elem<GDIM, DEG>;
   constexpr int ND = E::ND, NQ = E::NQ, GS = E::GS;
   extern __shared__ double acc[];  // [width][64]
+  __shared__ double dM[DICT ? 256 : 1], dK[DICT ? 256 : 1];
   const int lane = threadIdx.x;
+  if constexpr (DICT) {
+    for (int i = lane; i < F.nMd; i += 64) dM[i] = F.Md[i];
+    for (int i = lane; i < F.nKd; i += 64) dK[i] = F.Kd[i];
+    __syncthreads();
+  }
   const int slice = slice_list[blockIdx.x];
   const int64_t base = A.slice_ptr[slice];
   const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
@@ -219,8 +229,19 @@ __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int3
     double bf[GDIM];
 #pragma unroll
     for (int d = 0; d < GDIM; ++d) bf[d] = 0.0;
+    const unsigned short *__restrict__ mc =
+        DICT ? reinterpret_cast<const unsigned short *>(F.Mc + base) + lane : nullptr;
+    const unsigned short *__restrict__ kc =
+        DICT ? reinterpret_cast<const unsigned short *>(F.Kc + base) + lane : nullptr;
     for (int k = 0; k < npair; ++k) {
-      const double2 m = mv[(size_t)k * 64], kk = kv[(size_t)k * 64];
+      double2 m, kk;
+      if constexpr (DICT) {
+        const unsigned cm = mc[(size_t)k * 64], ck = kc[(size_t)k * 64];
+        m.x = dM[cm & 0xff], m.y = dM[cm >> 8];
+        kk.x = dK[ck & 0xff], kk.y = dK[ck >> 8];
+      } else {
+        m = mv[(size_t)k * 64], kk = kv[(size_t)k * 64];
+      }
       const int2 col = cp[(size_t)k * 64];
       const double c0 = acc[(2 * k) * 64 + lane], c1 = acc[(2 * k + 1) * 64 + lane];
       // A = -0.5 C; A += (1/dt) M; A += (-0.5 nu) K        (fracstep.py:438-442)
@@ -243,12 +264,17 @@ __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int3
   }
 }
 
-template <int GDIM, int DEG, int KIND, int PW>
+template <int GDIM, int DEG, int KIND, int PW, bool DICT = false>
 static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj,
                          const uint8_t *adj_pos, const ox_sell *A, const FirstArgs &F, int n_bins,
                          const int64_t *bin_ptr, const int32_t *bin_slices, const int32_t *bin_width,
                          hipStream_t st) {
-  auto kern = k_assemble_rows<GDIM, DEG, KIND, PW>;
+  if constexpr (KIND == OX_KIND_CONV && !DICT) {
+    if (F.Mc && F.Kc && F.Md && F.Kd && F.nMd >= 1 && F.nMd <= 256 && F.nKd >= 1 && F.nKd <= 256)
+      return launch_rows_t<GDIM, DEG, KIND, PW, true>(cells, cell_dofs, adj, adj_pos, A, F, n_bins, bin_ptr,
+                                                      bin_slices, bin_width, st);
+  }
+  auto kern = k_assemble_rows<GDIM, DEG, KIND, PW, DICT>;
   for (int b = 0; b < n_bins; ++b) {
     const int64_t cnt = bin_ptr[b + 1] - bin_ptr[b];
     if (cnt <= 0) continue;
@@ -299,15 +325,19 @@ extern "C" int ox_assemble_matrix(int kind, int degree, const ox_cells *cells, c
 
 extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dofs,
                                  const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
-                                 const double *Mvals, const double *Kvals, const double *uab,
+                                 const ox_sell *M, const ox_sell *K, const double *uab,
                                  const double *u1, const double *b0, double *b_first, double dt,
                                  double nu, int n_bins, const int64_t *bin_ptr_host,
                                  const int32_t *bin_slices, const int32_t *bin_width_host,
                                  void *stream) {
-  if (!cells || !cell_dofs || !adj || !adj_pos || !A || !Mvals || !Kvals || !uab || !u1 || !b0 || !b_first)
+  if (!cells || !cell_dofs || !adj || !adj_pos || !A || !M || !K || !M->vals || !K->vals || !uab || !u1 ||
+      !b0 || !b_first)
     OX_FAIL("ox_assemble_first: null argument");
+  if (M->slice_ptr != A->slice_ptr || K->slice_ptr != A->slice_ptr)
+    OX_FAIL("ox_assemble_first: M, K and A must share one sparsity pattern");
   if (!(dt > 0.0)) OX_FAIL("ox_assemble_first: dt=%g", dt);
-  FirstArgs F{Mvals, Kvals, uab, u1, b0, b_first, 1.0 / dt, nu};
+  FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, 1.0 / dt, nu,
+              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict};
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
   const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
                                            bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));

@@ -240,6 +240,7 @@ class FractionalStep_AB_CN:
         if self._options.get("value_dictionary", True):
             # M and Ap never change again: 1-byte value codes where <= 256 distinct values (la.freeze)
             self._M.freeze()
+            self._K.freeze()  # read by the fused assemble_first only
             self._Ap.freeze()
         if not self._low_memory:  # the rectangular operators (:392-404)
             for fam, Mat, R_, C_, adj_, pos_, pw_ in ((0, self._p_vdxi_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
@@ -271,7 +272,7 @@ class FractionalStep_AB_CN:
         nb, bptr, bsl, bw = Vi.pattern.bins_args()
         _lib.check(lib.ox_assemble_first(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
                                          C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
-                                         self._A.ref(), _lib.ptr(self._M.vals), _lib.ptr(self._K.vals),
+                                         self._A.ref(), self._M.ref(), self._K.ref(),
                                          self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
                                          float(dt), float(nu), nb, bptr, bsl, bw, st), "ox_assemble_first")
         self._A.version += 1
