@@ -296,36 +296,80 @@ extern "C" int ox_sell_compress_cols(const ox_sell *A, uint16_t *cols16, int32_t
 // One pass reads the columns once for all GD components (4 + 8 GD bytes per entry).
 // (Nontemporal 16-B loads + unroll 4, which help k_spmv, measured 30 % SLOWER here.)
 // ---------------------------------------------------------------------------------------
-template <int GD, int V2S>
+template <int GD, int V2S, bool DICT>
 __global__ __launch_bounds__(256) void k_spmv_multi(ox_sell A, const double *__restrict__ x,
                                                     const double *__restrict__ base, double scale,
                                                     double *__restrict__ y) {
+  // DICT: the GD values of an entry as one packed uint32 of 1-byte codes into a dictionary of
+  // <= 256 doubles (la.MultiSellMatrix.freeze) + the 16-bit column stream: 6 B per entry
+  // instead of 4 + 8 GD.
+  __shared__ double dict[DICT ? 256 : 1];
+  if constexpr (DICT) {
+    if ((int)threadIdx.x < A.n_dict) dict[threadIdx.x] = A.vdict[threadIdx.x];
+    __syncthreads();
+  }
   const int ngroups = (A.n_slices + 3) >> 2;
   const int chunk = (ngroups + 7) >> 3;
   const int g = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);  // XCD-chunked, as k_spmv
   if ((int)(blockIdx.x >> 3) >= chunk || g >= ngroups) return;
-  const int slice = g * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane(g * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (slice >= A.n_slices) return;
   const int64_t row = (int64_t)slice * 64 + lane;
   const int64_t sbase = A.slice_ptr[slice];
   const int npair = (int)((A.slice_ptr[slice + 1] - sbase) >> 7);
-  const double *__restrict__ vp = A.vals + (size_t)sbase * GD + (size_t)lane * 2 * GD;
   const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + sbase) + lane;
   double acc[GD];
 #pragma unroll
   for (int d = 0; d < GD; ++d) acc[d] = 0.0;
-#pragma unroll 2
-  for (int k = 0; k < npair; ++k) {
-    const int2 c = cp[(size_t)k * 64];
-    const double *v = vp + (size_t)k * 128 * GD;  // 2 slots x GD values, contiguous per lane
+  auto mac = [&](const double (&v)[2 * GD], int c0, int c1) {
     if (V2S) {
-      const double *x0 = x + (size_t)c.x * GD, *x1 = x + (size_t)c.y * GD;
+      const double *x0 = x + (size_t)c0 * GD, *x1 = x + (size_t)c1 * GD;
 #pragma unroll
       for (int d = 0; d < GD; ++d) acc[0] = fma(v[GD + d], x1[d], fma(v[d], x0[d], acc[0]));
     } else {
-      const double x0 = x[c.x], x1 = x[c.y];
+      const double x0 = x[c0], x1 = x[c1];
 #pragma unroll
       for (int d = 0; d < GD; ++d) acc[d] = fma(v[GD + d], x1, fma(v[d], x0, acc[d]));
+    }
+  };
+  if constexpr (DICT) {
+    typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+    const uint2 *__restrict__ cc = reinterpret_cast<const uint2 *>(A.vcode) + (sbase >> 1) + lane;
+    const int2 *__restrict__ cb = reinterpret_cast<const int2 *>(A.cbase) + (sbase >> 7);
+    const v2h *__restrict__ hp = reinterpret_cast<const v2h *>(A.cols16 + sbase) + lane;
+    const bool c16 = cb[0].x >= 0;  // wave-uniform: this slice has 16-bit column codes
+#pragma unroll 4
+    for (int k = 0; k < npair; ++k) {
+      const uint2 code = cc[(size_t)k * 64];
+      int c0, c1;
+      if (c16) {
+        const v2h d = hp[(size_t)k * 64];
+        const int2 b = cb[k];
+        const int dx = d.x, dy = d.y;
+        c0 = ((dx & 0x8000) ? b.y : b.x) + (dx & 0x7fff);
+        c1 = ((dy & 0x8000) ? b.y : b.x) + (dy & 0x7fff);
+      } else {
+        const int2 c = cp[(size_t)k * 64];
+        c0 = c.x, c1 = c.y;
+      }
+      double v[2 * GD];
+#pragma unroll
+      for (int d = 0; d < GD; ++d) {
+        v[d] = dict[(code.x >> (8 * d)) & 0xff];
+        v[GD + d] = dict[(code.y >> (8 * d)) & 0xff];
+      }
+      mac(v, c0, c1);
+    }
+  } else {
+    const double *__restrict__ vp = A.vals + (size_t)sbase * GD + (size_t)lane * 2 * GD;
+#pragma unroll 2
+    for (int k = 0; k < npair; ++k) {
+      const int2 c = cp[(size_t)k * 64];
+      const double *vv = vp + (size_t)k * 128 * GD;  // 2 slots x GD values, contiguous per lane
+      double v[2 * GD];
+#pragma unroll
+      for (int d = 0; d < 2 * GD; ++d) v[d] = vv[d];
+      mac(v, c.x, c.y);
     }
   }
   if (row < A.n_rows) {
@@ -347,11 +391,23 @@ extern "C" int ox_spmv_multi(int v2s, int gdim, const ox_sell *A, const double *
   const int nblk = ox_spmv_blocks(A);
   if (nblk == 0) return 0;
   const int tag = v2s ? OX_TAG_RECT_V2S : OX_TAG_RECT_S2V;
+  const bool dict = A->vcode && A->vdict && A->cols16 && A->cbase && A->n_dict >= 1 && A->n_dict <= 256 &&
+                    (g_spmv_variant < 0 || (g_spmv_variant & 4));
   if (ox_prof_on) ox_prof_start(tag, st, A->n_rows);
-  if (gdim == 2 && v2s) hipLaunchKernelGGL((k_spmv_multi<2, 1>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
-  if (gdim == 2 && !v2s) hipLaunchKernelGGL((k_spmv_multi<2, 0>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
-  if (gdim == 3 && v2s) hipLaunchKernelGGL((k_spmv_multi<3, 1>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
-  if (gdim == 3 && !v2s) hipLaunchKernelGGL((k_spmv_multi<3, 0>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y);
+#define OX_MULTI(GD, V, D) \
+  hipLaunchKernelGGL((k_spmv_multi<GD, V, D>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y)
+  if (dict) {
+    if (gdim == 2 && v2s) OX_MULTI(2, 1, true);
+    if (gdim == 2 && !v2s) OX_MULTI(2, 0, true);
+    if (gdim == 3 && v2s) OX_MULTI(3, 1, true);
+    if (gdim == 3 && !v2s) OX_MULTI(3, 0, true);
+  } else {
+    if (gdim == 2 && v2s) OX_MULTI(2, 1, false);
+    if (gdim == 2 && !v2s) OX_MULTI(2, 0, false);
+    if (gdim == 3 && v2s) OX_MULTI(3, 1, false);
+    if (gdim == 3 && !v2s) OX_MULTI(3, 0, false);
+  }
+#undef OX_MULTI
   if (ox_prof_on) ox_prof_stop(st);
   OX_LAUNCH_CHECK();
   return 0;

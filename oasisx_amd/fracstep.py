@@ -248,6 +248,8 @@ class FractionalStep_AB_CN:
                                                     (2, self._divu_Mat, Q, Vi, self._adj_q, self._pos_qv, self._pw_qv)):
                 _lib.check(lib.ox_assemble_rect(fam, R_.degree, C_.degree, C.byref(self._cells), C.byref(adj_),
                                                 _lib.ptr(pos_), pw_, Mat.ref(), st), "ox_assemble_rect")
+                if self._options.get("value_dictionary", True):
+                    Mat.freeze()
         # int phi_r dx on both spaces: body force vector (:387-390), mean of phi (:585-590)
         self._wV = torch.zeros(Vi.n_owned, dtype=torch.float64, device=dev)
         self._wQ = torch.zeros(Q.n_owned, dtype=torch.float64, device=dev)

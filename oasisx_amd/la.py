@@ -92,9 +92,41 @@ class MultiSellMatrix:
         self.pattern, self.gdim, self.name = pattern, gdim, name
         self.vals = torch.zeros(pattern.size * gdim, dtype=torch.float64, device=pattern.device)
         self._struct = pattern.struct(self.vals, compress=False)
+        self.vcode = self.vdict = None
 
     def ref(self):
         return C.byref(self._struct)
+
+    def freeze(self, block: int = 1 << 26) -> bool:
+        """Value dictionary for the (constant) operator, as ``SellMatrix.freeze``: if all
+        ``gdim`` value arrays together take at most 256 distinct bit patterns (they do on meshes
+        of congruent cells), every entry keeps one packed uint32 of ``gdim`` code bytes; with the
+        16-bit column stream the mat-vec then reads 6 B per entry instead of 4 + 8*gdim.
+        Bit-identical results.  Returns whether the dictionary was built."""
+        P = self.pattern
+        if P.device.type != "cuda" or P.size == 0:
+            return False
+        full = P.struct(self.vals)  # builds / fetches the pattern's 16-bit column stream
+        if P.cols16 is None:
+            return False
+        bits = self.vals.view(torch.int64)
+        u = None
+        for a in range(0, bits.numel(), block):
+            ub = torch.unique(bits[a:a + block])
+            u = ub if u is None else torch.unique(torch.cat([u, ub]))
+            if u.numel() > 256:
+                return False
+        code = torch.zeros(P.size, dtype=torch.int32, device=P.device)
+        bv = bits.reshape(P.size, self.gdim)
+        rows = max(1, block // self.gdim)
+        for a in range(0, P.size, rows):
+            c = torch.searchsorted(u, bv[a:a + rows].contiguous()).to(torch.int32)
+            for d in range(self.gdim):
+                code[a:a + rows] |= c[:, d] << (8 * d)
+        self.vcode, self.vdict = code, u.view(torch.float64).contiguous()
+        full.vcode, full.vdict, full.n_dict = self.vcode.data_ptr(), self.vdict.data_ptr(), int(u.numel())
+        self._struct = full
+        return True
 
     def mult(self, v2s: bool, x, base, scale: float, y):
         """y = base + scale * (A applied to x); x, base, y are device pointers (c_void_p)."""

@@ -146,3 +146,38 @@ def test_value_dictionary_is_bit_identical_and_drops_when_values_change():
     y = torch.zeros(M.pattern.n_rows, 1, dtype=torch.float64, device="cuda")
     M.mult(x, y, 1)
     np.testing.assert_allclose(y.cpu().numpy(), M.to_scipy() @ x.cpu().numpy(), rtol=1e-13, atol=1e-15)
+
+
+def test_rectangular_operators_with_value_codes_are_bit_identical():
+    """la.MultiSellMatrix.freeze: the pre-assembled P / G / D operators (reference
+    fracstep.py:392-404) through packed 1-byte codes + 16-bit columns == through f64 + int32."""
+    import ctypes as C
+
+    from oasisx_amd import _lib
+    from tests.helpers import make_hip_problem
+
+    # N = 8: h = 1/4 is exact in binary, so all cells have bit-identical geometry and the operators
+    # few distinct values (with h = 1/3 the rounding noise of the vertex coordinates alone makes
+    # thousands of distinct bit patterns and freeze() declines -- checked below)
+    S, clock, mesh = make_hip_problem(3, 8, u_deg=2, low_memory=False)
+    lib = _lib.load()
+    nu_, nq = S._n_u, S._n_q
+    for Mat, v2s, nx, ny in ((S._p_vdxi_Mat, False, nq, nu_ * 3), (S._grad_p_Mat, False, nq, nu_ * 3),
+                             (S._divu_Mat, True, nu_ * 3, nq)):
+        assert Mat.vcode is not None and 1 <= Mat._struct.n_dict <= 256
+        # the codes reproduce the values bit for bit
+        code = Mat.vcode.cpu().numpy().astype(np.int64)
+        dec = np.stack([Mat.vdict.cpu().numpy()[(code >> (8 * d)) & 255] for d in range(3)], axis=1)
+        np.testing.assert_array_equal(dec.view(np.int64), Mat.vals.cpu().numpy().reshape(-1, 3).view(np.int64))
+        x = torch.randn(nx, dtype=torch.float64, device="cuda")
+        ys = []
+        for var in (3, 7):  # bit 2 off: f64 values + int32 columns; on: codes
+            lib.ox_set_spmv_variant(var)
+            y = torch.zeros(ny, dtype=torch.float64, device="cuda")
+            Mat.mult(v2s, C.c_void_p(x.data_ptr()), None, 0.5, C.c_void_p(y.data_ptr()))
+            ys.append(y.cpu().numpy())
+        lib.ox_set_spmv_variant(7)
+        np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
+        assert np.abs(ys[0]).max() > 0
+    S6, _, _ = make_hip_problem(3, 6, u_deg=2, low_memory=False)
+    assert S6._p_vdxi_Mat.vcode is None and S6._divu_Mat.vcode is None  # no dictionary: f64 path, same results
