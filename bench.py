@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL and the xGMI windows share device
+# memory between the ranks); exported by the launcher normally -- make sure before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
