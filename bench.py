@@ -285,7 +285,10 @@ def main():
                     "stored_bytes_per_launch": sb, "stored_gbs": sb / (1e3 * cg["avg_us"]),
                     "stored_frac": sb / (1e3 * cg["avg_us"]) / HBM_PEAK_GBS,
                     "cols16_fraction": Pp.frac16,
-                    "value_dictionary_entries": int(S._Ap._struct.n_dict)}
+                    "value_dictionary_entries": int(S._Ap._struct.n_dict),
+                    "note": ("achieved/frac use the metric's CSR byte count (BASELINE.md); frac > 1 means the "
+                             "kernel moves fewer bytes than CSR (lossless column/value codes) -- see stored_* "
+                             "and traffic for the bytes actually moved") if sb < b_p else None}
 
     if roofline and N == 128 and args.udeg == 2:
         tr = pmc_traffic()
