@@ -326,6 +326,7 @@ def main():
             "kernels": kernels,
             "setup_s": t_setup,
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "cpu_baseline": None,  # timed on rank 0 at N = 1 only (below)
         }
         if not args.no_cpu and world == 1:
             try:

@@ -47,3 +47,31 @@ def test_bench_runs_and_prints_one_json_line():
     d = json.loads(lines[0])
     _check(d)
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_under_the_driver_launch_line_with_two_ranks():
+    """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), rehearsed with 2 ranks on the
+    one GPU of the box: torch.distributed over gloo (RCCL refuses two ranks on one device), the
+    data path over the xGMI windows.  One JSON line from rank 0, whole-job figures."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OX_P2P_TIMEOUT_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "-N", "16", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    _check(d, live_cpu=False)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == "mesh-partition x2" and d["config"]["transport"].startswith("p2p")
+    assert d["cpu_baseline"] is None or "value" in d["cpu_baseline"]
+    assert d["config"]["n_u_per_component"] == 33 ** 3 and d["config"]["n_p"] == 17 ** 3  # global sizes
