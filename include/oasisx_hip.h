@@ -260,6 +260,7 @@ int ox_p2p_window_close(void *win_dev);
 int ox_p2p_window_free(void *win_dev);
 int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wins, const int64_t *peer_recv_off,
                        const int64_t *peer_n_ghost, double timeout_s);
+int ox_dist_p2p_timeout(ox_dist *d, double timeout_s); /* change the bound of the peer waits */
 int ox_dist_disable_p2p(ox_dist *d);
 int ox_dist_status(const ox_dist *d);
 /* Same plan on a caller-supplied transport instead of RCCL (rehearsals on one GPU, other

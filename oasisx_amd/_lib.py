@@ -116,6 +116,7 @@ SIGNATURES = {
     "ox_p2p_window_close": (_I, [_P]),
     "ox_p2p_window_free": (_I, [_P]),
     "ox_dist_enable_p2p": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_L), C.POINTER(_L), _D]),
+    "ox_dist_p2p_timeout": (_I, [_P, _D]),
     "ox_dist_disable_p2p": (_I, [_P]),
     "ox_dist_status": (_I, [_P]),
     "ox_dist_create_custom": (_I, [_I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P, C.POINTER(_L), _L, _L,

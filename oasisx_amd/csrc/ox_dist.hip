@@ -238,6 +238,12 @@ extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wi
   return 0;
 }
 
+extern "C" int ox_dist_p2p_timeout(ox_dist *d, double timeout_s) {
+  if (!d || !d->p2p) OX_FAIL("ox_dist_p2p_timeout: the plan has no xGMI transport");
+  d->p2p->timeout_ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);
+  return 0;
+}
+
 extern "C" int ox_dist_status(const ox_dist *d) {
   if (!d || !d->p2p) return 0;
   int e = 0;  // callers have drained the stream: a blocking 4-byte copy

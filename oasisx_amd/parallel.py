@@ -100,8 +100,8 @@ class Comm:
                 png = np.asarray([infos[q]["n_ghost"] for q in peers] or [0], dtype=np.int64)
                 _lib.check(lib.ox_dist_enable_p2p(plan, win, wins, off.ctypes.data_as(C.POINTER(C.c_int64)),
                                                   png.ctypes.data_as(C.POINTER(C.c_int64)),
-                                                  float(os.environ.get("OX_P2P_TIMEOUT_S", "120"))),
-                           "ox_dist_enable_p2p")
+                                                  float(os.environ.get("OX_P2P_SELFTEST_TIMEOUT_S", "15"))),
+                           "ox_dist_enable_p2p")  # the ranks are aligned here: a short bound suffices
             except _lib.OasisxHipError as e:
                 ok, self.p2p_error = False, str(e)
         if not self._all_ok(ok):
@@ -132,6 +132,9 @@ class Comm:
         if not self._all_ok(ok):
             lib.ox_dist_disable_p2p(plan)
             return False
+        # production bound: ranks may reach an exchange far apart (set-up work, host-side I/O)
+        _lib.check(lib.ox_dist_p2p_timeout(plan, float(os.environ.get("OX_P2P_TIMEOUT_S", "120"))),
+                   "ox_dist_p2p_timeout")
         return True
 
     def allreduce(self, v, op=None):
