@@ -123,3 +123,44 @@ def test_rccl_single_rank_communicator(hip):
     assert out[0] == 285.0
     _lib.check(hip.ox_dist_destroy(d), "ox_dist_destroy")
     _lib.check(hip.ox_comm_destroy(comm), "ox_comm_destroy")
+
+
+def test_rccl_calls_of_the_halo_plan_run_on_a_self_loop(hip):
+    """The RCCL branch of ox_halo_forward / ox_allreduce_sum -- pack kernel, grouped
+    ncclSend/ncclRecv into the ghost block, ncclAllReduce on the caller's stream -- executed for
+    real on ONE GPU: a one-rank communicator whose halo plan lists rank 0 itself as the neighbour
+    (RCCL matches a send to self with the receive of the same group).  The plan claims two ranks so
+    that no single-rank shortcut is taken."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from oasisx_amd import _lib
+
+    buf = C.create_string_buffer(128)
+    _lib.check(hip.ox_comm_unique_id(buf), "ox_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(hip.ox_comm_create(buf.raw, 0, 1, C.byref(comm)), "ox_comm_create")
+    n_owned, send = 12, [3, 0, 7, 11, 5]
+    ng = len(send)
+    peers = np.asarray([0], dtype=np.int32)
+    off = np.asarray([0, ng], dtype=np.int64)
+    send_idx = torch.tensor(send, dtype=torch.int32, device="cuda")
+    d = C.c_void_p()
+    _lib.check(hip.ox_dist_create(comm, 0, 2, 1, peers.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  off.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(send_idx),
+                                  off.ctypes.data_as(C.POINTER(C.c_int64)), n_owned, ng, C.byref(d)), "ox_dist_create")
+    for nc in (1, 3):
+        x = torch.zeros(n_owned + ng, nc, dtype=torch.float64, device="cuda")
+        x[:n_owned] = torch.arange(n_owned * nc, dtype=torch.float64, device="cuda").reshape(n_owned, nc) + 1.0
+        x[n_owned:] = float("nan")
+        _lib.check(hip.ox_halo_forward(d, _lib.ptr(x), nc, _lib.current_stream()), "ox_halo_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(x[n_owned:], x[torch.tensor(send, device="cuda")])
+    s = torch.tensor([1.5, -2.0, 3.25], dtype=torch.float64, device="cuda")
+    _lib.check(hip.ox_allreduce_sum(d, _lib.ptr(s), 3, _lib.current_stream()), "ox_allreduce_sum")
+    torch.cuda.synchronize()
+    assert s.tolist() == [1.5, -2.0, 3.25]  # sum over the communicator's one rank
+    _lib.check(hip.ox_dist_destroy(d), "ox_dist_destroy")
+    _lib.check(hip.ox_comm_destroy(comm), "ox_comm_destroy")
