@@ -41,7 +41,7 @@ class KSPSolver:
         self._work = None
         self.last_result = None
         self.check_every = None  # override of the automatic check interval (see solve_block)
-        self._every = None
+        self._every = {}
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -57,7 +57,7 @@ class KSPSolver:
     def setOperators(self, A: SellMatrix, P: typing.Optional[SellMatrix] = None):
         self._A = A
         self._dinv_version = -1
-        self._every = None
+        self._every = {}
 
     def solve(self, b, x: Function) -> int:
         """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
@@ -115,15 +115,23 @@ class KSPSolver:
         if self._work is None or self._work.shape[0] < need:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
         res = _lib.ox_ksp_result()
-        # iterations enqueued between two host reads of the device state: a read costs ~30 us, so
-        # short iterations (pressure: ~80 us) are checked every 16, long ones (velocity matrix:
-        # 2-4 ms) every time -- converged columns then leave the lockstep at once (narrowing)
-        if self._every is None:
-            self._every = max(1, min(16, int(5e8 // max(A.pattern.nnz, 1))))
+        # Iterations enqueued between two host reads of the device state (a read costs ~30 us of
+        # idle GPU).  One right-hand side: amortise the read over ~1.5 ms of iterations, at most 16
+        # (pressure CG: 14-16).  Several in lockstep: a column that has converged should leave the
+        # lockstep at once (narrowing) -- being k iterations late costs k half-price iterations --
+        # so check every iteration unless iterations are shorter than two reads.
+        key = (nc, meth)
+        if key not in self._every:
+            t_iter = (2 if meth == _lib.KSP_BCGS else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6  # seconds
+            if nc > 1:
+                ev = 1 if t_iter > 60e-6 else 4
+            else:
+                ev = max(1, min(16, int(1.5e-3 / t_iter)))
             if A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
                 # every rank must enqueue the same number of iterations (each carries exchanges)
-                self._every = int(self._comm.allreduce(self._every, op="max"))
-        every = self.check_every or self._every
+                ev = int(self._comm.allreduce(ev, op="max"))
+            self._every[key] = ev
+        every = self.check_every or self._every[key]
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
