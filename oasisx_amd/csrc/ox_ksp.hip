@@ -187,11 +187,13 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
                                                                int nparts, int nv, KspParams P) {
   __shared__ double red[16 * OX_MAX_NV];
   __shared__ KspState sh;
-  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  // state and partials are loaded in ONE memory round trip; the done flag is looked at afterwards
+  // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
   ksp_state_load(&sh, S);
   double v[OX_MAX_NV];
   ox_gather_partials(partial, nparts, nv, v);
   ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
+  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done) return;  // uniform: nothing is stored
   if (threadIdx.x == 0) {
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
     ksp_finish(&sh, P.nc_total);
@@ -211,11 +213,11 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
   __shared__ KspState sh;
   __shared__ double vals[OX_P2P_MAXV + 1];
   __shared__ double stage[64][OX_P2P_MAXV + 1];
-  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;  // every rank skips this exchange
   ksp_state_load(&sh, S);
   double v[OX_MAX_NV];
   ox_gather_partials(partial, nparts, nv, v);
-  ox_block_sum_wide(v, nv, red);
+  ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
+  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done) return;  // every rank skips this exchange
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i)
