@@ -260,7 +260,10 @@ def test_c_port_matches_numpy_oracle():
             bc = S.bcs_u[0][0].dofs
             cpu.step(dt, nu, np.stack([S.bcs_u[i][0].g[bc] for i in range(dim)]))
         assert np.abs(cpu.u1.T - S.u1).max() < 1e-9 and np.abs(cpu.p - S.p).max() < 1e-8
-        assert cpu.its["tentative"] == S.its["tentative"] and cpu.its["update"] == S.its["update"]
+        # OpenMP reductions sum in a run-dependent order: a residual that lands within round-off of
+        # the threshold can cost one iteration more or less
+        for k in ("tentative", "update"):
+            assert all(abs(int(a) - int(b)) <= 1 for a, b in zip(cpu.its[k], S.its[k])), (k, cpu.its[k], S.its[k])
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
