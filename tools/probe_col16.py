@@ -1,3 +1,6 @@
+"""Probe (CPU): how many pairs of SELL-64 storage columns fit a single 16-bit column base --
+the measurement behind the dual-base column codes.
+Usage: PYTHONPATH=. python tools/probe_col16.py N degree"""
 import torch, numpy as np, time, sys
 from oasisx_amd import mesh as M, fem
 N=int(sys.argv[1]); deg=int(sys.argv[2])

@@ -1,5 +1,7 @@
+"""Probe (GPU): distinct bit patterns among the stored values of M, K and Ap on the box meshes --
+the measurement behind the 1-byte value codes: 49 / 89 / 14, independent of N."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from tests.helpers import make_hip_problem
 for N in (16, 32, 64):
