@@ -127,6 +127,28 @@ class Comm:
                 want[0] = self.size * (self.size + 1) / 2.0 + k * self.size
                 if not torch.equal(buf.cpu(), want):
                     raise RuntimeError(f"p2p all-reduce self-test: got {buf.tolist()}")
+            # stress: back-to-back exchanges with a payload that changes every round, checked on the
+            # device -- a flag that overtakes its data, or a buffer reused too early, shows up here
+            # and not as wrong physics later
+            rounds = int(os.environ.get("OX_P2P_STRESS_ROUNDS", "200"))
+            d = V.mesh.gdim
+            bad = torch.zeros((), dtype=torch.int64, device=V.mesh.device)
+            X = V.x.clone().contiguous()
+            red = torch.empty(3, dtype=torch.float64, device=V.mesh.device)
+            for k in range(rounds):
+                f = 1.0 + 0.5 * k
+                X[: V.n_owned] = V.x[: V.n_owned] * f
+                X[V.n_owned:] = float("nan")
+                _lib.check(lib.ox_halo_forward(plan, _lib.ptr(X), d, _lib.current_stream()), "ox_halo_forward")
+                bad += (X[V.n_owned:] != V.x[V.n_owned:] * f).sum()
+                red[0], red[1], red[2] = self.rank + f, 1.0, -f
+                _lib.check(lib.ox_allreduce_sum(plan, _lib.ptr(red), 3, _lib.current_stream()), "ox_allreduce_sum")
+                bad += (red[0] != self.size * (self.size - 1) / 2.0 + self.size * f).to(torch.int64)
+                bad += (red[1] != float(self.size)).to(torch.int64) + (red[2] != -f * self.size).to(torch.int64)
+            torch.cuda.synchronize()
+            _lib.check(lib.ox_dist_status(plan), "ox_dist_status")
+            if int(bad.item()) != 0:
+                raise RuntimeError(f"p2p stress self-test: {int(bad.item())} wrong values in {rounds} rounds")
         except (RuntimeError, _lib.OasisxHipError) as e:
             ok, self.p2p_error = False, str(e)
         if not self._all_ok(ok):
