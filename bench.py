@@ -294,6 +294,11 @@ def main():
         tr = pmc_traffic()
         if tr:
             roofline["traffic"], roofline["traffic_source"] = tr[0], "profiles/" + tr[1]
+    transport_check = None
+    if world > 1:  # the transports once more after the timed steps: every ghost dof must still get its owner's value
+        S._Vi[0][0].check_halo()
+        S._Q.check_halo()
+        transport_check = "halo self-test passed after the timed steps"
     nnz_glob = [Pu.nnz, Pp.nnz]
     if world > 1:
         import torch.distributed as dist
@@ -319,7 +324,8 @@ def main():
                        "transport": (None if world == 1 else
                                      "/".join(sorted(set(comm.active.values()))) or "none")
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
-                       if world > 1 else None},
+                       if world > 1 else None,
+                       "transport_check": transport_check},
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the metric's second figure
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
