@@ -175,6 +175,29 @@ def main():
     log(f"setup {t_setup:.1f} s; n_u={S._n_u} n_p={S._n_q} nnz_u={S._M.pattern.nnz} nnz_p={S._Ap.pattern.nnz}; "
         f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
+    # per-phase device time of the timed steps: the phase methods of THIS instance are wrapped with a
+    # pair of events on the launching stream (bench-only instrumentation; 12 events per step)
+    phase_events = {}
+
+    def timed_phase(name):
+        fn = getattr(S, name)
+
+        def wrapped(*a, **k):
+            if not phase_events.get("_on"):
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            phase_events.setdefault(name, []).append((e0, e1))
+            return r
+
+        setattr(S, name, wrapped)
+
+    for name in ("assemble_first", "velocity_tentative_assemble", "velocity_tentative_solve", "pressure_assemble",
+                 "pressure_solve", "velocity_update"):
+        timed_phase(name)
+
     def step():
         clock["t"] += dt
         return S.solve(dt, nu, max_iter=1)
@@ -194,6 +217,7 @@ def main():
     # HIP events on the launching stream around every 8th launch of each kernel tag (an event pair costs
     # ~12 us of stream bubbles; every launch would slow the 150 us pressure iteration by 8 %)
     _lib.check(lib.ox_profile_begin(200000, 8), "ox_profile_begin")
+    phase_events["_on"] = True
     t0 = time.perf_counter()
     its = []
     for _ in range(args.steps):
@@ -201,7 +225,13 @@ def main():
         its.append(S.iteration_counts())
     barrier()
     elapsed = time.perf_counter() - t0
+    phase_events["_on"] = False
     _lib.check(lib.ox_profile_end(), "ox_profile_end")
+    phase_ms = {k: sum(a.elapsed_time(b) for a, b in v) / args.steps for k, v in phase_events.items() if k != "_on"}
+    # accuracy at the end of the timed steps: nodal error against the analytic field (rank-local dofs)
+    Xd = S._Vi[0][0].x[: S._n_u].T
+    Ud = S._U.dev()[: S._n_u]
+    err_u = max(float((Ud[:, i] - f(Xd, clock["t"])).abs().max()) for i, f in enumerate(fns))
     if world > 1:
         import torch.distributed as dist
 
@@ -329,6 +359,14 @@ def main():
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the metric's second figure
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
+            "phase_ms_per_step": phase_ms,  # device time between events around each phase method (rank 0)
+            # whole Jacobi-CG iteration of the pressure solve in the metric's bytes (SURVEY.md 8d:
+            # SpMV + 16 vector passes), over the measured time per iteration
+            "pressure_cg_iteration": ({"us": 1e3 * phase_ms["pressure_solve"] / max(mean_its["pressure"], 1.0),
+                                       "algorithmic_gbs": (b_p + 128 * Pp.n_rows) * max(mean_its["pressure"], 1.0)
+                                       / (1e6 * phase_ms["pressure_solve"])}
+                                      if phase_ms.get("pressure_solve") else None),
+            "accuracy": {"max_nodal_error_u_vs_analytic": err_u, "t_end": clock["t"]},
             "kernels": kernels,
             "setup_s": t_setup,
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
