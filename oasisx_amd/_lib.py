@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboasisx_hip.so")
+LIB_PATH = os.environ.get("OX_LIB_PATH") or os.path.join(_HERE, "liboasisx_hip.so")  # override: tuning builds
 
 KSP_CG, KSP_BCGS = 1, 2
 CONVERGED_RTOL, CONVERGED_ATOL, CONVERGED_ITS = 2, 3, 4

@@ -10,7 +10,7 @@ from oasisx_amd.la import SellMatrix
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 which = sys.argv[2] if len(sys.argv) > 2 else "p"
 mesh = M.create_box(None, [[-1.,-1.,-1.],[1.,1.,1.]], [N,N,N])
-deg, nc = (1, 1) if which == "p" else (2, 3)
+deg, nc = {"p": (1, 1), "u": (2, 3), "u1": (2, 1)}[which]  # u1: one column on the velocity matrix (narrowed solves)
 V = fem.FunctionSpace(mesh, deg, window=int(os.environ.get("WINDOW", "4096")))
 A = SellMatrix(V.pattern); A.vals.uniform_(0.5, 1.5)
 npal = int(os.environ.get("PALETTE", "0"))  # > 0: values drawn from that many distinct numbers (mass /
