@@ -68,18 +68,6 @@ typedef struct {
    * meshes of congruent cells): vals[e] == vdict[vcode[e]] bit for bit; used with cols16 */
   const uint8_t *vcode;      /* device [slice_ptr[n_slices]]                                */
   const double *vdict;       /* device [n_dict]                                             */
-  /* optional packed stream (ox_sell_pack): the same 16-bit column codes and 1-byte value codes
-   * regrouped so that ONE lane reads 8 consecutive entries of its row with one 16-byte (columns)
-   * and one 8-byte (values) load -- 2 instead of 8 vector-memory instructions per 8 entries.
-   * Group g of slice s (pk_ptr[s] <= g < pk_ptr[s+1]) holds entries 8(g-pk_ptr[s]) .. +7 of the
-   * slice's 64 rows; rows shorter than the group are padded with (own row, value 0). */
-  const int64_t *pk_ptr;     /* device [n_slices+1], in groups                              */
-  const uint16_t *pk_cols;   /* device [groups][64][8] column codes (as cols16)             */
-  const int32_t *pk_base;    /* device [groups][16] group headers: [0..7] the two bases of each
-                                entry pair, [8] 1 = the slice is read from cols / vals,
-                                [9] groups of the slice, [10] index of the group in it,
-                                [11] entry pairs of the slice, [12..13] slice_ptr[slice]    */
-  const uint8_t *pk_vals;    /* device [groups][64][8] value codes into vdict, or NULL      */
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */
@@ -129,16 +117,6 @@ int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp, const ox_di
  * sets in ox_sell.  n_compressed (host, may be NULL): stored entries now read as 16 bit. */
 int ox_sell_compress_cols(const ox_sell *A, uint16_t *cols16, int32_t *cbase, int64_t *n_compressed,
                           void *stream);
-
-/* Set-up: packed stream of a pattern (and optionally of one matrix's value codes).
- * 1. ox_sell_pack_plan fills pk_ptr (device, [n_slices+1]) and returns the number of groups;
- * 2. the caller allocates pk_cols [groups*512] uint16, pk_base [groups*16] int32 and, for a matrix
- *    with a value dictionary, pk_vals [groups*512] uint8, sets pk_ptr in A and calls ox_sell_pack
- *    (vcode/zero_code: the matrix's 1-byte codes in slot order and the code of 0.0, or NULL/0).
- * n_fallback (host, may be NULL): slices that keep their int32 columns. */
-int ox_sell_pack_plan(const ox_sell *A, int64_t *pk_ptr, int64_t *n_groups, void *stream);
-int ox_sell_pack(const ox_sell *A, uint16_t *pk_cols, int32_t *pk_base, uint8_t *pk_vals,
-                 const uint8_t *vcode, int zero_code, int64_t *n_fallback, void *stream);
 
 /* ---- S2: Mat.mult of the pre-assembled rectangular operators (low_memory_version = False,
  *      reference fracstep.py:499-502, 540-542, 642).  One SELL pattern, gdim values per entry
@@ -250,12 +228,6 @@ int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, doubl
 /* ---- measurement: per-kernel HIP-event timing on the launching stream (bench.py) ------- */
 /* tags: 10*ncomp+epi for SpMV (epi 0 plain, 1 CG p.q, 2/3 BiCGStab), 100 assemble_first,
  * 110/111 grad vectors, 120 div vector. */
-/* packed-stream SpMV tuning (tools/spmv_bench.py): mode 0 off, 1 packed stream, 2 packed + LDS x window
- * (default), 9 diagnostic (no gathers; wrong results); waves per block (1..16), slices per wave, LDS window
- * capacity in doubles; <= 0 keeps the current value.  Drops the cached launch plans. */
-int ox_set_pk_mode(int mode, int waves, int spw, int wmax);
-/* launch plan of a matrix with a packed stream: blocks, blocks whose x window fits, window capacity (0: off) */
-int ox_pk_plan_info(const ox_sell *A, int *nblk, int *n_fit, int *wmax);
 int ox_set_spmv_variant(int v); /* A/B switch of the SpMV micro-benchmark (tools/spmv_bench.py):
                                    1 = nontemporal matrix loads (default), 0 = plain loads */
 int ox_profile_begin(int max_records, int sample_every); /* time every sample_every-th launch per tag */

@@ -34,10 +34,6 @@ class ox_sell(C.Structure):
         ("cbase", C.c_void_p),
         ("vcode", C.c_void_p),
         ("vdict", C.c_void_p),
-        ("pk_ptr", C.c_void_p),
-        ("pk_cols", C.c_void_p),
-        ("pk_base", C.c_void_p),
-        ("pk_vals", C.c_void_p),
     ]
 
 
@@ -82,8 +78,6 @@ SIGNATURES = {
     "ox_device_info": (_I, [C.POINTER(_I), C.c_char_p, _I]),
     "ox_spmv": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_sell_compress_cols": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _P]),
-    "ox_sell_pack_plan": (_I, [C.POINTER(ox_sell), _P, C.POINTER(_L), _P]),
-    "ox_sell_pack": (_I, [C.POINTER(ox_sell), _P, _P, _P, _P, _I, C.POINTER(_L), _P]),
     "ox_spmv_multi": (_I, [_I, _I, C.POINTER(ox_sell), _P, _P, _D, _P, _P, _P]),
     "ox_assemble_rect": (_I, [_I, _I, _I, C.POINTER(ox_cells), C.POINTER(ox_adj), _P, _I, C.POINTER(ox_sell), _P]),
     "ox_axpby": (_I, [_L, _D, _P, _D, _P, _P, _P]),
@@ -108,8 +102,6 @@ SIGNATURES = {
                           C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
-    "ox_set_pk_mode": (_I, [_I, _I, _I, _I]),
-    "ox_pk_plan_info": (_I, [C.POINTER(ox_sell), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),

@@ -86,15 +86,6 @@ __device__ __forceinline__ void ox_block_sum_wide(double (&v)[OX_MAX_NV], int nv
   }
 }
 
-// packed-stream path (ox_spmv_pk.hip): returns 1 when the matrix has none (or OX_PK_MODE=0)
-int ox_spmv_pk_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi, const double *dinv,
-                      const double *aux, double *partial, const int *done, hipStream_t st);
-int ox_spmv_pk_blocks(const ox_sell *A);
-int ox_pk_mode();
-// per-block partials a fused-epilogue SpMV launch on A writes
-static inline int ox_spmv_nparts(const ox_sell *A) {
-  return (ox_pk_mode() != 0 && A->pk_ptr && A->pk_cols && A->pk_base) ? ox_spmv_pk_blocks(A) : ox_spmv_blocks(A);
-}
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
                    hipStream_t st);

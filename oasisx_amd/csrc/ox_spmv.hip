@@ -166,10 +166,6 @@ extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
                    hipStream_t st) {
-  {  // packed stream (ox_spmv_pk.hip) where the matrix carries one
-    const int rc = ox_spmv_pk_launch(A, x, y, ncomp, epi, dinv, aux, partial, done, st);
-    if (rc <= 0) return rc;
-  }
   const int nblk = ox_spmv_blocks(A);
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {

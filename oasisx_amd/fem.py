@@ -38,26 +38,15 @@ def local_edges(gdim: int):
 import os as _os
 
 
-def default_tile_bits(mesh: Mesh, degree: int | None = None) -> int:
+def default_tile_bits(mesh: Mesh) -> int:
     """log2 of the tiles per slow direction for ``locality_key``: tiles of about 24 vertex lines
     (48 P2 lines) a side, whatever the mesh size -- 2 at 128^3 (measured on the whole step: 117.7 ms
-    with 2, 119.1 with 3, 120.8 with 4), 3 at 256^3.  OX_TILE_BITS overrides (tuning hook).
-
-    ``degree=1`` (dof order of a P1 space in 3-D; the cells keep the mesh-level value): the tiles are
-    additionally kept low enough that one tile plane (line length x lines per tile) stays under
-    ~4300 dofs, so that the columns of 4096 consecutive rows span <= ~12.7 K entries and the packed
-    SpMV can stage them in LDS (ox_spmv_pk.hip): 32 lines at 128^3, 16 at 256^3.  OX_TILE_BITS_P1
-    overrides."""
+    with 2, 119.1 with 3, 120.8 with 4), 3 at 256^3.  OX_TILE_BITS overrides (tuning hook)."""
     env = _os.environ.get("OX_TILE_BITS")
+    if env is not None:
+        return int(env)
     lines = max(float(mesh.num_vertices) ** (1.0 / mesh.gdim), 1.0)
-    tb = int(env) if env is not None else int(min(6, max(0, round(np.log2(lines / 24.0)))))
-    if degree == 1 and mesh.gdim == 3:
-        env1 = _os.environ.get("OX_TILE_BITS_P1")
-        if env1 is not None:
-            return int(env1)
-        while lines * (lines / 2 ** tb) > 4300.0 and tb < 8:
-            tb += 1
-    return tb
+    return int(min(6, max(0, round(np.log2(lines / 24.0)))))
 
 
 def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bits: int,
@@ -124,8 +113,6 @@ class SellPattern:
         self.device = cols.device
         self.dist = None  # ox_dist* (halo plan) of the column space, mesh-partitioned runs
         self.cols16 = self.cbase = None  # 16-bit column stream, built by struct() on the GPU
-        self.pk_ptr = self.pk_cols = self.pk_base = None  # packed column stream (pack())
-        self.pk_groups = self.pk_fallback_slices = 0
         self.frac16 = 0.0
         # width bins for the LDS-accumulating row kernels
         w = torch.from_numpy(widths.astype(np.int64))
@@ -156,48 +143,8 @@ class SellPattern:
                                                              _lib.current_stream()), "ox_sell_compress_cols")
                 self.frac16 = n16.value / self.size  # share of the stored entries read as 16 bit
             c16, cb = self.cols16.data_ptr(), self.cbase.data_ptr()
-        S = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                         self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
-        if c16 is not None and self.pack():
-            S.pk_ptr, S.pk_cols, S.pk_base = self.pk_ptr.data_ptr(), self.pk_cols.data_ptr(), self.pk_base.data_ptr()
-        return S
-
-    def pack(self) -> bool:
-        """Packed column stream of the pattern (``ox_sell_pack``: 8 entries of a row per 16-byte load),
-        built on first use on the GPU and shared by all matrices on the pattern."""
-        if self.pk_ptr is not None:
-            return True
-        if self.device.type != "cuda" or self.size == 0 or _os.environ.get("OX_PK_MODE", "") == "0":
-            return False
-        lib = _lib.load()
-        st = _lib.current_stream()
-        plain = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                             self.cols.data_ptr(), None, None, None, None, None)
-        self.pk_ptr = torch.zeros(self.n_slices + 1, dtype=torch.int64, device=self.device)
-        ng = C.c_int64(0)
-        _lib.check(lib.ox_sell_pack_plan(C.byref(plain), _lib.ptr(self.pk_ptr), C.byref(ng), st), "ox_sell_pack_plan")
-        self.pk_groups = int(ng.value)
-        self.pk_cols = torch.empty(self.pk_groups * 512, dtype=torch.int16, device=self.device)
-        self.pk_base = torch.empty(self.pk_groups * 16, dtype=torch.int32, device=self.device)
-        plain.pk_ptr = self.pk_ptr.data_ptr()
-        nfb = C.c_int64(0)
-        _lib.check(lib.ox_sell_pack(C.byref(plain), _lib.ptr(self.pk_cols), _lib.ptr(self.pk_base), None, None, 0,
-                                    C.byref(nfb), st), "ox_sell_pack")
-        self.pk_fallback_slices = int(nfb.value)
-        return True
-
-    def pack_values(self, vcode: torch.Tensor, zero_code: int) -> torch.Tensor:
-        """Packed 1-byte value codes of one matrix on this pattern (padding: ``zero_code``)."""
-        assert self.pack()
-        lib = _lib.load()
-        plain = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                             self.cols.data_ptr(), None, None, None, None, None)
-        plain.pk_ptr = self.pk_ptr.data_ptr()
-        pk_vals = torch.empty(self.pk_groups * 512, dtype=torch.uint8, device=self.device)
-        # the column part is rewritten with identical contents (one kernel does both)
-        _lib.check(lib.ox_sell_pack(C.byref(plain), _lib.ptr(self.pk_cols), _lib.ptr(self.pk_base), _lib.ptr(pk_vals),
-                                    _lib.ptr(vcode), int(zero_code), None, _lib.current_stream()), "ox_sell_pack")
-        return pk_vals
+        return _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
+                            self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
 
     def bins_args(self):
         return (int(self.bin_width.shape[0]), self.bin_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
@@ -279,7 +226,7 @@ class FunctionSpace:
     an owned dof (own cells + one ghost layer), so that every owned row is assembled locally."""
 
     def __init__(self, mesh: Mesh, degree: int, window: int = 4096, part=None,
-                 block_pairs: int = 1 << 24, block_nnz: int = 1 << 27, tile_bits: int | None = None):
+                 block_pairs: int = 1 << 24, block_nnz: int = 1 << 27):
         if degree not in (1, 2):
             raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
         self.mesh = mesh
@@ -346,7 +293,7 @@ class FunctionSpace:
             xL[~isv] = 0.5 * (mesh.coords[torch.div(ek, nverts, rounding_mode="floor")] + mesh.coords[ek % nverts])
         del isv
         # ---- 2. owned dofs in tiled spatial order, then ghosts by (owner, global id) --------------
-        skey = locality_key(xL, lo, span, default_tile_bits(mesh, degree) if tile_bits is None else int(tile_bits))
+        skey = locality_key(xL, lo, span, tb)
         if owned is None:
             perm1 = torch.argsort(skey, stable=True)
             n_owned = nL

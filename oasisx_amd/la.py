@@ -18,7 +18,7 @@ class SellMatrix:
         self.symmetric = symmetric
         self.name = name
         self.version = 0  # bumped whenever the values change (Jacobi setup is cached on it)
-        self.vcode = self.vdict = self._vc_version = self.pk_vals = None  # value dictionary, see freeze()
+        self.vcode = self.vdict = self._vc_version = None  # value dictionary, see freeze()
         self._struct = pattern.struct(self.vals)
 
     @property
@@ -31,8 +31,8 @@ class SellMatrix:
         return C.byref(self._struct)
 
     def _drop_codes(self):
-        self.vcode = self.vdict = self._vc_version = self.pk_vals = None
-        self._struct.vcode = self._struct.vdict = self._struct.pk_vals = None
+        self.vcode = self.vdict = self._vc_version = None
+        self._struct.vcode = self._struct.vdict = None
         self._struct.n_dict = 0
 
     def freeze(self, block: int = 1 << 27) -> bool:
@@ -46,9 +46,10 @@ class SellMatrix:
         if P.device.type != "cuda" or P.cols16 is None or P.size == 0:
             return False
         bits = self.vals.view(torch.int64)
-        u = torch.zeros(1, dtype=torch.int64, device=P.device)  # +0.0 is always a member: padding of the packed stream
+        u = None
         for a in range(0, P.size, block):
-            u = torch.unique(torch.cat([u, torch.unique(bits[a:a + block])]))
+            ub = torch.unique(bits[a:a + block])
+            u = ub if u is None else torch.unique(torch.cat([u, ub]))
             if u.numel() > 256:
                 return False
         code = torch.empty(P.size, dtype=torch.uint8, device=P.device)
@@ -58,10 +59,6 @@ class SellMatrix:
         self._vc_version = self.version
         self._struct.vcode, self._struct.vdict = self.vcode.data_ptr(), self.vdict.data_ptr()
         self._struct.n_dict = int(u.numel())
-        if P.pack():  # packed value codes ride on the pattern's packed column stream
-            zero_code = int(torch.searchsorted(u, torch.zeros(1, dtype=torch.int64, device=P.device)).item())
-            self.pk_vals = P.pack_values(self.vcode, zero_code)
-            self._struct.pk_vals = self.pk_vals.data_ptr()
         return True
 
     def getSize(self):

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-pmc_spmv}
 mkdir -p $OUT
 cd $R
-export REPS=3 ROUNDS=1 PALETTE=${PALETTE:-14}
+export REPS=3 ROUNDS=1 PALETTE=${PALETTE:-14} VARIANTS=${VARIANTS:-7}
 N=${N:-128}
 W=${W:-p}
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/p1 -- python3 tools/spmv_bench.py $N $W > $OUT/p1.log 2>&1
