@@ -46,7 +46,8 @@ def parse():
                     help="PETSc default: zero the solution before every Krylov solve "
                          "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-one-core", action="store_true",
+                    help="skip the 1-core repetition of the cpu_baseline step (about a minute at 128^3)")
     ap.add_argument("--matrix-free", action="store_true",
                     help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
                          "terms instead of the pre-assembled rectangular operators (reference "
@@ -376,10 +377,10 @@ def main():
             try:
                 from oracle.cpu_baseline import run_cpu_baseline
 
-                bc0 = S._bcs_u[0][0]
                 ksp_cpu = {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess}
                 out["cpu_baseline"] = run_cpu_baseline(
-                    S, clock, dt, nu, ksp_cpu, lambda t: np.stack([f(bc0._xbc, t) for f in fns]), gpu_step=step)
+                    S, clock, dt, nu, ksp_cpu, lambda X, t: np.stack([f(X, t) for f in fns]), gpu_step=step,
+                    mesh_def=([-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [N, N, N]), threads_1=not args.no_cpu_one_core)
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}

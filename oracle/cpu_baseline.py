@@ -7,6 +7,7 @@ in the order reference fracstep.py:660-696 drives DOLFINx/PETSc.  It is (a) vali
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import time
 
@@ -171,6 +172,105 @@ class CpuIPCS:
         return diff
 
 
+def reference_setup_tensors(d, deg):
+    """Reference-simplex tensors of the port's own mass / stiffness / weight assembly."""
+    bary, w = O.simplex_quadrature(d, 4)
+    phi, dphi = O.tabulate(d, deg, bary)
+    Tm = np.einsum("q,qi,qj->ij", w, phi, phi)
+    Tk = np.einsum("q,qia,qjb->ijab", w, dphi, dphi)
+    Ti = np.einsum("q,qi->i", w, phi)
+    return [np.ascontiguousarray(t) for t in (Tm, Tk, Ti)]
+
+
+def own_csr(lib, n_rows, row_dofs, col_dofs, n_cols=None):
+    """(indptr, indices) of the operator on (row space, col space), built by the C port from the
+    two cell->dof tables alone."""
+    nc, nd_r = row_dofs.shape
+    adj_ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    adj_cells = np.zeros(nc * nd_r, dtype=np.int32)
+    lib.cpu_adjacency(C.c_int64(n_rows), C.c_int64(nc), C.c_int(nd_r), _p(row_dofs), _p(adj_ptr), _p(adj_cells))
+    n_cols = n_rows if n_cols is None else n_cols
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    lib.cpu_pattern(C.c_int64(n_rows), C.c_int64(n_cols), _p(adj_ptr), _p(adj_cells), C.c_int(col_dofs.shape[1]),
+                    _p(col_dofs), _p(rp), None)
+    ci = np.zeros(int(rp[-1]), dtype=np.int32)
+    lib.cpu_pattern(C.c_int64(n_rows), C.c_int64(n_cols), _p(adj_ptr), _p(adj_cells), C.c_int(col_dofs.shape[1]),
+                    _p(col_dofs), _p(rp), _p(ci))
+    return rp, ci
+
+
+def from_mesh(coords, cells, u_deg, p_deg, ksp, body_force=None):
+    """CpuIPCS built from NOTHING but a mesh (vertex coordinates + cell->vertex table): own dof
+    numbering (oracle ``build_dofmap``: vertices, then edges by first appearance), own CSR patterns,
+    own mass / stiffness / pressure-Laplacian assembly, all in the C port.  Returns (cpu, x_v, x_q):
+    the solver and its dof coordinates, through which fields are matched with another
+    implementation's.  Velocity Dirichlet dofs = every dof on the bounding box of the mesh."""
+    import scipy.sparse as sp
+
+    lib = load()
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    cells = np.ascontiguousarray(cells, dtype=np.int64)
+    d = coords.shape[1]
+    nverts = coords.shape[0]
+    vd, nv_dofs, ev = O.build_dofmap(cells, nverts, u_deg)
+    x_v = O.dof_coordinates(coords, u_deg, ev)
+    if p_deg == u_deg:
+        qd, nq_dofs, x_q = vd, nv_dofs, x_v
+    else:
+        qd, nq_dofs, eq = O.build_dofmap(cells, nverts, p_deg)
+        x_q = O.dof_coordinates(coords, p_deg, eq)
+    del ev
+    G, adet = O.cell_geometry(coords, cells)
+    geom = pack_geometry(G, adet)
+    del G
+    vd32 = np.ascontiguousarray(vd, dtype=np.int32)
+    qd32 = np.ascontiguousarray(qd, dtype=np.int32)
+    nc = cells.shape[0]
+    rp, ci = own_csr(lib, nv_dofs, vd32, vd32)
+    Tm, Tk, Ti = reference_setup_tensors(d, u_deg)
+    Mv, Kv = np.zeros(ci.shape[0]), np.zeros(ci.shape[0])
+    lib.cpu_assemble_matrix(C.c_int(0), C.c_int(d), C.c_int(vd32.shape[1]), C.c_int64(nc), _p(geom), _p(vd32), _p(Tm),
+                            _p(rp), _p(ci), _p(Mv))
+    lib.cpu_assemble_matrix(C.c_int(1), C.c_int(d), C.c_int(vd32.shape[1]), C.c_int64(nc), _p(geom), _p(vd32), _p(Tk),
+                            _p(rp), _p(ci), _p(Kv))
+    wv = np.zeros(nv_dofs)
+    lib.cpu_assemble_weights(C.c_int(d), C.c_int(vd32.shape[1]), C.c_int64(nc), _p(geom), _p(vd32), _p(Ti), _p(wv))
+    prp, pci = (rp, ci) if p_deg == u_deg else own_csr(lib, nq_dofs, qd32, qd32)
+    _, Tkq, Tiq = reference_setup_tensors(d, p_deg)
+    pv = np.zeros(pci.shape[0])
+    lib.cpu_assemble_matrix(C.c_int(1), C.c_int(d), C.c_int(qd32.shape[1]), C.c_int64(nc), _p(geom), _p(qd32), _p(Tkq),
+                            _p(prp), _p(pci), _p(pv))
+    wq = np.zeros(nq_dofs)
+    lib.cpu_assemble_weights(C.c_int(d), C.c_int(qd32.shape[1]), C.c_int64(nc), _p(geom), _p(qd32), _p(Tiq), _p(wq))
+    vol = float(adet.sum()) / math.factorial(d)
+    M = sp.csr_matrix((Mv, ci, rp), shape=(nv_dofs, nv_dofs))
+    K = sp.csr_matrix((Kv, ci, rp), shape=(nv_dofs, nv_dofs))
+    Ap = sp.csr_matrix((pv, pci, prp), shape=(nq_dofs, nq_dofs))
+    f = np.zeros(d) if body_force is None else np.asarray(body_force, dtype=np.float64)
+    b0 = f[:, None] * wv[None, :]
+    bc = O.boundary_dofs(x_v, coords.min(axis=0), coords.max(axis=0)).astype(np.int32)
+    cpu = CpuIPCS(d, u_deg, p_deg, geom, vd32, qd32, M, K, Ap, b0, wq, vol, bc, ksp)
+    return cpu, x_v, x_q
+
+
+def match_by_coordinates(xa, xb, lo, hi):
+    """perm with xa[perm] == xb for two orderings of the same point set inside the box [lo, hi]
+    (lattice points of a box mesh and their edge midpoints: integer keys on a 2^20 lattice)."""
+    def key(x):
+        q = np.rint((x - lo) / (hi - lo) * float(1 << 20)).astype(np.int64)
+        k = q[:, 0]
+        for j in range(1, q.shape[1]):
+            k = (k << 21) | q[:, j]
+        return k
+    ka, kb = key(xa), key(xb)
+    oa, ob = np.argsort(ka, kind="stable"), np.argsort(kb, kind="stable")
+    if not (ka[oa] == kb[ob]).all():
+        raise RuntimeError("match_by_coordinates: the two point sets differ")
+    perm = np.empty_like(oa)
+    perm[ob] = oa
+    return perm
+
+
 def pack_geometry(G, adet):
     return np.ascontiguousarray(np.concatenate([G.reshape(G.shape[0], -1), adet[:, None]], axis=1))
 
@@ -204,50 +304,75 @@ def sell_to_csr_host(pattern, vals_list):
     return rp.cpu().numpy(), cols, vals
 
 
-def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values, gpu_step=None):
-    """Time ONE step of the same workload, from the GPU solver's current state, on the host
-    cores with the C/OpenMP port; optionally let the GPU take the same step and report the
-    relative difference of the two results (a full-size parity data point)."""
-    import scipy.sparse as sp
-    import torch
+def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_def=None, threads_1=True):
+    """Time ONE step of the same workload on the host cores with the C/OpenMP port and compare it
+    with the GPU's step from the same state.
 
+    The port is set up from the mesh DEFINITION alone (``mesh_def = (p0, p1, n)`` of the box): its
+    own vertex numbering and cell list (oracle ``create_box_mesh``), its own dof numbering, CSR
+    patterns and M / K / Ap assembly -- nothing is exported from the GPU but the state vectors
+    (u, u1, u2, p, dp), which are carried over through the dof COORDINATES.  The relative L2
+    difference of the two results after the step is therefore a full-size check of assembly, step
+    algebra and solvers with no shared dof map.  ``bc_values_at(X, t)`` -> (d, npts) Dirichlet values.
+    """
     Vi, Q = S._Vi[0][0], S._Q
     mesh = S._mesh
     d = mesh.gdim
     t0 = time.perf_counter()
-    rp, ci, (Mv, Kv) = sell_to_csr_host(Vi.pattern, [S._M.vals, S._K.vals])
-    prp, pci, (pv,) = sell_to_csr_host(Q.pattern, [S._Ap.vals])
+    p0, p1, nn = mesh_def
+    coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
+    cpu, x_v, x_q = from_mesh(coords, cells, Vi.degree, Q.degree, ksp, body_force=S._body_force)
+    del coords, cells
     n, nq = Vi.num_dofs, Q.num_dofs
-    M = sp.csr_matrix((Mv, ci, rp), shape=(n, n))
-    K = sp.csr_matrix((Kv, ci, rp), shape=(n, n))
-    Ap = sp.csr_matrix((pv, pci, prp), shape=(nq, nq))
-    geom = S._geom.cpu().numpy()  # rows lambda_1..d then |detJ|
-    nc = geom.shape[0]
-    Gd = geom[:, : d * d].reshape(nc, d, d)
-    G = np.concatenate([-Gd.sum(axis=1, keepdims=True), Gd], axis=1)
-    cpu = CpuIPCS(d, Vi.degree, Q.degree, pack_geometry(G, geom[:, d * d]), Vi.cell_dofs.cpu().numpy(),
-                  Q.cell_dofs.cpu().numpy(), M, K, Ap, S._B0.dev()[:n].cpu().numpy().T.copy(),
-                  S._wQ.cpu().numpy(), S._vol, S._bcs_u[0][0]._dofs, ksp)
-    cpu.u[:] = S._U.dev()[:n].cpu().numpy().T
-    cpu.u1[:] = S._U1.dev()[:n].cpu().numpy().T
-    cpu.u2[:] = S._U2.dev()[:n].cpu().numpy().T
-    cpu.p[:] = S._P.dev()[:nq, 0].cpu().numpy()
-    cpu.dp[:] = S._DP.dev()[:nq, 0].cpu().numpy()
+    lo, hi = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)
+    pv = match_by_coordinates(Vi.x[:n].cpu().numpy(), x_v, lo, hi)  # product index of the port's dof k
+    pq = pv if Q is Vi else match_by_coordinates(Q.x[:nq].cpu().numpy(), x_q, lo, hi)
+    cpu.u[:] = S._U.dev()[:n].cpu().numpy()[pv].T
+    cpu.u1[:] = S._U1.dev()[:n].cpu().numpy()[pv].T
+    cpu.u2[:] = S._U2.dev()[:n].cpu().numpy()[pv].T
+    cpu.p[:] = S._P.dev()[:nq, 0].cpu().numpy()[pq]
+    cpu.dp[:] = S._DP.dev()[:nq, 0].cpu().numpy()[pq]
     t_setup = time.perf_counter() - t0
     clock["t"] += dt
-    g = bc_values(clock["t"])
+    Xbc = np.zeros((3, cpu.bc_dofs.shape[0]))
+    Xbc[:d] = x_v[cpu.bc_dofs].T
+    g = bc_values_at(Xbc, clock["t"])
+    snap = [a.copy() for a in (cpu.u, cpu.u1, cpu.u2, cpu.p, cpu.dp)]
     t0 = time.perf_counter()
     cpu.step(dt, nu, g)
     t_step = time.perf_counter() - t0
     out = {"value": 1.0 / t_step, "unit": "steps/s", "cores": cpu.threads, "kind": "port",
-           "sample": f"1 time step of the same workload (same mesh, state, Krylov settings) on the host: "
-                     f"oracle/ipcs_cpu.c, OpenMP x{cpu.threads}, CSR, per-component solves as the reference",
+           "cpu_model": cpu_model(),
+           "sample": f"1 time step of the same workload (same mesh definition, state, Krylov settings) on the host: "
+                     f"oracle/ipcs_cpu.c, OpenMP x{cpu.threads}, CSR, per-component solves as the reference; own "
+                     f"dof numbering, patterns and M/K/Ap assembly",
            "seconds": t_step, "setup_seconds": t_setup, "krylov_iterations": cpu.its}
     if gpu_step is not None:
         clock["t"] -= dt
         gpu_step()
-        ug = S._U1.dev()[:n].cpu().numpy().T
-        pg = S._P.dev()[:nq, 0].cpu().numpy()
+        ug = S._U1.dev()[:n].cpu().numpy()[pv].T
+        pg = S._P.dev()[:nq, 0].cpu().numpy()[pq]
         out["gpu_vs_cpu_rel_l2_u"] = float(np.linalg.norm(ug - cpu.u1) / np.linalg.norm(cpu.u1))
         out["gpu_vs_cpu_rel_l2_p"] = float(np.linalg.norm(pg - cpu.p) / max(np.linalg.norm(cpu.p), 1e-300))
+        out["gpu_vs_cpu_shared"] = "mesh definition and state vectors only (matched through dof coordinates)"
+    if threads_1:  # the same step once more on ONE core (BASELINE.md: a 1-core figure beside the all-core one)
+        for a, b in zip((cpu.u, cpu.u1, cpu.u2, cpu.p, cpu.dp), snap):
+            a[:] = b
+        lib = load()
+        lib.cpu_set_threads(C.c_int(1))
+        t0 = time.perf_counter()
+        cpu.step(dt, nu, g)
+        t1 = time.perf_counter() - t0
+        lib.cpu_set_threads(C.c_int(cpu.threads))
+        out["one_core"] = {"value": 1.0 / t1, "seconds": t1}
     return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"

@@ -335,3 +335,125 @@ void cpu_axpby(int64_t n, double a, const double *x, double b, const double *y, 
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) z[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
 }
+
+/* ---- own set-up of the port (so that a full-size cross-check shares NOTHING with the product but
+ * the mesh definition): dof -> cell adjacency, CSR pattern, mass and stiffness assembly ---------- */
+
+/* adj_ptr[r] .. adj_ptr[r+1]: the cells that contain dof r (ascending), from a cell->dof table */
+void cpu_adjacency(int64_t n_rows, int64_t ncells, int nd, const int32_t *cell_dofs, int64_t *adj_ptr,
+                   int32_t *adj_cells) {
+  memset(adj_ptr, 0, sizeof(int64_t) * (size_t)(n_rows + 1));
+  for (int64_t i = 0; i < ncells * nd; ++i) adj_ptr[cell_dofs[i] + 1]++;
+  for (int64_t r = 0; r < n_rows; ++r) adj_ptr[r + 1] += adj_ptr[r];
+  int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_rows + 1));
+  memcpy(fill, adj_ptr, sizeof(int64_t) * (size_t)(n_rows + 1));
+  for (int64_t c = 0; c < ncells; ++c)
+    for (int k = 0; k < nd; ++k) adj_cells[fill[cell_dofs[c * nd + k]]++] = (int32_t)c;
+  free(fill);
+}
+
+static int cmp_i32(const void *a, const void *b) {
+  const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+  return (x > y) - (x < y);
+}
+
+/* CSR pattern of the operator with rows = dofs of the adjacency's space and columns = the col_dofs
+ * of the adjacent cells (DOLFINx create_matrix / create_sparsity_pattern, fracstep.py:293-300,324).
+ * ci == NULL: count only (fills rp); otherwise fill ci (sorted rows) with the rp of the first call. */
+void cpu_pattern(int64_t n_rows, int64_t n_cols, const int64_t *adj_ptr, const int32_t *adj_cells, int nd_c,
+                 const int32_t *col_dofs, int64_t *rp, int32_t *ci) {
+  if (!ci) rp[0] = 0;
+#pragma omp parallel
+  {
+    /* thread-private marker: mark[c] == r + 1 <=> column c already seen in row r */
+    int64_t *mark = (int64_t *)calloc((size_t)n_cols, sizeof(int64_t));
+    int32_t *buf = NULL;
+    int64_t cap = 0;
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < n_rows; ++r) {
+      const int64_t nc = adj_ptr[r + 1] - adj_ptr[r];
+      if (nc * nd_c > cap) {
+        cap = 2 * nc * nd_c;
+        buf = (int32_t *)realloc(buf, sizeof(int32_t) * (size_t)cap);
+      }
+      int64_t u = 0;
+      for (int64_t a = adj_ptr[r]; a < adj_ptr[r + 1]; ++a)
+        for (int k = 0; k < nd_c; ++k) {
+          const int32_t c = col_dofs[(int64_t)adj_cells[a] * nd_c + k];
+          if (mark[c] != r + 1) {
+            mark[c] = r + 1;
+            buf[u++] = c;
+          }
+        }
+      if (ci) {
+        qsort(buf, (size_t)u, sizeof(int32_t), cmp_i32);
+        memcpy(ci + rp[r], buf, sizeof(int32_t) * (size_t)u);
+      } else {
+        rp[r + 1] = u;
+      }
+    }
+    free(buf);
+    free(mark);
+  }
+  if (!ci)
+    for (int64_t r = 0; r < n_rows; ++r) rp[r + 1] += rp[r];
+}
+
+/* kind 0: u*v*dx with Tm[i][j] = int phi_i phi_j;  kind 1: inner(grad u, grad v)*dx with
+ * Tk[i][j][a][b] = int dphi_i/dl_a dphi_j/dl_b (reference simplex), Ae = |J| sum_ab (G[a].G[b]) Tk.
+ * assemble_matrix of fracstep.py:373-380; vals must be zeroed by the caller. */
+void cpu_assemble_matrix(int kind, int d, int nd, int64_t ncells, const double *geom,
+                         const int32_t *cell_dofs, const double *T, const int64_t *rp,
+                         const int32_t *ci, double *vals) {
+  const int nv = d + 1, gs = nv * d + 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < ncells; ++c) {
+    const double *G = geom + c * gs;
+    const double adet = G[nv * d];
+    const int32_t *dd = cell_dofs + c * nd;
+    double gg[MAXV][MAXV];
+    if (kind == 1)
+      for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b) {
+          double s = 0.0;
+          for (int e = 0; e < d; ++e) s += G[a * d + e] * G[b * d + e];
+          gg[a][b] = s;
+        }
+    for (int i = 0; i < nd; ++i)
+      for (int j = 0; j < nd; ++j) {
+        double s;
+        if (kind == 0) {
+          s = T[i * nd + j];
+        } else {
+          s = 0.0;
+          for (int a = 0; a < nv; ++a)
+            for (int b = 0; b < nv; ++b) s += gg[a][b] * T[((i * nd + j) * nv + a) * nv + b];
+        }
+        const int64_t pos = csr_find(rp, ci, dd[i], dd[j]);
+        const double val = adet * s;
+#pragma omp atomic
+        vals[pos] += val;
+      }
+  }
+}
+
+/* w[r] += int phi_r dx  (Ti[i] = int phi_i on the reference simplex) */
+void cpu_assemble_weights(int d, int nd, int64_t ncells, const double *geom, const int32_t *cell_dofs,
+                          const double *Ti, double *w) {
+  const int gs = (d + 1) * d + 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < ncells; ++c)
+    for (int i = 0; i < nd; ++i) {
+      const double val = geom[c * gs + (d + 1) * d] * Ti[i];
+#pragma omp atomic
+      w[cell_dofs[c * nd + i]] += val;
+    }
+}
+
+void cpu_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n < 1 ? 1 : n);
+#else
+  (void)n;
+#endif
+}
