@@ -1,23 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- time-steps/sec and pressure-CG SpMV GB/s of the IPCS hot path on MI355X.
 
-Workload (BASELINE.json configs[2]): 3-D Taylor-Green on [-1,1]^3, N^3 x 6 tetrahedra
-(N = 128 by default), P2-P1 Taylor-Hood, z-extruded analytic Taylor-Green field with exact
-Dirichlet data on every face, nu = 0.01, dt = 0.005*32/N, max_iter = 1, BiCGStab+Jacobi
-tentative velocity, CG+Jacobi pressure and velocity update, rtol 1e-8 / atol 1e-14.
-A "step" is one FractionalStep_AB_CN.solve().  Synthetic data, float64 throughout.
+Default workload (BASELINE.json configs[2]): 3-D Taylor-Green on [-1,1]^3, N^3 x 6 tetrahedra
+(N = 128), P2-P1 Taylor-Hood, z-extruded analytic Taylor-Green field with exact Dirichlet data on
+every face, nu = 0.01, dt = 0.005*32/N, max_iter = 1, BiCGStab+Jacobi tentative velocity, CG+Jacobi
+pressure and velocity update, rtol 1e-8 / atol 1e-14.  A "step" is one FractionalStep_AB_CN.solve().
+Synthetic data, float64 throughout.
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0.
+Other workloads: ``--workload beltrami`` (Ethier-Steinman, w != 0: SURVEY.md 8d's stronger field),
+``--workload cavity`` (BASELINE.json configs[3]: unit cube, lid u = (1,0,0) on z = 1, nu = 1e-3,
+dt = 1/N, from rest).
+
+Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
+  roofline      the pressure-Poisson CG SpMV: bytes the kernel really streams (its stored matrix +
+                vectors) / HIP-event time / 8 TB/s; `traffic` = HBM bytes per launch from two
+                rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same command, run as child
+                processes before the timed run; `csr_equivalent_gbs` = the metric's CSR-priced figure;
+                `past_cache` = the same kernel on the 256^3 pressure matrix (1.1 GB: beyond the 256 MB
+                Infinity Cache)
+  variants      the same timed steps with PETSc's default zero initial guess, and with the value
+                dictionaries off (what a mesh without bit-identical cells gets)
+  cpu_baseline  one step of the same workload on the host cores (oracle/ipcs_cpu.c), all cores and
+                one core, set up from the mesh definition alone
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 
 def spmv_bytes(nnz, n_rows, n_cols):
-    """Algorithmic bytes of one CSR SpMV, f64 values + int32 columns."""
+    """Bytes of one CSR SpMV, f64 values + int32 columns (SURVEY.md 8d / BASELINE.md)."""
     return 12 * nnz + 4 * (n_rows + 1) + 8 * n_cols + 8 * n_rows
 
 
@@ -42,16 +60,22 @@ def parse():
     ap.add_argument("-N", type=int, default=128, help="cubes per direction")
     ap.add_argument("--udeg", type=int, default=2)
     ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--workload", default="tg", choices=["tg", "beltrami", "cavity"])
     ap.add_argument("--zero-guess", action="store_true",
                     help="PETSc default: zero the solution before every Krylov solve "
                          "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-cpu-one-core", action="store_true",
                     help="skip the 1-core repetition of the cpu_baseline step (about a minute at 128^3)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the variant legs (zero guess, dictionaries off) and the 256^3 past-cache SpMV")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--matrix-free", action="store_true",
                     help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
                          "terms instead of the pre-assembled rectangular operators (reference "
                          "fracstep.py:392-404; the demo's default is the pre-assembled form)")
+    ap.add_argument("--no-dictionary", action="store_true", help="options['value_dictionary'] = False for the main run")
     ap.add_argument("--window", type=int, default=None,
                     help="rows per length-sorting window of the SELL-64 numbering (tuning; default: the library's)")
     ap.add_argument("--profile-setup", action="store_true",
@@ -76,15 +100,138 @@ def host_cores():
     return n
 
 
+# ---- HBM traffic of the pressure SpMV: rocprofv3 --pmc passes of this command ------------------
+def pmc_traffic(args, log):
+    """Run this same command (1 warm-up + 1 timed step, nothing else) twice under
+    ``rocprofv3 --pmc`` -- FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md's
+    HBM section prescribes -- and return the per-launch averages for the pressure CG SpMV.
+    Must run BEFORE this process touches the GPU (the children are started as ordinary child
+    processes; nothing is exec'ed from a GPU-initialised process).  FETCH_SIZE counts 128-B requests
+    as 64 B on gfx950: a streamed read is 2 x FETCH_SIZE (same section)."""
+    import csv
+    import glob
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="ox_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "-N", str(args.N), "--udeg", str(args.udeg),
+                   "--workload", args.workload, "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol)]
+            for flag, on in (("--zero-guess", args.zero_guess), ("--matrix-free", args.matrix_free),
+                             ("--no-dictionary", args.no_dictionary)):
+                if on:
+                    cmd.append(flag)
+            if args.window:
+                cmd += ["--window", str(args.window)]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if p.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode}): "
+                                 + p.stderr.decode(errors="replace")[-300:]}
+            child = None
+            for line in p.stdout.decode(errors="replace").splitlines():
+                if line.startswith("{") and '"pmc_child"' in line:
+                    child = json.loads(line)
+            if child is None:
+                return {"error": f"rocprofv3 --pmc {counter}: the child printed no record"}
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if (r["Counter_Name"] == counter and r["Kernel_Name"].replace(" ", "").startswith(child["kernel_prefix"])
+                            and int(r["Grid_Size"]) == child["grid_size"]):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return {"error": f"rocprofv3 --pmc {counter}: no dispatch of {child['kernel_prefix']} grid {child['grid_size']}"}
+            res[counter] = {"dispatches": len(vals), "avg_KiB": sum(vals) / len(vals)}
+            res["kernel"] = child["kernel_prefix"]
+    except Exception as e:  # the counters are a reported figure: never fail the bench for them
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = 2.0 * res["FETCH_SIZE"]["avg_KiB"] * 1024.0
+    wr = res["WRITE_SIZE"]["avg_KiB"] * 1024.0
+    log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
+    return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel": res["kernel"],
+            "dispatches": res["FETCH_SIZE"]["dispatches"],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command "
+                      "(FETCH_SIZE x 2: gfx950 counts 128-B requests as 64 B)", "seconds": time.perf_counter() - t0}
+
+
+# ---- workloads ----------------------------------------------------------------------------------
+def make_workload(name, N, np, torch):
+    """Analytic fields as array-API callables (numpy on the host, torch tensors on the device for the
+    per-step Dirichlet values)."""
+    pi = math.pi
+
+    def xp(x):
+        return torch if torch.is_tensor(x) else np
+
+    if name == "tg":
+        nu, dt = 0.01, 0.005 * 32.0 / N
+        box = ([-1.0, -1.0, -1.0], [1.0, 1.0, 1.0])
+        fns = [lambda x, t: -xp(x).cos(pi * x[0]) * xp(x).sin(pi * x[1]) * math.exp(-2.0 * nu * pi ** 2 * t),
+               lambda x, t: xp(x).cos(pi * x[1]) * xp(x).sin(pi * x[0]) * math.exp(-2.0 * nu * pi ** 2 * t),
+               lambda x, t: xp(x).zeros_like(x[0])]
+
+        def pres(x, t):
+            return -0.25 * (np.cos(2 * pi * x[0]) + np.cos(2 * pi * x[1])) * math.exp(-4.0 * nu * pi ** 2 * t)
+        desc = "3D Taylor-Green (z-extruded analytic field, exact Dirichlet data)"
+    elif name == "beltrami":
+        nu, dt = 0.01, 0.005 * 32.0 / N
+        box = ([-1.0, -1.0, -1.0], [1.0, 1.0, 1.0])
+        a, d = pi / 4.0, pi / 2.0
+
+        def comp(i, j, k):  # -a [e^{a x_i} sin(a x_j + d x_k) + e^{a x_k} cos(a x_i + d x_j)] e^{-nu d^2 t}
+            return lambda x, t: -a * (xp(x).exp(a * x[i]) * xp(x).sin(a * x[j] + d * x[k])
+                                      + xp(x).exp(a * x[k]) * xp(x).cos(a * x[i] + d * x[j])) * math.exp(-nu * d * d * t)
+        fns = [comp(0, 1, 2), comp(1, 2, 0), comp(2, 0, 1)]
+
+        def pres(x, t):
+            X, Y, Z = x[0], x[1], x[2]
+            s = (np.exp(2 * a * X) + np.exp(2 * a * Y) + np.exp(2 * a * Z)
+                 + 2 * np.sin(a * X + d * Y) * np.cos(a * Z + d * X) * np.exp(a * (Y + Z))
+                 + 2 * np.sin(a * Y + d * Z) * np.cos(a * X + d * Y) * np.exp(a * (Z + X))
+                 + 2 * np.sin(a * Z + d * X) * np.cos(a * Y + d * Z) * np.exp(a * (X + Y)))
+            return -0.5 * a * a * s * math.exp(-2.0 * nu * d * d * t)
+        desc = "3D Ethier-Steinman Beltrami flow (a = pi/4, d = pi/2, exact Dirichlet data)"
+    else:
+        nu, dt = 1e-3, 1.0 / N
+        box = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+
+        def lid(x, t):
+            on = x[2] > 1.0 - 1e-12
+            return on.to(torch.float64) if torch.is_tensor(x) else on.astype(np.float64)
+        fns = [lid, lambda x, t: xp(x).zeros_like(x[0]), lambda x, t: xp(x).zeros_like(x[0])]
+        pres = None
+        desc = "3D lid-driven cavity, unit cube, lid u = (1,0,0) on z = 1, Re = 1000, from rest"
+    return {"nu": nu, "dt": dt, "box": box, "fns": fns, "p": pres, "desc": desc, "analytic": name != "cavity"}
+
+
 def main():
     args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def log(*a):
+        if args.verbose and rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    # the PMC child passes come first: this process has not touched the GPU yet
+    traffic = None
+    if world == 1 and not args.no_pmc and not args.pmc_child:
+        traffic = pmc_traffic(args, log)
+
     os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))  # cpu_baseline leg (oracle/ipcs_cpu.c)
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local_rank %= torch.cuda.device_count()
@@ -102,35 +249,17 @@ def main():
     from oasisx_amd import mesh as M
 
     lib = _lib.load()
-    N, nu = args.N, 0.01
-    dt = 0.005 * 32.0 / N
+    N = args.N
+    W = make_workload(args.workload, N, np, torch)
+    nu, dt, fns = W["nu"], W["dt"], W["fns"]
     clock = {"t": 0.0}
-
-    def log(*a):
-        if args.verbose and rank == 0:
-            print("[bench]", *a, file=sys.stderr, flush=True)
-
-    import math
-
-    # array-API style: numpy for the initial conditions, torch device tensors for the per-step
-    # Dirichlet values (DirichletBC's opt-in ``supports_torch`` path keeps them off the host)
-    def xp(x):
-        return torch if torch.is_tensor(x) else np
-
-    def tg_u(x, t):
-        return -xp(x).cos(np.pi * x[0]) * xp(x).sin(np.pi * x[1]) * math.exp(-2.0 * nu * np.pi ** 2 * t)
-
-    def tg_v(x, t):
-        return xp(x).cos(np.pi * x[1]) * xp(x).sin(np.pi * x[0]) * math.exp(-2.0 * nu * np.pi ** 2 * t)
-
-    def tg_w(x, t):
-        return xp(x).zeros_like(x[0])
-
-    def tg_p(x, t):
-        return -0.25 * (np.cos(2 * np.pi * x[0]) + np.cos(2 * np.pi * x[1])) * math.exp(-4.0 * nu * np.pi ** 2 * t)
+    p0, p1 = W["box"]
 
     def on_boundary(x):
-        return (np.isclose(np.abs(x[0]), 1.0) | np.isclose(np.abs(x[1]), 1.0) | np.isclose(np.abs(x[2]), 1.0))
+        on = np.zeros(x.shape[1], dtype=bool)
+        for k in range(3):
+            on |= np.isclose(x[k], p0[k]) | np.isclose(x[k], p1[k])
+        return on
 
     prof = None
     if args.profile_setup:
@@ -144,27 +273,42 @@ def main():
         from oasisx_amd.parallel import init_comm
 
         comm = init_comm()  # RCCL communicator of the library, bootstrapped over torch.distributed
-    mesh = M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N])
-    fns = [tg_u, tg_v, tg_w]
+
     def bc_value(f):
         def g(x):
             return f(x, clock["t"])
         g.supports_torch = True
         return g
 
-    bcs_u = [[ox.DirichletBC(bc_value(f), ox.LocatorMethod.GEOMETRICAL, on_boundary)] for f in fns]
-    ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
-           "ksp_initial_guess_nonzero": not args.zero_guess}
-    solver_options = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"),
-                      "scalar": dict(ksp, ksp_type="cg")}
-    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", args.udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
-                                solver_options=solver_options,
-                                options=dict({"low_memory_version": args.matrix_free},
-                                             **({"sell_window": args.window} if args.window else {})))
-    for i, f in enumerate(fns):
-        S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
-        S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
-    S._p.interpolate(lambda x: tg_p(x, -dt / 2.0))
+    def build(n, udeg, opts, zero_guess):
+        mesh = M.create_box(comm, [p0, p1], [n, n, n])
+        bcs_u = [[ox.DirichletBC(bc_value(f), ox.LocatorMethod.GEOMETRICAL, on_boundary)] for f in fns]
+        ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
+               "ksp_initial_guess_nonzero": not zero_guess}
+        tent = dict(ksp, ksp_type="bcgs")
+        if args.workload == "cavity":
+            # a start from rest leaves the first BiCGStab residual on the identity rows only: rho = 0
+            # after one iteration, where PETSc's KSPBCGS reports DIVERGED_BREAKDOWN; the documented
+            # extension re-seeds the shadow residual instead (oasisx_amd/ksp.py)
+            tent["ksp_bcgs_restarts"] = 5
+        so = {"tentative": tent, "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")}
+        S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
+                                     solver_options=so, options=opts)
+        return mesh, S_
+
+    options = dict({"low_memory_version": args.matrix_free, "value_dictionary": not args.no_dictionary},
+                   **({"sell_window": args.window} if args.window else {}))
+    mesh, S = build(N, args.udeg, options, args.zero_guess)
+
+    def set_initial_state():
+        clock["t"] = 0.0
+        if W["analytic"]:
+            for i, f in enumerate(fns):
+                S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
+                S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
+            S._p.interpolate(lambda x: W["p"](x, -dt / 2.0))
+
+    set_initial_state()
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     if prof is not None:
@@ -203,10 +347,6 @@ def main():
         clock["t"] += dt
         return S.solve(dt, nu, max_iter=1)
 
-    for _ in range(args.warmup):
-        step()
-        log("warmup step", S.iteration_counts())
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -214,117 +354,188 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    # HIP events on the launching stream around every 8th launch of each kernel tag (an event pair costs
-    # ~12 us of stream bubbles; every launch would slow the 150 us pressure iteration by 8 %)
-    _lib.check(lib.ox_profile_begin(200000, 8), "ox_profile_begin")
-    phase_events["_on"] = True
-    t0 = time.perf_counter()
-    its = []
-    for _ in range(args.steps):
-        step()
-        its.append(S.iteration_counts())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    phase_events["_on"] = False
-    _lib.check(lib.ox_profile_end(), "ox_profile_end")
+    def timed_run(steps, warmup, main_run):
+        """W untimed + K timed steps, barrier + synchronize on both sides; returns seconds, iterations."""
+        for _ in range(warmup):
+            step()
+            log("warmup step", S.iteration_counts())
+        barrier()
+        # HIP events on the launching stream around every 8th launch of each kernel tag (an event pair
+        # costs ~12 us of stream bubbles; every launch would slow the 150 us pressure iteration by 8 %)
+        _lib.check(lib.ox_profile_begin(200000, 8), "ox_profile_begin")
+        phase_events["_on"] = main_run
+        t0 = time.perf_counter()
+        its = []
+        for _ in range(steps):
+            step()
+            its.append(S.iteration_counts())
+        barrier()
+        el = time.perf_counter() - t0
+        phase_events["_on"] = False
+        _lib.check(lib.ox_profile_end(), "ox_profile_end")
+        if world > 1:
+            import torch.distributed as dist
+
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, its
+
+    def mean_iterations(its):
+        return {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
+
+    elapsed, its = timed_run(args.steps, args.warmup, True)
     phase_ms = {k: sum(a.elapsed_time(b) for a, b in v) / args.steps for k, v in phase_events.items() if k != "_on"}
     # accuracy at the end of the timed steps: nodal error against the analytic field (rank-local dofs)
     Xd = S._Vi[0][0].x[: S._n_u].T
     Ud = S._U.dev()[: S._n_u]
-    err_u = max(float((Ud[:, i] - f(Xd, clock["t"])).abs().max()) for i, f in enumerate(fns))
-    if world > 1:
-        import torch.distributed as dist
+    err_u = max(float((Ud[:, i] - f(Xd, clock["t"])).abs().max()) for i, f in enumerate(fns)) if W["analytic"] else None
+    umax = float(Ud.abs().max())
 
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    def prof(tag, key=-1):
+    def prof_get(tag, key=-1):
         cnt, ms = C.c_longlong(0), C.c_double(0.0)
         _lib.check(lib.ox_profile_get(tag, key, C.byref(cnt), C.byref(ms)), "ox_profile_get")
         return int(cnt.value), float(ms.value)
 
-    gd = mesh.gdim
-    Pp, Pu = S._Ap.pattern, S._M.pattern
-    b_p = spmv_bytes(Pp.nnz, Pp.n_rows, Pp.n_cols)
-    # velocity SpMM on gd interleaved vectors: matrix read once, gd x/y vectors
-    b_u = 12 * Pu.nnz + 4 * (Pu.n_rows + 1) + gd * 8 * (Pu.n_cols + Pu.n_rows)
-    kernels = {}
-    ku, kp = Pu.n_rows, Pp.n_rows  # SpMV records are keyed by the matrix's row count
-    b_u1 = spmv_bytes(Pu.nnz, Pu.n_rows, Pu.n_cols)  # narrowed (1-column) solves on the velocity matrix
-    for name, tag, key, nbytes in (
-            ("pressure_cg_spmv", 11, kp, b_p),
-            ("velocity_bcgs_spmv_v", 10 * gd + 2, ku, b_u), ("velocity_bcgs_spmv_t", 10 * gd + 3, ku, b_u),
-            ("velocity_bcgs_spmv_v_narrowed", 12, ku, b_u1), ("velocity_bcgs_spmv_t_narrowed", 13, ku, b_u1),
-            ("mass_cg_spmv", 10 * gd + 1, ku, b_u), ("mass_cg_spmv_narrowed", 11, ku, b_u1),
-            ("mass_spmv", 10 * gd + 0, ku, b_u), ("assemble_first", 100, -1, None),
-            ("grad_vector_p", 110, -1, None), ("grad_vector_dp", 111, -1, None), ("div_vector", 120, -1, None),
-            ("rect_spmv_p_and_gradp", 140, -1, None), ("rect_spmv_div", 141, -1, None),
-            # mesh-partitioned runs: exchanges on rank 0 (both include the wait for the peers)
-            ("halo_exchange_1comp", 150, 1, None), ("halo_exchange_3comp", 150, 3, None),
-            ("krylov_sync_point", 151, -1, None)):
-        if key == kp and ku == kp and name != "pressure_cg_spmv":
-            continue  # P1-P1: both matrices have the same size; keep the pressure entry only
-        cnt, ms = prof(tag, key)
-        if cnt:
-            k = {"launches": cnt, "avg_us": 1e3 * ms / cnt, "total_ms": ms}
-            if nbytes:
-                k["algorithmic_bytes"] = nbytes
-                k["gbs"] = nbytes / (1e6 * ms / cnt)
-            kernels[name] = k
-    cg = kernels.get("pressure_cg_spmv")
-
-    def pmc_traffic():
-        """HBM bytes per launch of the pressure SpMV from the latest committed PMC pass
-        (profiles/*_pmc_hbm.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-        import csv
-        import glob
-
-        best = None
-        grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)  # launch grid of the pressure SpMV
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv"))):
-            for r in csv.DictReader(open(path)):
-                if r["kernel"].replace(" ", "").startswith("voidk_spmv<1,1") and int(r.get("grid_size", grid)) == grid:
-                    best = (float(r["hbm_total_MB_per_launch"]) * 1e6, os.path.basename(path))
-        return best
-
     def stored_bytes(A, nc=1):
-        """Bytes one SpMV launch actually streams from this SELL-64 storage: f64 values (or 1-byte
-        value codes where the matrix has a dictionary), 16-bit column codes where the pattern carries
-        them (int32 elsewhere), the per-pair bases, slice offsets and the x / y vectors -- padding
-        included."""
+        """Bytes one SpMV launch streams from this SELL-64 storage: f64 values (or 1-byte value codes
+        where the matrix has a dictionary), 16-bit column codes where the pattern carries them (int32
+        elsewhere), the per-pair bases, slice offsets and the x / y vectors -- padding included."""
         P = A.pattern
         cols = P.size * (2 * P.frac16 + 4 * (1.0 - P.frac16))
         bases = 8 * (P.size // 128) if P.frac16 > 0 else 0
         vals = (1 if A.vcode is not None else 8) * P.size
         return int(vals + cols + bases + 8 * (P.n_slices + 1) + nc * 8 * (P.n_cols + P.n_rows))
 
+    gd = mesh.gdim
+    Pp, Pu = S._Ap.pattern, S._M.pattern
+    b_p = spmv_bytes(Pp.nnz, Pp.n_rows, Pp.n_cols)
+    b_u = 12 * Pu.nnz + 4 * (Pu.n_rows + 1) + gd * 8 * (Pu.n_cols + Pu.n_rows)  # matrix once, gd x/y vectors
+    b_u1 = spmv_bytes(Pu.nnz, Pu.n_rows, Pu.n_cols)  # narrowed (1-column) solves on the velocity matrix
+    ku, kp = Pu.n_rows, Pp.n_rows  # SpMV records are keyed by the matrix's row count
+
+    def kernel_table():
+        kernels = {}
+        sA3, sA1 = stored_bytes(S._A, gd), stored_bytes(S._A, 1)
+        sM3, sM1 = stored_bytes(S._M, gd), stored_bytes(S._M, 1)
+        for name, tag, key, csr, moved in (
+                ("pressure_cg_spmv", 11, kp, b_p, stored_bytes(S._Ap)),
+                ("velocity_bcgs_spmv_v", 10 * gd + 2, ku, b_u, sA3), ("velocity_bcgs_spmv_t", 10 * gd + 3, ku, b_u, sA3),
+                ("velocity_bcgs_spmv_v_narrowed", 12, ku, b_u1, sA1), ("velocity_bcgs_spmv_t_narrowed", 13, ku, b_u1, sA1),
+                ("mass_cg_spmv", 10 * gd + 1, ku, b_u, sM3), ("mass_cg_spmv_narrowed", 11, ku, b_u1, sM1),
+                ("mass_spmv", 10 * gd + 0, ku, b_u, sM3), ("assemble_first", 100, -1, None, None),
+                ("grad_vector_p", 110, -1, None, None), ("grad_vector_dp", 111, -1, None, None),
+                ("div_vector", 120, -1, None, None),
+                ("rect_spmv_p_and_gradp", 140, -1, None, None), ("rect_spmv_div", 141, -1, None, None),
+                # mesh-partitioned runs: exchanges on rank 0 (both include the wait for the peers)
+                ("halo_exchange_1comp", 150, 1, None, None), ("halo_exchange_3comp", 150, 3, None, None),
+                ("krylov_sync_point", 151, -1, None, None)):
+            if key == kp and ku == kp and name != "pressure_cg_spmv":
+                continue  # P1-P1: both matrices have the same size; keep the pressure entry only
+            cnt, ms = prof_get(tag, key)
+            if cnt:
+                k = {"launches": cnt, "avg_us": 1e3 * ms / cnt, "total_ms": ms}
+                if csr:
+                    us = 1e3 * ms / cnt
+                    k.update({"bytes_moved": moved, "gbs": moved / (1e3 * us),
+                              "frac_of_hbm_peak": moved / (1e3 * us) / HBM_PEAK_GBS,
+                              "csr_bytes": csr, "csr_equivalent_gbs": csr / (1e3 * us)})
+                kernels[name] = k
+        return kernels
+
+    kernels = kernel_table()
+    cg = kernels.get("pressure_cg_spmv")
     roofline = None
     if cg:
-        sb = stored_bytes(S._Ap)
-        roofline = {"kernel": "k_spmv<1,OX_EPI_DOT> (pressure-Poisson CG SpMV, SELL-64, f64)", "bound": "hbm",
-                    "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": cg["gbs"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                    "algorithmic_bytes_per_launch": b_p, "avg_launch_us": cg["avg_us"],
-                    "launches": cg["launches"],
-                    # "achieved" prices the launch at the metric's CSR figure (12 B per nonzero,
-                    # BASELINE.md).  The kernel streams fewer bytes -- 16-bit column codes and, where the
-                    # matrix has <= 256 distinct values (Laplacian / mass on box meshes), 1-byte value
-                    # codes, both lossless -- so frac can exceed 1; the bytes really moved are here:
-                    "stored_bytes_per_launch": sb, "stored_gbs": sb / (1e3 * cg["avg_us"]),
-                    "stored_frac": sb / (1e3 * cg["avg_us"]) / HBM_PEAK_GBS,
-                    "cols16_fraction": Pp.frac16,
-                    "value_dictionary_entries": int(S._Ap._struct.n_dict),
-                    "note": ("achieved/frac use the metric's CSR byte count (BASELINE.md); frac > 1 means the "
-                             "kernel moves fewer bytes than CSR (lossless column/value codes) -- see stored_* "
-                             "and traffic for the bytes actually moved") if sb < b_p else None}
+        roofline = {"kernel": "k_spmv<1,OX_EPI_DOT,*> (pressure-Poisson CG SpMV, SELL-64, f64)", "bound": "hbm",
+                    # bytes the kernel really streams per launch (its stored matrix + x + y) / HIP-event time
+                    "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg["frac_of_hbm_peak"],
+                    "traffic": None, "traffic_detail": None,
+                    "bytes_moved_per_launch": cg["bytes_moved"], "avg_launch_us": cg["avg_us"], "launches": cg["launches"],
+                    "csr_bytes_per_launch": b_p, "csr_equivalent_gbs": cg["csr_equivalent_gbs"],
+                    "cols16_fraction": Pp.frac16, "value_dictionary_entries": int(S._Ap._struct.n_dict),
+                    "note": "achieved = stored bytes (lossless 16-bit column codes and, with a dictionary, 1-byte value "
+                            "codes; f64 arithmetic) / time; csr_equivalent_gbs prices the same launch at the metric's "
+                            "12 B per nonzero and is NOT a fraction of anything.  At 128^3 the 139 MB matrix fits the "
+                            "256 MB Infinity Cache between CG iterations: see past_cache for the HBM-resident size"}
+        if traffic is not None:
+            if "error" in traffic:
+                roofline["traffic_detail"] = traffic
+            else:
+                roofline["traffic"] = traffic["bytes_per_launch"]
+                roofline["traffic_detail"] = traffic
 
-    if roofline and N == 128 and args.udeg == 2:
-        tr = pmc_traffic()
-        if tr:
-            roofline["traffic"], roofline["traffic_source"] = tr[0], "profiles/" + tr[1]
+    # ---- variant legs on the same solver (reported beside the headline, never instead of it) -------
+    variants = {}
+    if world == 1 and not args.no_extras and not args.pmc_child:
+        sv = min(args.steps, 5)
+
+        def leg(label, note):
+            el, it = timed_run(sv, 1, False)
+            kt = kernel_table()
+            variants[label] = {"value": sv / el, "unit": "steps/s", "ms_per_step": 1e3 * el / sv, "steps": sv,
+                               "krylov_iterations_per_step": mean_iterations(it),
+                               "pressure_cg_spmv": kt.get("pressure_cg_spmv"), "note": note}
+
+        guess_now = not args.zero_guess
+        for sol in (S._solver_u, S._solver_p, S._solver_c):
+            sol.updateOptions({"ksp_initial_guess_nonzero": not guess_now})
+        leg("initial_guess_nonzero=%s" % (not guess_now),
+            "PETSc's default is a zero initial guess; the headline uses -ksp_initial_guess_nonzero" if guess_now else
+            "the previous field as the initial guess (-ksp_initial_guess_nonzero)")
+        for sol in (S._solver_u, S._solver_p, S._solver_c):
+            sol.updateOptions({"ksp_initial_guess_nonzero": guess_now})
+        if not args.no_dictionary and S._Ap.vcode is not None:
+            for A in (S._M, S._K, S._Ap):
+                A._drop_codes()
+            if not args.matrix_free:
+                for A in (S._p_vdxi_Mat, S._grad_p_Mat, S._divu_Mat):
+                    A.unfreeze()
+            leg("value_dictionary=False",
+                "f64 value streams everywhere: what a mesh without bit-identical cells (any unstructured mesh) gets; "
+                "same arithmetic, same results")
+
+    # ---- the metric's kernel past the Infinity Cache: 256^3 pressure matrix -----------------------
+    if world == 1 and not args.no_extras and not args.pmc_child and roofline is not None:
+        try:
+            t0 = time.perf_counter()
+            m2 = M.create_box(None, [p0, p1], [256, 256, 256])
+            bc2 = [[ox.DirichletBC(0.0, ox.LocatorMethod.GEOMETRICAL, on_boundary)] for _ in range(3)]
+            S2 = ox.FractionalStep_AB_CN(m2, ("Lagrange", 1), ("Lagrange", 1), bcs_u=bc2, bcs_p=[],
+                                         options={"low_memory_version": True, "value_dictionary": not args.no_dictionary})
+            A2 = S2._Ap
+            P2 = A2.pattern
+            x2 = (torch.sin(torch.arange(P2.n_cols, device="cuda", dtype=torch.float64) * 1e-3) + 1).reshape(-1, 1)
+            y2 = torch.zeros_like(x2)
+            for _ in range(20):
+                A2.mult(x2, y2, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                A2.mult(x2, y2, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 200
+            sb2 = stored_bytes(A2)
+            csr2 = spmv_bytes(P2.nnz, P2.n_rows, P2.n_cols)
+            roofline["past_cache"] = {
+                "workload": "pressure Laplacian of the 256^3 box mesh (P1, 16 974 593 rows, SURVEY.md 8 C5), "
+                            "x_j = sin(j*1e-3)+1, 200 launches after 20 warm-up (SURVEY.md 8d), plain y = A x",
+                "nnz": P2.nnz, "bytes_moved_per_launch": sb2, "avg_launch_us": us,
+                "achieved": sb2 / (1e3 * us), "frac": sb2 / (1e3 * us) / HBM_PEAK_GBS, "unit": "GB/s",
+                "csr_bytes_per_launch": csr2, "csr_equivalent_gbs": csr2 / (1e3 * us),
+                "value_dictionary_entries": int(A2._struct.n_dict), "seconds": time.perf_counter() - t0}
+            del S2, A2, x2, y2, m2
+            torch.cuda.empty_cache()
+        except Exception as e:
+            roofline["past_cache"] = {"error": repr(e)}
+
+    if args.pmc_child:  # what the parent needs to find this run's pressure SpMV in the counter CSV
+        var = 7 if S._Ap.vcode is not None else (3 if Pp.frac16 > 0 else 1)
+        grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)
+        print(json.dumps({"pmc_child": True, "kernel_prefix": f"voidk_spmv<1,1,{var}>", "grid_size": grid}), flush=True)
+        return
+
     transport_check = None
     if world > 1:  # the transports once more after the timed steps: every ghost dof must still get its owner's value
         S._Vi[0][0].check_halo()
@@ -338,17 +549,17 @@ def main():
         dist.all_reduce(tn)
         nnz_glob = [int(v) for v in tn.tolist()]
     if rank == 0:
-        mean_its = {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
+        mean_its = mean_iterations(its)
+        short = {"tg": "Taylor-Green", "beltrami": "Beltrami (Ethier-Steinman)", "cavity": "lid-driven cavity"}[args.workload]
         out = {
-            "metric": "time-steps/sec, 3D Taylor-Green %d^3 P2-P1 (with pressure-CG SpMV GB/s in roofline)" % N
-            if args.udeg == 2 else "time-steps/sec, 3D Taylor-Green %d^3 P%d-P1" % (N, args.udeg),
+            "metric": f"time-steps/sec, 3D {short} {N}^3 P{args.udeg}-P1 (with pressure-CG SpMV GB/s in roofline)",
             "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D Taylor-Green {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
+            "config": {"workload": f"{W['desc']}, {N}^3x6 tets P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
                                    f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
                                    f"initial_guess_nonzero={not args.zero_guess}, max_iter=1, "
-                                   f"low_memory_version={args.matrix_free}",
+                                   f"low_memory_version={args.matrix_free}, value_dictionary={not args.no_dictionary}",
                        "cells": mesh.num_cells, "n_u_per_component": S._Vi[0][0].num_dofs_global,
                        "n_p": S._Q.num_dofs_global,
                        "nnz_velocity": nnz_glob[0], "nnz_pressure": nnz_glob[1], "parallelism": f"mesh-partition x{world}",
@@ -357,18 +568,16 @@ def main():
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
                        if world > 1 else None,
                        "transport_check": transport_check},
-            "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the metric's second figure
+            "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
             "phase_ms_per_step": phase_ms,  # device time between events around each phase method (rank 0)
-            # whole Jacobi-CG iteration of the pressure solve in the metric's bytes (SURVEY.md 8d:
-            # SpMV + 16 vector passes), over the measured time per iteration
-            "pressure_cg_iteration": ({"us": 1e3 * phase_ms["pressure_solve"] / max(mean_its["pressure"], 1.0),
-                                       "algorithmic_gbs": (b_p + 128 * Pp.n_rows) * max(mean_its["pressure"], 1.0)
-                                       / (1e6 * phase_ms["pressure_solve"])}
+            # whole Jacobi-CG iteration of the pressure solve (SpMV + vector kernels + scalar kernels)
+            "pressure_cg_iteration": ({"us": 1e3 * phase_ms["pressure_solve"] / max(mean_its["pressure"], 1.0)}
                                       if phase_ms.get("pressure_solve") else None),
-            "accuracy": {"max_nodal_error_u_vs_analytic": err_u, "t_end": clock["t"]},
+            "accuracy": {"max_nodal_error_u_vs_analytic": err_u, "max_abs_u": umax, "t_end": clock["t"]},
             "kernels": kernels,
+            "variants": variants,
             "setup_s": t_setup,
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
             "cpu_baseline": None,  # timed on rank 0 at N = 1 only (below)
@@ -379,8 +588,8 @@ def main():
 
                 ksp_cpu = {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess}
                 out["cpu_baseline"] = run_cpu_baseline(
-                    S, clock, dt, nu, ksp_cpu, lambda X, t: np.stack([f(X, t) for f in fns]), gpu_step=step,
-                    mesh_def=([-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [N, N, N]), threads_1=not args.no_cpu_one_core)
+                    S, clock, dt, nu, ksp_cpu, lambda X, t: np.stack([np.asarray(f(X, t), dtype=np.float64) for f in fns]),
+                    gpu_step=step, mesh_def=(p0, p1, [N, N, N]), threads_1=not args.no_cpu_one_core)
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}

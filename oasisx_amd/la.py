@@ -125,8 +125,15 @@ class MultiSellMatrix:
                 code[a:a + rows] |= c[:, d] << (8 * d)
         self.vcode, self.vdict = code, u.view(torch.float64).contiguous()
         full.vcode, full.vdict, full.n_dict = self.vcode.data_ptr(), self.vdict.data_ptr(), int(u.numel())
+        self._plain = self._struct
         self._struct = full
         return True
+
+    def unfreeze(self):
+        """Back to the f64 value stream (bench.py's dictionary-off leg); same results."""
+        if self.vcode is not None:
+            self._struct = self._plain
+            self.vcode = self.vdict = None
 
     def mult(self, v2s: bool, x, base, scale: float, y):
         """y = base + scale * (A applied to x); x, base, y are device pointers (c_void_p)."""

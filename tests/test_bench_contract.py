@@ -21,7 +21,9 @@ def _check(d, live_cpu=True):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (1e3 * r["avg_launch_us"])) < 1e-6 * r["achieved"]
+    assert 0.0 < r["frac"] < 1.0  # a fraction of the HBM peak: bytes really moved, not CSR-priced
+    assert abs(r["achieved"] - r["bytes_moved_per_launch"] / (1e3 * r["avg_launch_us"])) < 1e-6 * r["achieved"]
+    assert r["csr_equivalent_gbs"] >= r["achieved"]
     c = d["cpu_baseline"]
     if live_cpu:
         assert {"value", "unit", "cores", "kind", "sample"} <= set(c), c
@@ -30,16 +32,21 @@ def _check(d, live_cpu=True):
 
 
 def test_committed_bench_line_meets_the_contract():
-    path = os.path.join(ROOT, "profiles", "r01_bench_default_with_cpu_baseline.json")
+    path = os.path.join(ROOT, "profiles", "r02_bench_default.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     _check(d)
     assert d["n_gpus"] == 1 and "128^3" in d["config"]["workload"]
-    assert d["roofline"]["traffic"] is not None  # PMC pass of the same command, profiles/*_pmc_hbm.csv
+    r = d["roofline"]
+    assert r["traffic"] is not None and r["traffic_detail"]["dispatches"] > 0  # live PMC child passes of the command
+    assert 0.5 < r["traffic"] / r["bytes_moved_per_launch"] < 2.0  # counters agree with the stored bytes
+    assert 0.0 < r["past_cache"]["frac"] < 1.0 and r["past_cache"]["bytes_moved_per_launch"] > 256 * 2 ** 20
+    assert any(k.startswith("value_dictionary") for k in d["variants"]) and any("guess" in k for k in d["variants"])
+    assert d["cpu_baseline"]["one_core"]["value"] < d["cpu_baseline"]["value"] and d["cpu_baseline"]["cpu_model"]
 
 
 @pytest.mark.gpu
 def test_bench_runs_and_prints_one_json_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "-N", "16", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "-N", "16", "--steps", "2", "--warmup", "1", "--no-extras"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
