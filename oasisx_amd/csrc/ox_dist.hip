@@ -288,8 +288,12 @@ __global__ __launch_bounds__(256) void k_halo_pull(double *__restrict__ ghost, i
                                                    const unsigned long long *hflag,
                                                    const int32_t *__restrict__ peers, int n_peers,
                                                    unsigned long long seq, long long timeout_ticks, int *err) {
-  if ((int)threadIdx.x < n_peers) ox_p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err);
+  __shared__ int failed;
+  if (threadIdx.x == 0) failed = 0;
   __syncthreads();
+  if ((int)threadIdx.x < n_peers && !ox_p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err)) failed = 1;
+  __syncthreads();
+  if (failed) return;  // a peer never delivered: leave the ghost block alone (the sticky flag fails the host call)
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
     ghost[i] = __hip_atomic_load(stage + i, __ATOMIC_RELAXED, OX_SYS);

@@ -217,14 +217,18 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
   double v[OX_MAX_NV];
   ox_gather_partials(partial, nparts, nv, v);
   ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
-  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done) return;  // every rank skips this exchange
+  // A queued sync point that runs after `done` still takes part in the exchange (the host has advanced
+  // the sequence number for it; skipping would let two LIVE exchanges share a parity slot), it only
+  // leaves the state alone.  `done` is the same on every rank (rank-ordered sums: identical bits).
+  const bool idle = PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i)
-      if (i < nv) vals[i] = v[i];
+      if (i < nv) vals[i] = idle ? 0.0 : v[i];
   }
   __syncthreads();
   ox_p2p_allreduce_block(vals, nv, ar, stage);
+  if (idle) return;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i) v[i] = i < nv ? vals[i] : 0.0;

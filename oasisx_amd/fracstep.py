@@ -396,6 +396,9 @@ class FractionalStep_AB_CN:
         _lib.check(lib.ox_axpby(n, 1.0, self._U1.ptr(), 0.0, None, self._U2.ptr(), st), "ox_axpby")
         _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._U1.ptr(), st), "ox_axpby")
         _lib.check(lib.ox_axpby(nq, 1.0, self._PS.ptr(), 0.0, None, self._P.ptr(), st), "ox_axpby")
+        for d_ in (self._du, self._dq):  # partitioned runs: a peer wait that timed out anywhere in the step fails it
+            if d_ is not None:
+                _lib.check(lib.ox_dist_status(d_), "ox_dist_status (halo exchange / all-reduce of this step)")
         return diff
 
     @property

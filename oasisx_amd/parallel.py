@@ -16,8 +16,10 @@ ksp.py:77).  Here:
   (``ox_halo_forward``); per Krylov synchronisation point one small all-reduce merges all dot
   products.  Two device transports sit behind those call sites: direct xGMI stores into
   IPC-mapped windows (``p2p``, two small kernels per exchange) and RCCL (grouped
-  ncclSend/ncclRecv, ncclAllReduce).  ``OX_TRANSPORT=auto`` (default) enables p2p, self-tests it
-  collectively and keeps RCCL when any rank fails; ``p2p`` / ``rccl`` / ``host`` force one.
+  ncclSend/ncclRecv, ncclAllReduce).  Default: ``rccl`` when the job has an RCCL communicator (the
+  conservative choice until the windows have run between two real GPUs); ``OX_TRANSPORT=auto`` enables
+  p2p, self-tests it collectively and keeps RCCL when any rank fails; ``p2p`` / ``rccl`` / ``host``
+  force one.
 """
 from __future__ import annotations
 
@@ -38,7 +40,11 @@ class Comm:
         import os
 
         self.rank, self.size, self.handle = rank, size, handle
-        self.transport = (transport or os.environ.get("OX_TRANSPORT", "auto")).lower()
+        # default: RCCL where the job has an RCCL communicator (the library transport, until the xGMI
+        # windows have moved bytes between two real GPUs); a gloo job (rehearsals on one GPU) has none
+        # and falls through "auto": the windows, self-tested, else the host-staged transport
+        default = "rccl" if handle is not None else "auto"
+        self.transport = (transport or os.environ.get("OX_TRANSPORT", default)).lower()
         if self.transport not in ("auto", "p2p", "rccl", "host"):
             raise ValueError(f"OX_TRANSPORT={self.transport!r}: expected auto, p2p, rccl or host")
         self.active = {}  # space degree -> transport that ended up serving its plan
