@@ -99,6 +99,84 @@ typedef struct {
   double bnorm[4];           /* per component, preconditioned norm of b                  */
 } ox_ksp_result;
 
+/* ---- set-up: mesh -> spaces -> patterns (ox_setup.hip) ----------------------------------
+ * What DOLFINx does for the reference behind functionspace() / create_matrix() /
+ * create_sparsity_pattern() (reference fracstep.py:187-216,293-300,315,324,336,352).  The objects
+ * own their device arrays; the *_view calls hand out pointers that stay valid until the object is
+ * destroyed (pointers named *_host are host memory).  A binding needs nothing but these calls and
+ * numpy arrays of vertex coordinates and cell->vertex indices. */
+typedef struct ox_mesh ox_mesh;
+typedef struct ox_space ox_space;
+typedef struct ox_rect ox_rect;
+
+typedef struct {
+  int32_t gdim, tile_bits;
+  int64_t n_vertices, n_cells;
+  double lo[3], span[3];     /* bounding box                                                */
+  const double *coords;      /* device [n_vertices][gdim]                                   */
+  const int32_t *cells;      /* device [n_cells][gdim+1], KERNEL order (tiled by centroid)  */
+  const int32_t *cell_perm;  /* device [n_cells]: kernel cell index -> caller's cell index  */
+  ox_cells cells_struct;     /* geometry of the cells in kernel order, as the kernels take it */
+} ox_mesh_info;
+
+typedef struct {
+  ox_sell sell;              /* the pattern (vals == NULL: copy the struct and set vals per matrix) */
+  int64_t size, nnz;         /* storage slots (padding included) / real entries             */
+  int64_t n_compressed;      /* slots read through the 16-bit column stream                 */
+  const int32_t *row_len;    /* device [n_rows]                                             */
+  int32_t n_bins;            /* width bins of the assembly launches (ox_assemble_matrix)    */
+  const int64_t *bin_ptr_host;
+  const int32_t *bin_width_host;
+  const int32_t *bin_slices; /* device [n_slices]                                           */
+  const int32_t *widths_host;/* host [n_slices]                                             */
+} ox_pattern_info;
+
+typedef struct {
+  int32_t degree, nd, pw, gdim; /* dofs per cell; stride of the position bytes              */
+  int64_t n_dofs, n_edges, n_pairs;
+  const int32_t *cell_dofs;     /* device [n_cells][nd], kernel cell order, final numbering */
+  const double *x;              /* device [n_dofs][gdim] dof coordinates                    */
+  const int32_t *rank_initial;  /* device [n_dofs]: vertex id (or n_vertices + edge id) -> dof */
+  const uint64_t *edge_keys;    /* device [n_edges]: min_vertex * n_vertices + max_vertex, ascending */
+  ox_adj adj;                   /* dof -> cell adjacency in slice order                      */
+  const uint8_t *adj_pos;       /* device [n_pairs][pw]                                      */
+  const int64_t *pair_start;    /* device [n_dofs+1]: cells per dof = pair_start[r+1] - pair_start[r] */
+  ox_pattern_info pattern;      /* square operator on the space (M, K, A share it: fracstep.py:293-294) */
+} ox_space_info;
+
+typedef struct {
+  int32_t pw;
+  const uint8_t *pos;           /* device [rows' n_pairs][pw]: in-row positions of the column space's cell dofs */
+  ox_pattern_info pattern;
+} ox_rect_info;
+
+/* coords [n_vertices][gdim] f64, cells [n_cells][gdim+1] int32 (any order, any orientation);
+ * on_device: the two pointers are device pointers; tile_bits < 0: default. */
+int ox_mesh_create(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                   int on_device, int tile_bits, ox_mesh **out);
+int ox_mesh_view(const ox_mesh *mesh, ox_mesh_info *view);
+int ox_mesh_destroy(ox_mesh *mesh);
+/* scalar Lagrange space of degree 1 or 2 (functionspace(mesh, ("Lagrange", k)), fracstep.py:187-216);
+ * window: rows per length-sorting window of the SELL-64 numbering (< 64: the default 4096). */
+int ox_space_create(const ox_mesh *mesh, int degree, int window, ox_space **out);
+int ox_space_view(const ox_space *space, ox_space_info *view);
+int ox_space_destroy(ox_space *space);
+/* pattern of a mixed operator, rows = dofs of `rows`, columns = dofs of `cols` (fracstep.py:315,336,352) */
+int ox_rect_create(const ox_space *rows, const ox_space *cols, ox_rect **out);
+int ox_rect_view(const ox_rect *rect, ox_rect_info *view);
+int ox_rect_destroy(ox_rect *rect);
+/* Value dictionary of a matrix that will not change any more (M, K, Ap, the rectangular operators):
+ * vals [n_slots][ncomp] device doubles.  At most 256 distinct bit patterns: dict (device, room for 256,
+ * ascending as signed 64-bit integers), *n_dict of them, and codes (device; ncomp == 1: one byte per
+ * slot, ncomp 2..3: one uint32 per slot, byte c = code of component c).  More: *n_dict = 0. */
+int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *codes, double *dict, int *n_dict,
+                        void *stream);
+/* plain device memory for callers without a device array library (numpy + ctypes) */
+int ox_malloc(size_t bytes, void **out);
+int ox_free(void *p);
+int ox_memset(void *p, int value, size_t bytes, void *stream);
+int ox_synchronize(void *stream);
+
 /* ---- library -------------------------------------------------------------------- */
 int ox_version(void);
 const char *ox_last_error(void);

@@ -56,6 +56,64 @@ class ox_adj(C.Structure):
     ]
 
 
+class ox_mesh_info(C.Structure):
+    _fields_ = [
+        ("gdim", C.c_int32),
+        ("tile_bits", C.c_int32),
+        ("n_vertices", C.c_int64),
+        ("n_cells", C.c_int64),
+        ("lo", C.c_double * 3),
+        ("span", C.c_double * 3),
+        ("coords", C.c_void_p),
+        ("cells", C.c_void_p),
+        ("cell_perm", C.c_void_p),
+        ("cells_struct", ox_cells),
+    ]
+
+
+class ox_pattern_info(C.Structure):
+    _fields_ = [
+        ("sell", ox_sell),
+        ("size", C.c_int64),
+        ("nnz", C.c_int64),
+        ("n_compressed", C.c_int64),
+        ("row_len", C.c_void_p),
+        ("n_bins", C.c_int32),
+        ("bin_ptr_host", C.c_void_p),
+        ("bin_width_host", C.c_void_p),
+        ("bin_slices", C.c_void_p),
+        ("widths_host", C.c_void_p),
+    ]
+
+
+class ox_space_info(C.Structure):
+    _fields_ = [
+        ("degree", C.c_int32),
+        ("nd", C.c_int32),
+        ("pw", C.c_int32),
+        ("gdim", C.c_int32),
+        ("n_dofs", C.c_int64),
+        ("n_edges", C.c_int64),
+        ("n_pairs", C.c_int64),
+        ("cell_dofs", C.c_void_p),
+        ("x", C.c_void_p),
+        ("rank_initial", C.c_void_p),
+        ("edge_keys", C.c_void_p),
+        ("adj", ox_adj),
+        ("adj_pos", C.c_void_p),
+        ("pair_start", C.c_void_p),
+        ("pattern", ox_pattern_info),
+    ]
+
+
+class ox_rect_info(C.Structure):
+    _fields_ = [
+        ("pw", C.c_int32),
+        ("pos", C.c_void_p),
+        ("pattern", ox_pattern_info),
+    ]
+
+
 class ox_ksp_result(C.Structure):
     _fields_ = [
         ("reason", C.c_int32 * 4),
@@ -76,6 +134,20 @@ SIGNATURES = {
     "ox_last_error": (C.c_char_p, []),
     "ox_sell_kv": (_I, []),
     "ox_device_info": (_I, [C.POINTER(_I), C.c_char_p, _I]),
+    "ox_mesh_create": (_I, [_P, _L, _P, _L, _I, _I, _I, C.POINTER(_P)]),
+    "ox_mesh_view": (_I, [_P, C.POINTER(ox_mesh_info)]),
+    "ox_mesh_destroy": (_I, [_P]),
+    "ox_space_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "ox_space_view": (_I, [_P, C.POINTER(ox_space_info)]),
+    "ox_space_destroy": (_I, [_P]),
+    "ox_rect_create": (_I, [_P, _P, C.POINTER(_P)]),
+    "ox_rect_view": (_I, [_P, C.POINTER(ox_rect_info)]),
+    "ox_rect_destroy": (_I, [_P]),
+    "ox_value_dictionary": (_I, [_P, _L, _I, _P, _P, C.POINTER(_I), _P]),
+    "ox_malloc": (_I, [C.c_size_t, C.POINTER(_P)]),
+    "ox_free": (_I, [_P]),
+    "ox_memset": (_I, [_P, _I, C.c_size_t, _P]),
+    "ox_synchronize": (_I, [_P]),
     "ox_spmv": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_sell_compress_cols": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _P]),
     "ox_spmv_multi": (_I, [_I, _I, C.POINTER(ox_sell), _P, _P, _D, _P, _P, _P]),

@@ -1,0 +1,1140 @@
+// Set-up of the IPCS path behind the C ABI: from a simplicial mesh (vertex coordinates + cell->vertex
+// table) to everything the kernels of this library read -- kernel cell order and geometry, Lagrange
+// P1/P2 dof numbering in SELL-64 row order, cell->dof tables, the SELL-64 sparsity pattern with its
+// 16-bit column stream, the dof->cell adjacency with in-row position bytes, the width bins of the
+// assembly launches, the rectangular (V x Q, Q x V) patterns and the 1-byte value dictionaries.
+// It replaces what DOLFINx does for the reference behind functionspace(), create_matrix() /
+// create_sparsity_pattern() and the dofmap (reference fracstep.py:187,293-300,315,324,336,352).
+//
+// Everything runs on the device (rocPRIM radix sorts / scans + a few kernels of our own); sizes go
+// through size_t / int64 so patterns beyond 2^31 storage slots (256^3 P2) are built the same way.
+// The numbering is the one DESIGN.md section 2 describes: dofs (and cells, by centroid) ordered by
+// (tile_z, tile_y, z, y, x), then, inside windows of `window` rows, stably by decreasing row length.
+#include <cstring>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "ox_common.h"
+
+namespace {
+
+constexpr int KV = OX_KV;
+constexpr int SLICE = OX_SLICE;
+constexpr int ROW_CAP = 2048;  // candidate columns of one row (adjacent cells x dofs per cell) held in LDS
+
+struct DevBuf {  // owned device allocation
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  int alloc(size_t b) {
+    release();
+    bytes = b;
+    if (b == 0) return 0;
+    if (hipMalloc(&p, b) != hipSuccess) {
+      p = nullptr;
+      snprintf(ox_err_buf, sizeof(ox_err_buf), "set-up: hipMalloc of %zu bytes failed", b);
+      return -1;
+    }
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+  void *detach() {
+    void *q = p;
+    p = nullptr;
+    bytes = 0;
+    return q;
+  }
+};
+
+#define OX_TRY(expr)          \
+  do {                        \
+    if ((expr) != 0) return -1; \
+  } while (0)
+
+// ---- small device helpers -------------------------------------------------------------------
+template <class K, class V>
+int sort_pairs(K *keys_in, K *keys_out, V *vals_in, V *vals_out, size_t n, int end_bit, hipStream_t st) {
+  if (n == 0) return 0;
+  size_t tb = 0;
+  OX_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st));
+  DevBuf tmp;
+  OX_TRY(tmp.alloc(tb));
+  OX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int exclusive_scan_i64(const int64_t *in, int64_t *out, size_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  size_t tb = 0;
+  OX_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), st));
+  DevBuf tmp;
+  OX_TRY(tmp.alloc(tb));
+  OX_HIP(rocprim::exclusive_scan(tmp.p, tb, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int bits_for(uint64_t maxval) {
+  int b = 1;
+  while (b < 64 && (maxval >> b)) ++b;
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_iota32(int32_t *v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = (int32_t)i;
+}
+
+// per-dimension min / max of an [n][d] point set: per-block partials, finished on the host
+__global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, int64_t n, int d, double *__restrict__ part) {
+  __shared__ double lo_s[4][3], hi_s[4][3];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    for (int k = 0; k < d; ++k) {
+      const double v = x[i * d + k];
+      lo[k] = fmin(lo[k], v);
+      hi[k] = fmax(hi[k], v);
+    }
+  for (int k = 0; k < 3; ++k)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fmin(lo[k], __shfl_down(lo[k], off, 64));
+      hi[k] = fmax(hi[k], __shfl_down(hi[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; ++k) lo_s[threadIdx.x >> 6][k] = lo[k], hi_s[threadIdx.x >> 6][k] = hi[k];
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; ++k) {
+      part[blockIdx.x * 6 + k] = fmin(fmin(lo_s[0][k], lo_s[1][k]), fmin(lo_s[2][k], lo_s[3][k]));
+      part[blockIdx.x * 6 + 3 + k] = fmax(fmax(hi_s[0][k], hi_s[1][k]), fmax(hi_s[2][k], hi_s[3][k]));
+    }
+}
+
+// ordering key of a point: (tile_z, tile_y, z, y, x) on a 2^bits lattice
+struct KeySpec {
+  double lo[3], inv[3];  // (x - lo) * inv in [0, 2^bits - 1]
+  int d, bits, tb;
+};
+__device__ __forceinline__ uint64_t locality_key(const double *p, const KeySpec &K) {
+  uint64_t q[3] = {0, 0, 0};
+  for (int k = 0; k < K.d; ++k) {
+    double v = rint((p[k] - K.lo[k]) * K.inv[k]);
+    const double top = (double)((1ull << K.bits) - 1);
+    v = v < 0.0 ? 0.0 : (v > top ? top : v);
+    q[k] = (uint64_t)v;
+  }
+  uint64_t key = 0;
+  for (int k = K.d - 1; k >= 1; --k) key = (key << K.tb) | (q[k] >> (K.bits - K.tb));
+  for (int k = K.d - 1; k >= 0; --k) key = (key << K.bits) | q[k];
+  return key;
+}
+
+__global__ __launch_bounds__(256) void k_cell_keys(const double *__restrict__ coords, const int32_t *__restrict__ cells,
+                                                   int64_t nc, KeySpec K, uint64_t *__restrict__ keys,
+                                                   int32_t *__restrict__ ids) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  const int nv = K.d + 1;
+  double cen[3] = {0, 0, 0};
+  for (int a = 0; a < nv; ++a)
+    for (int k = 0; k < K.d; ++k) cen[k] += coords[(int64_t)cells[c * nv + a] * K.d + k];
+  for (int k = 0; k < K.d; ++k) cen[k] /= (double)nv;
+  keys[c] = locality_key(cen, K);
+  ids[c] = (int32_t)c;
+}
+
+__global__ __launch_bounds__(256) void k_point_keys(const double *__restrict__ x, int64_t n, KeySpec K,
+                                                    uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = locality_key(x + i * K.d, K);
+  ids[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_gather_cells(const int32_t *__restrict__ cells, const int32_t *__restrict__ perm,
+                                                      int64_t nc, int nv, int32_t *__restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  for (int a = 0; a < nv; ++a) out[c * nv + a] = cells[(int64_t)perm[c] * nv + a];
+}
+
+// [n_cells][gs] rows of grad(lambda_1..d) then |detJ| (gs = 6 in 2-D, 10 in 3-D): closed-form inverses
+__global__ __launch_bounds__(256) void k_geometry(const double *__restrict__ coords, const int32_t *__restrict__ cells,
+                                                  int64_t nc, int d, double *__restrict__ geom) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  const int nv = d + 1, gs = d == 2 ? 6 : 10;
+  double *g = geom + c * gs;
+  const double *x0 = coords + (int64_t)cells[c * nv] * d;
+  double e[3][3];  // rows = edge vectors x_a - x_0
+  for (int a = 1; a < nv; ++a)
+    for (int k = 0; k < d; ++k) e[a - 1][k] = coords[(int64_t)cells[c * nv + a] * d + k] - x0[k];
+  if (d == 2) {
+    const double a = e[0][0], b = e[1][0], cc = e[0][1], dd = e[1][1];  // J = [[a, b], [cc, dd]]
+    const double det = a * dd - b * cc;
+    g[0] = dd / det, g[1] = -b / det, g[2] = -cc / det, g[3] = a / det;
+    g[4] = fabs(det);
+    g[5] = 0.0;
+  } else {
+    const double *e1 = e[0], *e2 = e[1], *e3 = e[2];
+    double c23[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    double c31[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    double c12[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = e1[0] * c23[0] + e1[1] * c23[1] + e1[2] * c23[2];
+    for (int k = 0; k < 3; ++k) g[k] = c23[k] / det, g[3 + k] = c31[k] / det, g[6 + k] = c12[k] / det;
+    g[9] = fabs(det);
+  }
+}
+
+// ---- P2: edges ------------------------------------------------------------------------------
+__device__ __constant__ int EDGE2[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+__device__ __constant__ int EDGE3[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+
+__global__ __launch_bounds__(256) void k_edge_keys(const int32_t *__restrict__ cells, int64_t nc, int d, int64_t nverts,
+                                                   uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int ne = d == 2 ? 3 : 6;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nc * ne) return;
+  const int64_t c = i / ne;
+  const int le = (int)(i - c * ne);
+  const int a = d == 2 ? EDGE2[le][0] : EDGE3[le][0], b = d == 2 ? EDGE2[le][1] : EDGE3[le][1];
+  const int64_t va = cells[c * (d + 1) + a], vb = cells[c * (d + 1) + b];
+  keys[i] = (uint64_t)(va < vb ? va : vb) * (uint64_t)nverts + (uint64_t)(va < vb ? vb : va);
+  ids[i] = (int32_t)i;  // nc * ne < 2^31 is checked by the caller
+}
+
+__global__ __launch_bounds__(256) void k_heads(const uint64_t *__restrict__ ks, int64_t n, int64_t *__restrict__ head) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1 : 0;
+}
+
+// eid = exclusive scan of head shifted: id of sorted position i = (#heads at positions <= i) - 1
+__global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *__restrict__ ks, const int32_t *__restrict__ pos,
+                                                      const int64_t *__restrict__ head, const int64_t *__restrict__ excl,
+                                                      int64_t n, int32_t *__restrict__ cell_edges,
+                                                      uint64_t *__restrict__ edge_keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = excl[i] + head[i] - 1;
+  cell_edges[pos[i]] = (int32_t)id;
+  if (head[i]) edge_keys[id] = ks[i];
+}
+
+__global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, const int32_t *__restrict__ cell_edges,
+                                             int64_t nc, int d, int degree, int64_t nverts, int32_t *__restrict__ cd0) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  const int nv = d + 1, ne = degree == 2 ? (d == 2 ? 3 : 6) : 0, nd = nv + ne;
+  for (int a = 0; a < nv; ++a) cd0[c * nd + a] = cells[c * nv + a];
+  for (int e = 0; e < ne; ++e) cd0[c * nd + nv + e] = (int32_t)(nverts + cell_edges[c * ne + e]);
+}
+
+__global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ coords, const uint64_t *__restrict__ edge_keys,
+                                                    int64_t nverts, int64_t n, int d, double *__restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (i < nverts) {
+    for (int k = 0; k < d; ++k) x[i * d + k] = coords[i * d + k];
+  } else {
+    const uint64_t key = edge_keys[i - nverts];
+    const int64_t a = (int64_t)(key / (uint64_t)nverts), b = (int64_t)(key % (uint64_t)nverts);
+    for (int k = 0; k < d; ++k) x[i * d + k] = 0.5 * (coords[a * d + k] + coords[b * d + k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_invert(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ rank) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) rank[perm[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_relabel(const int32_t *__restrict__ in, const int32_t *__restrict__ rank, int64_t n,
+                                                 int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rank[in[i]];
+}
+
+__global__ __launch_bounds__(256) void k_compose(const int32_t *__restrict__ r1, const int32_t *__restrict__ r2, int64_t n,
+                                                 int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = r2[r1[i]];
+}
+
+__global__ __launch_bounds__(256) void k_permute_points(const double *__restrict__ xin, const int32_t *__restrict__ rank,
+                                                        int64_t n, int d, double *__restrict__ xout) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < d; ++k) xout[(int64_t)rank[i] * d + k] = xin[i * d + k];
+}
+
+// ---- dof -> (cell, local index) pairs grouped by dof -----------------------------------------
+__global__ __launch_bounds__(256) void k_pair_keys(const int32_t *__restrict__ cell_dofs, int64_t npairs,
+                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  keys[i] = (uint32_t)cell_dofs[i];
+  vals[i] = (uint32_t)i;  // = cell * nd + local index  (< 2^32 is checked by the caller)
+}
+
+// start[r] = first sorted position whose key is >= r (every dof occurs at least once)
+__global__ __launch_bounds__(256) void k_group_starts(const uint32_t *__restrict__ ks, int64_t npairs, int64_t n,
+                                                      int64_t *__restrict__ start) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  const uint32_t k = ks[i];
+  if (i == 0) {
+    for (uint32_t r = 0; r <= k; ++r) start[r] = 0;
+  } else {
+    const uint32_t kp = ks[i - 1];
+    for (uint32_t r = kp + 1; r <= k; ++r) start[r] = i;
+  }
+  if (i == npairs - 1)
+    for (int64_t r = (int64_t)k + 1; r <= n; ++r) start[r] = npairs;
+}
+
+// ---- the row kernel: one wave per row ---------------------------------------------------------
+// Candidates = the column-space dofs of the row's adjacent cells (in adjacency order), held in LDS;
+// first-occurrence flags and the rank of every candidate among the row's distinct columns by
+// all-pairs comparison (rows have 15 .. ~70 distinct columns; ~2 ms for 17 M rows).
+// mode 0: len[r] = number of distinct columns.
+// mode 1: cols (SELL slots, ascending per row, padding = own row), and per adjacency pair the cell,
+//         the row dof's local index and the in-row positions of the cell's column dofs.
+struct RowArgs {
+  int64_t n_rows, n_cols;
+  const int64_t *start;        // [n_rows+1] pair offsets of the rows (pairs grouped by row dof)
+  const uint32_t *pair;        // [npairs] cell * nd_r + local index, cells ascending per row
+  int nd_r, nd_c;
+  const int32_t *col_dofs;     // [n_cells][nd_c]
+  int32_t *len;                // mode 0
+  const int64_t *slice_ptr;    // mode 1 ...
+  int32_t *cols;
+  const int64_t *adj_ptr;
+  int32_t *adj_cell;
+  uint8_t *adj_loc;            // may be NULL (rectangular patterns reuse the row space's)
+  uint8_t *adj_pos;
+  int pw;
+  int *err;                    // 1: a row has more than ROW_CAP candidates; 2: a row is wider than 255
+};
+
+template <int MODE>
+__device__ __forceinline__ void k_rows_one(const RowArgs &A, int64_t r, int lane, int32_t *cand, uint16_t *rk, uint8_t *fs);
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rows(RowArgs A) {
+  __shared__ int32_t cand_s[4][ROW_CAP];
+  __shared__ uint16_t rank_s[4][ROW_CAP];
+  __shared__ uint8_t first_s[4][ROW_CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n_slots_rows = ((A.n_rows + SLICE - 1) / SLICE) * SLICE;
+  int32_t *cand = cand_s[wave];
+  uint16_t *rk = rank_s[wave];
+  uint8_t *fs = first_s[wave];
+  // grid-stride over the rows (a grid of n_rows / 4 blocks would exceed 2^32 threads beyond 2^26 rows)
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < (MODE == 0 ? A.n_rows : n_slots_rows); r += (int64_t)gridDim.x * 4)
+    k_rows_one<MODE>(A, r, lane, cand, rk, fs);
+}
+
+template <int MODE>
+__device__ __forceinline__ void k_rows_one(const RowArgs &A, int64_t r, int lane, int32_t *cand, uint16_t *rk, uint8_t *fs) {
+  if (MODE == 1 && r >= A.n_rows) {  // rows that only pad the last slice: columns point at 0, no pairs
+    const int64_t s = r >> 6;
+    const int64_t base = A.slice_ptr[s];
+    const int width = (int)((A.slice_ptr[s + 1] - base) >> 6);
+    for (int k = lane; k < width; k += 64)
+      A.cols[base + (int64_t)(k / KV) * (SLICE * KV) + (r & 63) * KV + (k % KV)] = 0;
+    const int64_t abase = A.adj_ptr[s];
+    const int T = (int)((A.adj_ptr[s + 1] - abase) >> 6);
+    for (int t = lane; t < T; t += 64) {
+      const int64_t pidx = abase + (int64_t)t * 64 + (r & 63);
+      A.adj_cell[pidx] = -1;
+      if (A.adj_loc) A.adj_loc[pidx] = 0;
+      for (int j = 0; j < A.pw; ++j) A.adj_pos[pidx * A.pw + j] = 0;
+    }
+    return;
+  }
+  const int64_t p0 = A.start[r];
+  const int m = (int)(A.start[r + 1] - p0);
+  const int nc = m * A.nd_c;
+  if (nc > ROW_CAP) {
+    if (lane == 0) atomicExch(A.err, 1);
+    if (MODE == 0 && lane == 0) A.len[r] = 0;
+    return;
+  }
+  for (int i = lane; i < nc; i += 64) {
+    const int t = i / A.nd_c, j = i - t * A.nd_c;
+    const int64_t cell = A.pair[p0 + t] / (uint32_t)A.nd_r;
+    cand[i] = A.col_dofs[cell * A.nd_c + j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
+  int nfirst = 0;
+  for (int i = lane; i < nc; i += 64) {
+    const int32_t v = cand[i];
+    bool f = true;
+    for (int j = 0; j < i; ++j) f = f && (cand[j] != v);
+    fs[i] = f ? 1 : 0;
+    nfirst += f ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) nfirst += __shfl_xor(nfirst, off, 64);
+  if (MODE == 0) {
+    if (lane == 0) A.len[r] = nfirst;
+    return;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int i = lane; i < nc; i += 64) {
+    const int32_t v = cand[i];
+    int q = 0;
+    for (int j = 0; j < nc; ++j) q += (fs[j] && cand[j] < v) ? 1 : 0;
+    rk[i] = (uint16_t)q;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const int64_t s = r >> 6;
+  const int rl = (int)(r & 63);
+  const int64_t base = A.slice_ptr[s];
+  const int width = (int)((A.slice_ptr[s + 1] - base) >> 6);
+  if (width > 255 && lane == 0) atomicExch(A.err, 2);
+  auto slot = [&](int k) { return base + (int64_t)(k / KV) * (SLICE * KV) + rl * KV + (k % KV); };
+  for (int i = lane; i < nc; i += 64)
+    if (fs[i]) A.cols[slot(rk[i])] = cand[i];
+  const int64_t nlim = A.n_rows < A.n_cols ? A.n_rows : A.n_cols;
+  const int32_t own = r < nlim ? (int32_t)r : 0;
+  for (int k = nfirst + lane; k < width; k += 64) A.cols[slot(k)] = own;  // padding: own row, value 0
+  // adjacency pairs of this row: (t, lane) of slice s at adj_ptr[s] + t*64 + lane
+  const int64_t abase = A.adj_ptr[s];
+  const int T = (int)((A.adj_ptr[s + 1] - abase) >> 6);
+  for (int t = lane; t < T; t += 64) {
+    const int64_t pidx = abase + (int64_t)t * 64 + rl;
+    if (t < m) {
+      const uint32_t pv = A.pair[p0 + t];
+      A.adj_cell[pidx] = (int32_t)(pv / (uint32_t)A.nd_r);
+      if (A.adj_loc) A.adj_loc[pidx] = (uint8_t)(pv % (uint32_t)A.nd_r);
+      for (int j = 0; j < A.pw; ++j) A.adj_pos[pidx * A.pw + j] = j < A.nd_c ? (uint8_t)rk[t * A.nd_c + j] : 0;
+    } else {
+      A.adj_cell[pidx] = -1;
+      if (A.adj_loc) A.adj_loc[pidx] = 0;
+      for (int j = 0; j < A.pw; ++j) A.adj_pos[pidx * A.pw + j] = 0;
+    }
+  }
+}
+
+// per slice: storage width (max row length, rounded up to OX_KV, at least OX_KV) and adjacency depth
+__global__ __launch_bounds__(256) void k_slice_sizes(const int32_t *__restrict__ row_len, const int64_t *__restrict__ start,
+                                                     int64_t n_rows, int64_t n_slices, int64_t *__restrict__ width64,
+                                                     int64_t *__restrict__ depth64, int32_t *__restrict__ width32) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  if (s >= n_slices) return;
+  const int64_t r = s * 64 + lane;
+  int w = r < n_rows ? row_len[r] : 0;
+  int t = (start && r < n_rows) ? (int)(start[r + 1] - start[r]) : 0;
+  for (int off = 32; off > 0; off >>= 1) {
+    w = max(w, __shfl_xor(w, off, 64));
+    t = max(t, __shfl_xor(t, off, 64));
+  }
+  w = ((w + KV - 1) / KV) * KV;
+  if (w < KV) w = KV;
+  if (lane == 0) {
+    width64[s] = (int64_t)w * SLICE;
+    if (depth64) depth64[s] = (int64_t)t * SLICE;
+    width32[s] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_window_keys(const int32_t *__restrict__ len, int64_t n, int window, int lmax,
+                                                     uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  keys[r] = (uint64_t)(r / window) * (uint64_t)(lmax + 1) + (uint64_t)(lmax - len[r]);
+  ids[r] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(256) void k_gather_i32(const int32_t *__restrict__ in, const int32_t *__restrict__ idx,
+                                                    int64_t n, int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+
+inline unsigned nblk(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+// grid of the wave-per-row kernels: 4 rows per block, capped (the kernels stride)
+inline unsigned row_grid(int64_t rows) { return (unsigned)std::min<int64_t>((rows + 3) / 4, (int64_t)1 << 22); }
+
+int reduce_max_i32(const int32_t *v, int64_t n, int32_t *out_host, hipStream_t st) {
+  *out_host = 0;
+  if (n == 0) return 0;
+  DevBuf res, tmp;
+  OX_TRY(res.alloc(sizeof(int32_t)));
+  size_t tb = 0;
+  OX_HIP(rocprim::reduce(nullptr, tb, v, res.as<int32_t>(), (int32_t)0, (size_t)n, rocprim::maximum<int32_t>(), st));
+  OX_TRY(tmp.alloc(tb));
+  OX_HIP(rocprim::reduce(tmp.p, tb, v, res.as<int32_t>(), (int32_t)0, (size_t)n, rocprim::maximum<int32_t>(), st));
+  OX_HIP(hipMemcpyAsync(out_host, res.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int reduce_sum_i32(const int32_t *v, int64_t n, int64_t *out_host, hipStream_t st) {
+  *out_host = 0;
+  if (n == 0) return 0;
+  DevBuf res, tmp;
+  OX_TRY(res.alloc(sizeof(int64_t)));
+  auto in = rocprim::make_transform_iterator(v, [] __device__(int32_t a) { return (int64_t)a; });
+  size_t tb = 0;
+  OX_HIP(rocprim::reduce(nullptr, tb, in, res.as<int64_t>(), (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
+  OX_TRY(tmp.alloc(tb));
+  OX_HIP(rocprim::reduce(tmp.p, tb, in, res.as<int64_t>(), (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
+  OX_HIP(hipMemcpyAsync(out_host, res.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace
+
+// ================================== the objects ====================================================
+struct ox_mesh {
+  int gdim = 0, tile_bits = 0, key_bits = 18;
+  int64_t nv = 0, nc = 0;
+  double lo[3] = {0, 0, 0}, span[3] = {1, 1, 1};
+  DevBuf coords;     // [nv][gdim]
+  DevBuf cells;      // [nc][gdim+1] int32, KERNEL order
+  DevBuf cell_perm;  // [nc] int32: kernel index -> caller's cell index
+  DevBuf geom;       // [nc][gs]
+};
+
+struct ox_pattern_store {  // SELL-64 pattern + 16-bit stream + width bins
+  int64_t n_rows = 0, n_cols = 0, n_slices = 0, size = 0, nnz = 0, n16 = 0;
+  DevBuf slice_ptr, cols, row_len, cols16, cbase, bin_slices;
+  std::vector<int32_t> widths, bin_width;
+  std::vector<int64_t> bin_ptr;
+};
+
+struct ox_space {
+  const ox_mesh *mesh = nullptr;
+  int degree = 0, nd = 0, pw = 0, window = 0;
+  int64_t n = 0, n_edges = 0, npairs = 0;  // dofs, edges, padded adjacency pairs
+  DevBuf cell_dofs;     // [nc][nd] int32, final numbering
+  DevBuf x;             // [n][gdim]
+  DevBuf rank_initial;  // [n] int32: initial dof (vertex id, or nv + edge id) -> final dof
+  DevBuf edge_keys;     // [n_edges] uint64: min_vertex * nv + max_vertex, ascending (edge id = position)
+  DevBuf start, pair;   // pairs grouped by final dof (kept for rectangular patterns)
+  DevBuf adj_ptr, adj_cell, adj_loc, adj_pos, adj_count;
+  ox_pattern_store P;
+};
+
+struct ox_rect {
+  const ox_space *R = nullptr, *C = nullptr;
+  int pw = 0;
+  DevBuf pos;  // [R.npairs][pw]
+  ox_pattern_store P;
+};
+
+namespace {
+
+KeySpec key_spec(const ox_mesh *M, int tb) {
+  KeySpec K;
+  K.d = M->gdim;
+  K.tb = tb;
+  int bits = 18;
+  while (bits > 4 && (K.d - 1) * tb + K.d * bits > 63) --bits;
+  if (tb > bits) K.tb = bits;
+  K.bits = bits;
+  for (int k = 0; k < 3; ++k) {
+    K.lo[k] = M->lo[k];
+    K.inv[k] = (double)((1ull << bits) - 1) / M->span[k];
+  }
+  return K;
+}
+
+// pattern of (rows grouped in `start`/`pair`, columns from col_dofs) with given row lengths
+int finish_pattern(ox_pattern_store &P, hipStream_t st) {
+  // 16-bit column stream
+  if (P.size > 0) {
+    OX_TRY(P.cols16.alloc(sizeof(uint16_t) * (size_t)P.size));
+    OX_TRY(P.cbase.alloc(sizeof(int32_t) * 2 * (size_t)(P.size / (SLICE * KV))));
+    ox_sell S{};
+    S.n_rows = P.n_rows, S.n_cols = P.n_cols, S.n_slices = (int32_t)P.n_slices;
+    S.slice_ptr = P.slice_ptr.as<int64_t>(), S.cols = P.cols.as<int32_t>();
+    if (ox_sell_compress_cols(&S, P.cols16.as<uint16_t>(), P.cbase.as<int32_t>(), &P.n16, st)) return -1;
+  }
+  // width bins for the LDS-accumulating row kernels: slices sorted (stably) by width
+  std::vector<int32_t> order(P.n_slices);
+  for (int64_t s = 0; s < P.n_slices; ++s) order[s] = (int32_t)s;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return P.widths[a] < P.widths[b]; });
+  P.bin_width.clear();
+  P.bin_ptr.assign(1, 0);
+  for (int64_t i = 0; i < P.n_slices; ++i) {
+    const int32_t w = P.widths[order[i]];
+    if (P.bin_width.empty() || P.bin_width.back() != w) {
+      if (!P.bin_width.empty()) P.bin_ptr.push_back(i);
+      P.bin_width.push_back(w);
+    }
+  }
+  P.bin_ptr.push_back(P.n_slices);
+  if (P.bin_width.empty()) P.bin_ptr.assign(1, 0);
+  OX_TRY(P.bin_slices.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_slices, 1)));
+  if (P.n_slices)
+    OX_HIP(hipMemcpyAsync(P.bin_slices.p, order.data(), sizeof(int32_t) * (size_t)P.n_slices, hipMemcpyHostToDevice, st));
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// slice widths, slice_ptr (and optionally adjacency depths, adj_ptr) from the row lengths
+int layout_slices(ox_pattern_store &P, const int64_t *start, DevBuf *adj_ptr, int64_t *npairs, hipStream_t st) {
+  P.n_slices = (P.n_rows + SLICE - 1) / SLICE;
+  const int64_t ns = P.n_slices;
+  DevBuf w64, d64, w32;
+  OX_TRY(w64.alloc(sizeof(int64_t) * (size_t)(ns + 1)));
+  OX_TRY(d64.alloc(sizeof(int64_t) * (size_t)(ns + 1)));
+  OX_TRY(w32.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
+  OX_HIP(hipMemsetAsync(w64.p, 0, w64.bytes, st));
+  OX_HIP(hipMemsetAsync(d64.p, 0, d64.bytes, st));
+  if (ns)
+    hipLaunchKernelGGL(k_slice_sizes, dim3(nblk(ns, 4)), dim3(256), 0, st, P.row_len.as<int32_t>(), start, P.n_rows, ns,
+                       w64.as<int64_t>(), adj_ptr ? d64.as<int64_t>() : nullptr, w32.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(P.slice_ptr.alloc(sizeof(int64_t) * (size_t)(ns + 1)));
+  OX_TRY(exclusive_scan_i64(w64.as<int64_t>(), P.slice_ptr.as<int64_t>(), (size_t)(ns + 1), st));
+  OX_HIP(hipMemcpy(&P.size, P.slice_ptr.as<int64_t>() + ns, sizeof(int64_t), hipMemcpyDeviceToHost));
+  P.widths.assign((size_t)ns, 0);
+  if (ns) OX_HIP(hipMemcpy(P.widths.data(), w32.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+  if (adj_ptr) {
+    OX_TRY(adj_ptr->alloc(sizeof(int64_t) * (size_t)(ns + 1)));
+    OX_TRY(exclusive_scan_i64(d64.as<int64_t>(), adj_ptr->as<int64_t>(), (size_t)(ns + 1), st));
+    OX_HIP(hipMemcpy(npairs, adj_ptr->as<int64_t>() + ns, sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  OX_TRY(reduce_sum_i32(P.row_len.as<int32_t>(), P.n_rows, &P.nnz, st));
+  OX_TRY(P.cols.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(P.size, 1)));
+  return 0;
+}
+
+int check_row_error(int *err_dev, const char *what) {
+  int e = 0;
+  OX_HIP(hipMemcpy(&e, err_dev, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == 1) OX_FAIL("%s: a dof touches so many cells that its row has more than %d candidate columns", what, ROW_CAP);
+  if (e == 2) OX_FAIL("%s: a row is longer than 255 entries (position bytes overflow)", what);
+  return 0;
+}
+
+// pairs (dof, cell*nd + k) grouped by dof, cells ascending: start [n+1], pair [nc*nd]
+int group_pairs(const int32_t *cell_dofs, int64_t nc, int nd, int64_t n, DevBuf &start, DevBuf &pair, hipStream_t st) {
+  const int64_t np = nc * nd;
+  if (np >= (int64_t)1 << 32) OX_FAIL("set-up: %lld (cell, dof) pairs exceed 2^32", (long long)np);
+  DevBuf k_in, k_out, v_in;
+  OX_TRY(k_in.alloc(sizeof(uint32_t) * (size_t)np));
+  OX_TRY(k_out.alloc(sizeof(uint32_t) * (size_t)np));
+  OX_TRY(v_in.alloc(sizeof(uint32_t) * (size_t)np));
+  OX_TRY(pair.alloc(sizeof(uint32_t) * (size_t)np));
+  hipLaunchKernelGGL(k_pair_keys, dim3(nblk(np)), dim3(256), 0, st, cell_dofs, np, k_in.as<uint32_t>(), v_in.as<uint32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(sort_pairs(k_in.as<uint32_t>(), k_out.as<uint32_t>(), v_in.as<uint32_t>(), pair.as<uint32_t>(), (size_t)np,
+                    bits_for((uint64_t)std::max<int64_t>(n - 1, 1)), st));
+  OX_TRY(start.alloc(sizeof(int64_t) * (size_t)(n + 1)));
+  OX_HIP(hipMemsetAsync(start.p, 0, start.bytes, st));
+  hipLaunchKernelGGL(k_group_starts, dim3(nblk(np)), dim3(256), 0, st, k_out.as<uint32_t>(), np, n, start.as<int64_t>());
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace
+
+// ================================== C ABI ===========================================================
+extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                              int on_device, int tile_bits, ox_mesh **out) {
+  if (!coords || !cells || !out) OX_FAIL("ox_mesh_create: null argument");
+  if (gdim != 2 && gdim != 3) OX_FAIL("ox_mesh_create: gdim=%d (triangles or tetrahedra)", gdim);
+  if (n_vertices < gdim + 1 || n_cells < 1) OX_FAIL("ox_mesh_create: empty mesh");
+  if (n_cells * 6 >= ((int64_t)1 << 31)) OX_FAIL("ox_mesh_create: %lld cells: cell-edge indices exceed 2^31", (long long)n_cells);
+  hipStream_t st = nullptr;
+  ox_mesh *M = new ox_mesh();
+  struct Guard {
+    ox_mesh *m;
+    ~Guard() { delete m; }
+  } guard{M};
+  M->gdim = gdim, M->nv = n_vertices, M->nc = n_cells;
+  const int nv = gdim + 1;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  OX_TRY(M->coords.alloc(sizeof(double) * (size_t)n_vertices * gdim));
+  OX_HIP(hipMemcpy(M->coords.p, coords, M->coords.bytes, kind));
+  DevBuf cells_in;
+  OX_TRY(cells_in.alloc(sizeof(int32_t) * (size_t)n_cells * nv));
+  OX_HIP(hipMemcpy(cells_in.p, cells, cells_in.bytes, kind));
+  // bounding box
+  {
+    const int nb = 512;
+    DevBuf part;
+    OX_TRY(part.alloc(sizeof(double) * 6 * nb));
+    hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, st, M->coords.as<double>(), n_vertices, gdim, part.as<double>());
+    OX_LAUNCH_CHECK();
+    std::vector<double> h(6 * nb);
+    OX_HIP(hipMemcpy(h.data(), part.p, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost));
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int b = 0; b < nb; ++b)
+      for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], h[b * 6 + k]), hi[k] = std::max(hi[k], h[b * 6 + 3 + k]);
+    for (int k = 0; k < 3; ++k) {
+      M->lo[k] = k < gdim ? lo[k] : 0.0;
+      M->span[k] = k < gdim ? std::max(hi[k] - lo[k], 1e-300) : 1.0;
+    }
+  }
+  // tiles of about 24 vertex lines a side; OX_TILE_BITS / the argument override
+  if (tile_bits < 0) {
+    const char *e = getenv("OX_TILE_BITS");
+    if (e) tile_bits = atoi(e);
+    else {
+      const double lines = std::max(std::pow((double)n_vertices, 1.0 / gdim), 1.0);
+      tile_bits = (int)std::min(6.0, std::max(0.0, std::nearbyint(std::log2(lines / 24.0))));
+    }
+  }
+  M->tile_bits = tile_bits;
+  const KeySpec K = key_spec(M, tile_bits);
+  M->key_bits = K.bits;
+  // kernel cell order: tiled order of the centroids (stable: ties keep the caller's order)
+  {
+    DevBuf k_in, k_out, v_in;
+    OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n_cells));
+    OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n_cells));
+    OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)n_cells));
+    OX_TRY(M->cell_perm.alloc(sizeof(int32_t) * (size_t)n_cells));
+    hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n_cells)), dim3(256), 0, st, M->coords.as<double>(), cells_in.as<int32_t>(),
+                       n_cells, K, k_in.as<uint64_t>(), v_in.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), M->cell_perm.as<int32_t>(),
+                      (size_t)n_cells, (K.d - 1) * K.tb + K.d * K.bits, st));
+  }
+  OX_TRY(M->cells.alloc(sizeof(int32_t) * (size_t)n_cells * nv));
+  hipLaunchKernelGGL(k_gather_cells, dim3(nblk(n_cells)), dim3(256), 0, st, cells_in.as<int32_t>(), M->cell_perm.as<int32_t>(),
+                     n_cells, nv, M->cells.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  const int gs = gdim == 2 ? 6 : 10;
+  OX_TRY(M->geom.alloc(sizeof(double) * (size_t)n_cells * gs));
+  hipLaunchKernelGGL(k_geometry, dim3(nblk(n_cells)), dim3(256), 0, st, M->coords.as<double>(), M->cells.as<int32_t>(), n_cells,
+                     gdim, M->geom.as<double>());
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  guard.m = nullptr;
+  *out = M;
+  return 0;
+}
+
+extern "C" int ox_mesh_destroy(ox_mesh *M) {
+  delete M;
+  return 0;
+}
+
+extern "C" int ox_mesh_view(const ox_mesh *M, ox_mesh_info *v) {
+  if (!M || !v) OX_FAIL("ox_mesh_view: null argument");
+  memset(v, 0, sizeof(*v));
+  v->gdim = M->gdim, v->tile_bits = M->tile_bits;
+  v->n_vertices = M->nv, v->n_cells = M->nc;
+  for (int k = 0; k < 3; ++k) v->lo[k] = M->lo[k], v->span[k] = M->span[k];
+  v->coords = M->coords.as<double>();
+  v->cells = M->cells.as<int32_t>();
+  v->cell_perm = M->cell_perm.as<int32_t>();
+  v->cells_struct.gdim = M->gdim;
+  v->cells_struct.n_cells = M->nc;
+  v->cells_struct.geom = M->geom.as<double>();
+  return 0;
+}
+
+extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_space **out) {
+  if (!M || !out) OX_FAIL("ox_space_create: null argument");
+  if (degree != 1 && degree != 2) OX_FAIL("ox_space_create: Lagrange degree %d (1 and 2 are built)", degree);
+  if (window < SLICE) window = 4096;
+  hipStream_t st = nullptr;
+  ox_space *V = new ox_space();
+  struct Guard {
+    ox_space *v;
+    ~Guard() { delete v; }
+  } guard{V};
+  const int d = M->gdim, nv = d + 1, ne = degree == 2 ? (d == 2 ? 3 : 6) : 0, nd = nv + ne;
+  const int64_t nc = M->nc;
+  V->mesh = M, V->degree = degree, V->nd = nd, V->window = window;
+  V->pw = nd <= 4 ? 4 : (nd <= 8 ? 8 : 16);
+  // ---- 1. initial dof ids: vertices, then edges numbered by ascending (min, max) vertex pair -------
+  DevBuf cd0;
+  OX_TRY(cd0.alloc(sizeof(int32_t) * (size_t)nc * nd));
+  {
+    DevBuf cell_edges;
+    if (degree == 2) {
+      const int64_t nk = nc * ne;
+      DevBuf k_in, k_out, v_in, v_out, head, excl;
+      OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)nk));
+      OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)nk));
+      OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)nk));
+      OX_TRY(v_out.alloc(sizeof(int32_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_edge_keys, dim3(nblk(nk)), dim3(256), 0, st, M->cells.as<int32_t>(), nc, d, M->nv, k_in.as<uint64_t>(),
+                         v_in.as<int32_t>());
+      OX_LAUNCH_CHECK();
+      OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nk,
+                        bits_for((uint64_t)M->nv * (uint64_t)M->nv), st));
+      k_in.release();
+      v_in.release();
+      OX_TRY(head.alloc(sizeof(int64_t) * (size_t)nk));
+      OX_TRY(excl.alloc(sizeof(int64_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_heads, dim3(nblk(nk)), dim3(256), 0, st, k_out.as<uint64_t>(), nk, head.as<int64_t>());
+      OX_LAUNCH_CHECK();
+      OX_TRY(exclusive_scan_i64(head.as<int64_t>(), excl.as<int64_t>(), (size_t)nk, st));
+      int64_t last[2];
+      OX_HIP(hipMemcpy(&last[0], excl.as<int64_t>() + nk - 1, sizeof(int64_t), hipMemcpyDeviceToHost));
+      OX_HIP(hipMemcpy(&last[1], head.as<int64_t>() + nk - 1, sizeof(int64_t), hipMemcpyDeviceToHost));
+      V->n_edges = last[0] + last[1];
+      OX_TRY(V->edge_keys.alloc(sizeof(uint64_t) * (size_t)V->n_edges));
+      OX_TRY(cell_edges.alloc(sizeof(int32_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(nk)), dim3(256), 0, st, k_out.as<uint64_t>(), v_out.as<int32_t>(),
+                         head.as<int64_t>(), excl.as<int64_t>(), nk, cell_edges.as<int32_t>(), V->edge_keys.as<uint64_t>());
+      OX_LAUNCH_CHECK();
+      OX_HIP(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(k_cd0, dim3(nblk(nc)), dim3(256), 0, st, M->cells.as<int32_t>(), cell_edges.as<int32_t>(), nc, d, degree,
+                       M->nv, cd0.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_HIP(hipStreamSynchronize(st));
+  }
+  const int64_t n = M->nv + V->n_edges;
+  if (n >= ((int64_t)1 << 31) - 64) OX_FAIL("ox_space_create: %lld dofs exceed int32", (long long)n);
+  V->n = n;
+  // ---- 2. dof coordinates, tiled spatial order ------------------------------------------------------
+  DevBuf xL, rank1;
+  OX_TRY(xL.alloc(sizeof(double) * (size_t)n * d));
+  hipLaunchKernelGGL(k_dof_coords, dim3(nblk(n)), dim3(256), 0, st, M->coords.as<double>(), V->edge_keys.as<uint64_t>(), M->nv, n,
+                     d, xL.as<double>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
+  {
+    const KeySpec K = key_spec(M, M->tile_bits);
+    DevBuf k_in, k_out, v_in, perm1;
+    OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
+    OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));
+    OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)n));
+    OX_TRY(perm1.alloc(sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_point_keys, dim3(nblk(n)), dim3(256), 0, st, xL.as<double>(), n, K, k_in.as<uint64_t>(), v_in.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), perm1.as<int32_t>(), (size_t)n,
+                      (K.d - 1) * K.tb + K.d * K.bits, st));
+    hipLaunchKernelGGL(k_invert, dim3(nblk(n)), dim3(256), 0, st, perm1.as<int32_t>(), n, rank1.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_HIP(hipStreamSynchronize(st));
+  }
+  // ---- 3. row lengths in that order (they do not depend on the numbering) ---------------------------
+  DevBuf err;
+  OX_TRY(err.alloc(sizeof(int)));
+  OX_HIP(hipMemset(err.p, 0, sizeof(int)));
+  DevBuf len1;
+  OX_TRY(len1.alloc(sizeof(int32_t) * (size_t)n));
+  {
+    DevBuf cd1, start1, pair1;
+    OX_TRY(cd1.alloc(sizeof(int32_t) * (size_t)nc * nd));
+    hipLaunchKernelGGL(k_relabel, dim3(nblk(nc * nd)), dim3(256), 0, st, cd0.as<int32_t>(), rank1.as<int32_t>(), nc * nd,
+                       cd1.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_TRY(group_pairs(cd1.as<int32_t>(), nc, nd, n, start1, pair1, st));
+    RowArgs A{};
+    A.n_rows = A.n_cols = n;
+    A.start = start1.as<int64_t>(), A.pair = pair1.as<uint32_t>();
+    A.nd_r = A.nd_c = nd;
+    A.col_dofs = cd1.as<int32_t>();
+    A.len = len1.as<int32_t>();
+    A.err = err.as<int>();
+    hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(n)), dim3(256), 0, st, A);
+    OX_LAUNCH_CHECK();
+    OX_HIP(hipStreamSynchronize(st));
+    OX_TRY(check_row_error(err.as<int>(), "ox_space_create"));
+  }
+  // ---- 4. inside windows of `window` rows: stably by decreasing row length --------------------------
+  int32_t lmax = 0;
+  OX_TRY(reduce_max_i32(len1.as<int32_t>(), n, &lmax, st));
+  DevBuf perm2, rank2;
+  OX_TRY(perm2.alloc(sizeof(int32_t) * (size_t)n));
+  OX_TRY(rank2.alloc(sizeof(int32_t) * (size_t)n));
+  {
+    DevBuf k_in, k_out, v_in;
+    OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
+    OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));
+    OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_window_keys, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), n, window, (int)lmax, k_in.as<uint64_t>(),
+                       v_in.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    const uint64_t kmax = (uint64_t)((n + window - 1) / window + 1) * (uint64_t)(lmax + 1);
+    OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), perm2.as<int32_t>(), (size_t)n, bits_for(kmax), st));
+    hipLaunchKernelGGL(k_invert, dim3(nblk(n)), dim3(256), 0, st, perm2.as<int32_t>(), n, rank2.as<int32_t>());
+    OX_LAUNCH_CHECK();
+  }
+  OX_TRY(V->rank_initial.alloc(sizeof(int32_t) * (size_t)n));
+  hipLaunchKernelGGL(k_compose, dim3(nblk(n)), dim3(256), 0, st, rank1.as<int32_t>(), rank2.as<int32_t>(), n,
+                     V->rank_initial.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(V->cell_dofs.alloc(sizeof(int32_t) * (size_t)nc * nd));
+  hipLaunchKernelGGL(k_relabel, dim3(nblk(nc * nd)), dim3(256), 0, st, cd0.as<int32_t>(), V->rank_initial.as<int32_t>(), nc * nd,
+                     V->cell_dofs.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(V->x.alloc(sizeof(double) * (size_t)n * d));
+  hipLaunchKernelGGL(k_permute_points, dim3(nblk(n)), dim3(256), 0, st, xL.as<double>(), V->rank_initial.as<int32_t>(), n, d,
+                     V->x.as<double>());
+  OX_LAUNCH_CHECK();
+  ox_pattern_store &P = V->P;
+  P.n_rows = P.n_cols = n;
+  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)n));
+  hipLaunchKernelGGL(k_gather_i32, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), perm2.as<int32_t>(), n, P.row_len.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  cd0.release(), xL.release(), rank1.release(), rank2.release(), perm2.release(), len1.release();
+  // ---- 5. final adjacency, SELL layout, columns and position bytes ------------------------------------
+  OX_TRY(group_pairs(V->cell_dofs.as<int32_t>(), nc, nd, n, V->start, V->pair, st));
+  OX_TRY(layout_slices(P, V->start.as<int64_t>(), &V->adj_ptr, &V->npairs, st));
+  OX_TRY(V->adj_cell.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(V->npairs, 1)));
+  OX_TRY(V->adj_loc.alloc((size_t)std::max<int64_t>(V->npairs, 1)));
+  OX_TRY(V->adj_pos.alloc((size_t)std::max<int64_t>(V->npairs, 1) * V->pw));
+  {
+    RowArgs A{};
+    A.n_rows = A.n_cols = n;
+    A.start = V->start.as<int64_t>(), A.pair = V->pair.as<uint32_t>();
+    A.nd_r = A.nd_c = nd;
+    A.col_dofs = V->cell_dofs.as<int32_t>();
+    A.slice_ptr = P.slice_ptr.as<int64_t>(), A.cols = P.cols.as<int32_t>();
+    A.adj_ptr = V->adj_ptr.as<int64_t>(), A.adj_cell = V->adj_cell.as<int32_t>();
+    A.adj_loc = V->adj_loc.as<uint8_t>(), A.adj_pos = V->adj_pos.as<uint8_t>();
+    A.pw = V->pw;
+    A.err = err.as<int>();
+    hipLaunchKernelGGL(k_rows<1>, dim3(row_grid(P.n_slices * SLICE)), dim3(256), 0, st, A);
+    OX_LAUNCH_CHECK();
+    OX_HIP(hipStreamSynchronize(st));
+    OX_TRY(check_row_error(err.as<int>(), "ox_space_create"));
+  }
+  OX_TRY(finish_pattern(P, st));
+  guard.v = nullptr;
+  *out = V;
+  return 0;
+}
+
+extern "C" int ox_space_destroy(ox_space *V) {
+  delete V;
+  return 0;
+}
+
+static void fill_pattern_view(const ox_pattern_store &P, ox_pattern_info *v) {
+  memset(v, 0, sizeof(*v));
+  v->sell.n_rows = P.n_rows, v->sell.n_cols = P.n_cols, v->sell.n_slices = (int32_t)P.n_slices;
+  v->sell.slice_ptr = P.slice_ptr.as<int64_t>(), v->sell.cols = P.cols.as<int32_t>();
+  v->sell.cols16 = P.cols16.as<uint16_t>(), v->sell.cbase = P.cbase.as<int32_t>();
+  v->size = P.size, v->nnz = P.nnz, v->n_compressed = P.n16;
+  v->row_len = P.row_len.as<int32_t>();
+  v->n_bins = (int32_t)P.bin_width.size();
+  v->bin_ptr_host = P.bin_ptr.data(), v->bin_width_host = P.bin_width.data();
+  v->bin_slices = P.bin_slices.as<int32_t>();
+  v->widths_host = P.widths.data();
+}
+
+extern "C" int ox_space_view(const ox_space *V, ox_space_info *v) {
+  if (!V || !v) OX_FAIL("ox_space_view: null argument");
+  memset(v, 0, sizeof(*v));
+  v->degree = V->degree, v->nd = V->nd, v->pw = V->pw, v->gdim = V->mesh->gdim;
+  v->n_dofs = V->n, v->n_edges = V->n_edges, v->n_pairs = V->npairs;
+  v->cell_dofs = V->cell_dofs.as<int32_t>();
+  v->x = V->x.as<double>();
+  v->rank_initial = V->rank_initial.as<int32_t>();
+  v->edge_keys = V->edge_keys.as<uint64_t>();
+  v->adj.n_slices = (int32_t)V->P.n_slices, v->adj.nd = V->nd;
+  v->adj.adj_ptr = V->adj_ptr.as<int64_t>(), v->adj.adj_cell = V->adj_cell.as<int32_t>(), v->adj.adj_loc = V->adj_loc.as<uint8_t>();
+  v->adj_pos = V->adj_pos.as<uint8_t>();
+  v->pair_start = V->start.as<int64_t>();
+  fill_pattern_view(V->P, &v->pattern);
+  return 0;
+}
+
+// Rectangular operator (rows = dofs of R, columns = dofs of C, same mesh): the reference's
+// create_matrix of the mixed forms (fracstep.py:315,336,352).
+extern "C" int ox_rect_create(const ox_space *R, const ox_space *C, ox_rect **out) {
+  if (!R || !C || !out) OX_FAIL("ox_rect_create: null argument");
+  if (R->mesh != C->mesh) OX_FAIL("ox_rect_create: the two spaces live on different meshes");
+  hipStream_t st = nullptr;
+  ox_rect *Q = new ox_rect();
+  struct Guard {
+    ox_rect *q;
+    ~Guard() { delete q; }
+  } guard{Q};
+  Q->R = R, Q->C = C;
+  Q->pw = C->nd <= 4 ? 4 : (C->nd <= 8 ? 8 : 16);
+  ox_pattern_store &P = Q->P;
+  P.n_rows = R->n, P.n_cols = C->n;
+  DevBuf err;
+  OX_TRY(err.alloc(sizeof(int)));
+  OX_HIP(hipMemset(err.p, 0, sizeof(int)));
+  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)R->n));
+  RowArgs A{};
+  A.n_rows = R->n, A.n_cols = C->n;
+  A.start = R->start.as<int64_t>(), A.pair = R->pair.as<uint32_t>();
+  A.nd_r = R->nd, A.nd_c = C->nd;
+  A.col_dofs = C->cell_dofs.as<int32_t>();
+  A.len = P.row_len.as<int32_t>();
+  A.err = err.as<int>();
+  hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(R->n)), dim3(256), 0, st, A);
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  OX_TRY(check_row_error(err.as<int>(), "ox_rect_create"));
+  OX_TRY(layout_slices(P, nullptr, nullptr, nullptr, st));
+  OX_TRY(Q->pos.alloc((size_t)std::max<int64_t>(R->npairs, 1) * Q->pw));
+  // the pair bookkeeping (cell, local index) is the row space's: written into scratch here
+  DevBuf scratch_cell;
+  OX_TRY(scratch_cell.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(R->npairs, 1)));
+  A.slice_ptr = P.slice_ptr.as<int64_t>(), A.cols = P.cols.as<int32_t>();
+  A.adj_ptr = R->adj_ptr.as<int64_t>(), A.adj_cell = scratch_cell.as<int32_t>();
+  A.adj_loc = nullptr, A.adj_pos = Q->pos.as<uint8_t>();
+  A.pw = Q->pw;
+  hipLaunchKernelGGL(k_rows<1>, dim3(row_grid(P.n_slices * SLICE)), dim3(256), 0, st, A);
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  OX_TRY(check_row_error(err.as<int>(), "ox_rect_create"));
+  OX_TRY(finish_pattern(P, st));
+  guard.q = nullptr;
+  *out = Q;
+  return 0;
+}
+
+extern "C" int ox_rect_destroy(ox_rect *Q) {
+  delete Q;
+  return 0;
+}
+
+extern "C" int ox_rect_view(const ox_rect *Q, ox_rect_info *v) {
+  if (!Q || !v) OX_FAIL("ox_rect_view: null argument");
+  memset(v, 0, sizeof(*v));
+  v->pw = Q->pw;
+  v->pos = Q->pos.as<uint8_t>();
+  fill_pattern_view(Q->P, &v->pattern);
+  return 0;
+}
+
+// ---- value dictionary ("1-byte value codes") ---------------------------------------
+namespace {
+constexpr int HSLOTS = 4096;
+constexpr unsigned long long HEMPTY = 0xffffffffffffffffull;
+
+__global__ __launch_bounds__(256) void k_dict_collect(const unsigned long long *__restrict__ bits, int64_t n,
+                                                      unsigned long long *table, int *count) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (*reinterpret_cast<volatile int *>(count) > 256) return;  // hopeless: more than 256 distinct values
+    const unsigned long long v = bits[i];
+    unsigned h = (unsigned)((v * 0x9e3779b97f4a7c15ull) >> 52) & (HSLOTS - 1);
+    for (int probe = 0; probe < HSLOTS; ++probe) {
+      const unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == v) break;
+      if (cur == HEMPTY) {
+        const unsigned long long old = atomicCAS(&table[h], HEMPTY, v);
+        if (old == HEMPTY) {
+          atomicAdd(count, 1);
+          break;
+        }
+        if (old == v) break;
+      }
+      h = (h + 1) & (HSLOTS - 1);
+    }
+  }
+}
+
+template <int NCOMP>
+__global__ __launch_bounds__(256) void k_dict_encode(const long long *__restrict__ bits, int64_t n_slots,
+                                                     const long long *__restrict__ dict, int nd, void *__restrict__ codes) {
+  __shared__ long long d_s[256];
+  if ((int)threadIdx.x < nd) d_s[threadIdx.x] = dict[threadIdx.x];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_slots; i += stride) {
+    unsigned packed = 0;
+    for (int c = 0; c < NCOMP; ++c) {
+      const long long v = bits[i * NCOMP + c];
+      int lo = 0, hi = nd - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (d_s[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      packed |= (unsigned)lo << (8 * c);
+    }
+    if (NCOMP == 1) static_cast<uint8_t *>(codes)[i] = (uint8_t)packed;
+    else static_cast<uint32_t *>(codes)[i] = packed;
+  }
+}
+}  // namespace
+
+// vals: [n_slots][ncomp] doubles.  If they take at most 256 distinct bit patterns: dict (ascending as
+// signed 64-bit integers, n_dict of them) and codes (ncomp == 1: one byte per slot; ncomp 2..3: one
+// uint32 per slot with byte c = the code of component c); otherwise *n_dict = 0 and nothing is written.
+extern "C" int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *codes, double *dict, int *n_dict,
+                                   void *stream) {
+  if (!vals || !codes || !dict || !n_dict) OX_FAIL("ox_value_dictionary: null argument");
+  if (ncomp < 1 || ncomp > 3) OX_FAIL("ox_value_dictionary: ncomp=%d", ncomp);
+  hipStream_t st = ox_stream(stream);
+  *n_dict = 0;
+  const int64_t n = n_slots * ncomp;
+  if (n <= 0) return 0;
+  DevBuf table, count;
+  OX_TRY(table.alloc(sizeof(unsigned long long) * HSLOTS));
+  OX_TRY(count.alloc(sizeof(int)));
+  OX_HIP(hipMemsetAsync(table.p, 0xff, table.bytes, st));
+  OX_HIP(hipMemsetAsync(count.p, 0, sizeof(int), st));
+  const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_dict_collect, dim3(nb), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(vals), n,
+                     table.as<unsigned long long>(), count.as<int>());
+  OX_LAUNCH_CHECK();
+  int cnt = 0;
+  std::vector<unsigned long long> h(HSLOTS);
+  OX_HIP(hipMemcpyAsync(&cnt, count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipMemcpyAsync(h.data(), table.p, table.bytes, hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  if (cnt > 256) return 0;
+  std::vector<long long> d;
+  for (auto v : h)
+    if (v != HEMPTY) d.push_back((long long)v);
+  if ((int)d.size() != cnt || d.empty()) return 0;  // (a value with the all-ones pattern: decline)
+  std::sort(d.begin(), d.end());
+  OX_HIP(hipMemcpyAsync(dict, d.data(), sizeof(long long) * d.size(), hipMemcpyHostToDevice, st));
+  const unsigned nb2 = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 8192);
+  const long long *bits = reinterpret_cast<const long long *>(vals);
+  const long long *dd = reinterpret_cast<const long long *>(dict);
+  if (ncomp == 1) hipLaunchKernelGGL(k_dict_encode<1>, dim3(nb2), dim3(256), 0, st, bits, n_slots, dd, cnt, codes);
+  else if (ncomp == 2) hipLaunchKernelGGL(k_dict_encode<2>, dim3(nb2), dim3(256), 0, st, bits, n_slots, dd, cnt, codes);
+  else hipLaunchKernelGGL(k_dict_encode<3>, dim3(nb2), dim3(256), 0, st, bits, n_slots, dd, cnt, codes);
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));
+  *n_dict = cnt;
+  return 0;
+}
+
+// ---- plain device memory for callers without a device array library (numpy + ctypes) ----------------
+extern "C" int ox_malloc(size_t bytes, void **out) {
+  if (!out) OX_FAIL("ox_malloc: null argument");
+  *out = nullptr;
+  if (bytes == 0) return 0;
+  OX_HIP(hipMalloc(out, bytes));
+  return 0;
+}
+extern "C" int ox_free(void *p) {
+  if (p) OX_HIP(hipFree(p));
+  return 0;
+}
+extern "C" int ox_memset(void *p, int value, size_t bytes, void *stream) {
+  if (bytes) OX_HIP(hipMemsetAsync(p, value, bytes, ox_stream(stream)));
+  return 0;
+}
+extern "C" int ox_synchronize(void *stream) {
+  OX_HIP(hipStreamSynchronize(ox_stream(stream)));
+  return 0;
+}

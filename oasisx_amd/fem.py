@@ -101,7 +101,7 @@ def cell_geometry(mesh: Mesh, cell_ids=None, chunk: int = 1 << 23) -> torch.Tens
 class SellPattern:
     """SELL-64 sparsity pattern shared by every matrix on one (row space, col space)."""
 
-    def __init__(self, n_rows, n_cols, slice_ptr, cols, row_len, widths):
+    def __init__(self, n_rows, n_cols, slice_ptr, cols, row_len, widths, nnz=None):
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.slice_ptr = slice_ptr  # int64 [n_slices+1] device
         self.cols = cols  # int32 device
@@ -109,7 +109,7 @@ class SellPattern:
         self.widths = widths  # int32 [n_slices] host numpy
         self.n_slices = int(widths.shape[0])
         self.size = int(cols.shape[0])
-        self.nnz = int(row_len.sum().item())
+        self.nnz = int(row_len.sum().item()) if nnz is None else int(nnz)
         self.device = cols.device
         self.dist = None  # ox_dist* (halo plan) of the column space, mesh-partitioned runs
         self.cols16 = self.cbase = None  # 16-bit column stream, built by struct() on the GPU
@@ -234,7 +234,13 @@ class FunctionSpace:
         self.element = _Element(degree, mesh.gdim)
         self.num_sub_spaces = 0
         self.part = part
+        self.native = None
         dev = mesh.device
+        if part is None and dev.type == "cuda" and _os.environ.get("OX_SETUP", "native") != "torch":
+            # the whole set-up runs inside liboasisx_hip.so (csrc/ox_setup.hip, behind the C ABI of
+            # include/oasisx_hip.h); this class only wraps the arrays the library owns
+            self._init_native(window)
+            return
         d = mesh.gdim
         nverts = mesh.num_vertices
         rank = 0 if part is None else part.rank
@@ -383,6 +389,37 @@ class FunctionSpace:
         self.dist = None
         if part is not None:
             self.halo = self._build_halo(part, ghost_owner, cd0g)
+
+    def _init_native(self, window: int):
+        from . import native as N
+
+        mesh, dev = self.mesh, self.mesh.device
+        ns = N.NativeSpace(mesh, self.degree, window)
+        self.native = ns
+        v, own = ns.info, ns.handle
+        nc, d = mesh.num_cells, mesh.gdim
+        n = int(v.n_dofs)
+        self.nd = int(v.nd)
+        self.local_cells = ns.nmesh.cell_perm.to(torch.int64)
+        self.num_dofs_global = self.n_owned = self.n_local = self.num_dofs = n
+        self._gl = None
+        self._edge_keys = N.dev_tensor(v.edge_keys, (int(v.n_edges),), torch.int64, own, dev) if self.degree == 2 else None
+        self._rank_initial = N.dev_tensor(v.rank_initial, (n,), torch.int32, own, dev)
+        self.cell_dofs = N.dev_tensor(v.cell_dofs, (nc, self.nd), torch.int32, own, dev)
+        self.x = N.dev_tensor(v.x, (n, d), torch.float64, own, dev)
+        self._x3 = None
+        self.dofmap = _DofMap(self)
+        self.pattern = N.pattern_from_info(v.pattern, own, dev, SellPattern)
+        npairs, pw = int(v.n_pairs), int(v.pw)
+        nsl = int(v.adj.n_slices)
+        self.adj = AdjTable(nsl, self.nd, N.dev_tensor(v.adj.adj_ptr, (nsl + 1,), torch.int64, own, dev),
+                            N.dev_tensor(v.adj.adj_cell, (npairs,), torch.int32, own, dev),
+                            N.dev_tensor(v.adj.adj_loc, (npairs,), torch.uint8, own, dev),
+                            N.dev_tensor(v.adj_pos, (npairs, pw), torch.uint8, own, dev), pw)
+        start = N.dev_tensor(v.pair_start, (n + 1,), torch.int64, own, dev)
+        self.adj_count = start[1:] - start[:-1]
+        self.halo = None
+        self.dist = None
 
     # ---------------------------------------------------------------------------------
     def global_to_local(self, gids: torch.Tensor) -> torch.Tensor:
@@ -627,6 +664,15 @@ def build_rect_pattern(R: "FunctionSpace", Cs: "FunctionSpace", block_pairs: int
     ``create_matrix`` of the mixed forms)."""
     dev = R.mesh.device
     assert R.mesh is Cs.mesh and R.local_cells.shape == Cs.local_cells.shape
+    if getattr(R, "native", None) is not None and getattr(Cs, "native", None) is not None:
+        from . import native as N
+
+        nr = N.NativeRect(R.native, Cs.native)
+        pattern = N.pattern_from_info(nr.info.pattern, nr.handle, dev, SellPattern)
+        pw = int(nr.info.pw)
+        pos = N.dev_tensor(nr.info.pos, (int(R.native.info.n_pairs), pw), torch.uint8, nr.handle, dev)
+        pattern.dist = Cs.dist
+        return pattern, pos, pw
     n_rows, n_cols, nd_r, nd_c = R.n_owned, Cs.n_local, R.nd, Cs.nd
     dof = R.cell_dofs.reshape(-1).to(torch.int64)
     order = torch.argsort(dof, stable=True)

@@ -198,7 +198,10 @@ class FractionalStep_AB_CN:
         compiled here -- the element kernels are the templated HIP kernels of ox_assemble.hip)."""
         mesh = self._mesh
         Vi, Q = self._Vi[0][0], self._Q
-        self._geom = cell_geometry(mesh, Vi.local_cells)
+        if getattr(Vi, "native", None) is not None:  # the library's own geometry (kernel cell order)
+            self._geom = Vi.native.nmesh.geom
+        else:
+            self._geom = cell_geometry(mesh, Vi.local_cells)
         self._cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
         self._adj_u = Vi.adj.struct()
         self._adj_q = Q.adj.struct()

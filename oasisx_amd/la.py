@@ -45,20 +45,17 @@ class SellMatrix:
         P = self.pattern
         if P.device.type != "cuda" or P.cols16 is None or P.size == 0:
             return False
-        bits = self.vals.view(torch.int64)
-        u = None
-        for a in range(0, P.size, block):
-            ub = torch.unique(bits[a:a + block])
-            u = ub if u is None else torch.unique(torch.cat([u, ub]))
-            if u.numel() > 256:
-                return False
         code = torch.empty(P.size, dtype=torch.uint8, device=P.device)
-        for a in range(0, P.size, block):
-            code[a:a + block] = torch.searchsorted(u, bits[a:a + block]).to(torch.uint8)
-        self.vcode, self.vdict = code, u.view(torch.float64).contiguous()
+        vdict = torch.zeros(256, dtype=torch.float64, device=P.device)
+        nd = C.c_int(0)
+        _lib.check(_lib.load().ox_value_dictionary(_lib.ptr(self.vals), P.size, 1, _lib.ptr(code), _lib.ptr(vdict),
+                                                   C.byref(nd), _lib.current_stream()), "ox_value_dictionary")
+        if nd.value == 0:
+            return False
+        self.vcode, self.vdict = code, vdict[: nd.value]
         self._vc_version = self.version
         self._struct.vcode, self._struct.vdict = self.vcode.data_ptr(), self.vdict.data_ptr()
-        self._struct.n_dict = int(u.numel())
+        self._struct.n_dict = int(nd.value)
         return True
 
     def getSize(self):
@@ -109,22 +106,15 @@ class MultiSellMatrix:
         full = P.struct(self.vals)  # builds / fetches the pattern's 16-bit column stream
         if P.cols16 is None:
             return False
-        bits = self.vals.view(torch.int64)
-        u = None
-        for a in range(0, bits.numel(), block):
-            ub = torch.unique(bits[a:a + block])
-            u = ub if u is None else torch.unique(torch.cat([u, ub]))
-            if u.numel() > 256:
-                return False
         code = torch.zeros(P.size, dtype=torch.int32, device=P.device)
-        bv = bits.reshape(P.size, self.gdim)
-        rows = max(1, block // self.gdim)
-        for a in range(0, P.size, rows):
-            c = torch.searchsorted(u, bv[a:a + rows].contiguous()).to(torch.int32)
-            for d in range(self.gdim):
-                code[a:a + rows] |= c[:, d] << (8 * d)
-        self.vcode, self.vdict = code, u.view(torch.float64).contiguous()
-        full.vcode, full.vdict, full.n_dict = self.vcode.data_ptr(), self.vdict.data_ptr(), int(u.numel())
+        vdict = torch.zeros(256, dtype=torch.float64, device=P.device)
+        nd = C.c_int(0)
+        _lib.check(_lib.load().ox_value_dictionary(_lib.ptr(self.vals), P.size, self.gdim, _lib.ptr(code), _lib.ptr(vdict),
+                                                   C.byref(nd), _lib.current_stream()), "ox_value_dictionary")
+        if nd.value == 0:
+            return False
+        self.vcode, self.vdict = code, vdict[: nd.value]
+        full.vcode, full.vdict, full.n_dict = self.vcode.data_ptr(), self.vdict.data_ptr(), int(nd.value)
         self._plain = self._struct
         self._struct = full
         return True

@@ -1,0 +1,119 @@
+"""ctypes views of the library's set-up objects (``ox_mesh`` / ``ox_space`` / ``ox_rect``,
+include/oasisx_hip.h): on the GPU the mesh -> dof numbering -> SELL-64 pattern -> adjacency pipeline
+runs inside ``liboasisx_hip.so`` (csrc/ox_setup.hip); the arrays it owns are wrapped as torch tensors
+WITHOUT copying so the rest of the Python host (boundary conditions, tests, diagnostics) reads them
+as before.  The torch implementation in fem.py remains for CPU-only hosts (host-logic tests) and for
+mesh-partitioned spaces."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _DevArray:
+    """Borrowed device memory exposed through __cuda_array_interface__; keeps its owner alive."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+_TYPES = {torch.float64: "<f8", torch.int64: "<i8", torch.int32: "<i4", torch.int16: "<i2", torch.uint8: "|u1"}
+
+
+def dev_tensor(ptr, shape, dtype, owner, device) -> torch.Tensor:
+    n = int(np.prod(shape)) if len(shape) else 1
+    if n == 0 or not ptr:
+        return torch.zeros(tuple(shape), dtype=dtype, device=device)
+    return torch.as_tensor(_DevArray(ptr, shape, _TYPES[dtype], owner), device=device)
+
+
+def host_array(ptr, n, ctype, dtype) -> np.ndarray:
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(int(n),)).astype(dtype, copy=True)
+
+
+class _Handle:
+    def __init__(self, ptr, destroy):
+        self.ptr, self._destroy = ptr, destroy
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._destroy(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+class NativeMesh:
+    """``ox_mesh`` of a :class:`oasisx_amd.mesh.Mesh` (kernel cell order, geometry); cached on the mesh."""
+
+    def __init__(self, mesh, tile_bits: int = -1):
+        lib = _lib.load()
+        out = C.c_void_p()
+        cells32 = mesh.cells.to(torch.int32).contiguous()
+        _lib.check(lib.ox_mesh_create(_lib.ptr(mesh.coords), mesh.num_vertices, _lib.ptr(cells32), mesh.num_cells,
+                                      mesh.gdim, 1, int(tile_bits), C.byref(out)), "ox_mesh_create")
+        self.handle = _Handle(out, lib.ox_mesh_destroy)
+        v = _lib.ox_mesh_info()
+        _lib.check(lib.ox_mesh_view(out, C.byref(v)), "ox_mesh_view")
+        self.info = v
+        dev = mesh.device
+        gs = 6 if mesh.gdim == 2 else 10
+        self.cell_perm = dev_tensor(v.cell_perm, (mesh.num_cells,), torch.int32, self.handle, dev)
+        self.geom = dev_tensor(v.cells_struct.geom, (mesh.num_cells, gs), torch.float64, self.handle, dev)
+        self.tile_bits = int(v.tile_bits)
+
+    @staticmethod
+    def of(mesh):
+        nm = getattr(mesh, "_native", None)
+        if nm is None:
+            nm = mesh._native = NativeMesh(mesh)
+        return nm
+
+
+def pattern_from_info(P, owner, device, SellPattern):
+    """fem.SellPattern over the library-owned arrays of an ``ox_pattern_info``."""
+    ns = int(P.sell.n_slices)
+    slice_ptr = dev_tensor(P.sell.slice_ptr, (ns + 1,), torch.int64, owner, device)
+    cols = dev_tensor(P.sell.cols, (int(P.size),), torch.int32, owner, device)
+    row_len = dev_tensor(P.row_len, (int(P.sell.n_rows),), torch.int32, owner, device)
+    widths = host_array(P.widths_host, ns, C.c_int32, np.int32)
+    pat = SellPattern(int(P.sell.n_rows), int(P.sell.n_cols), slice_ptr, cols, row_len, widths, nnz=int(P.nnz))
+    if P.size > 0 and P.sell.cols16:
+        pat.cols16 = dev_tensor(P.sell.cols16, (int(P.size),), torch.int16, owner, device)
+        pat.cbase = dev_tensor(P.sell.cbase, (2 * (int(P.size) // 128),), torch.int32, owner, device)
+        pat.frac16 = int(P.n_compressed) / int(P.size)
+    return pat
+
+
+class NativeSpace:
+    def __init__(self, mesh, degree: int, window: int):
+        lib = _lib.load()
+        self.nmesh = NativeMesh.of(mesh)
+        out = C.c_void_p()
+        _lib.check(lib.ox_space_create(self.nmesh.handle.ptr, int(degree), int(window), C.byref(out)), "ox_space_create")
+        self.handle = _Handle(out, lib.ox_space_destroy)
+        self.handle._mesh = self.nmesh  # the space reads the mesh object: keep it alive
+        v = _lib.ox_space_info()
+        _lib.check(lib.ox_space_view(out, C.byref(v)), "ox_space_view")
+        self.info = v
+
+
+class NativeRect:
+    def __init__(self, R: NativeSpace, Cs: NativeSpace):
+        lib = _lib.load()
+        out = C.c_void_p()
+        _lib.check(lib.ox_rect_create(R.handle.ptr, Cs.handle.ptr, C.byref(out)), "ox_rect_create")
+        self.handle = _Handle(out, lib.ox_rect_destroy)
+        self.handle._spaces = (R, Cs)
+        v = _lib.ox_rect_info()
+        _lib.check(lib.ox_rect_view(out, C.byref(v)), "ox_rect_view")
+        self.info = v

@@ -1,0 +1,154 @@
+"""GPU: the set-up the library runs behind the C ABI (csrc/ox_setup.hip: ox_mesh_create,
+ox_space_create, ox_rect_create, ox_value_dictionary) against the torch implementation of the same
+specification (fem.py, OX_SETUP=torch; the one CPU-only hosts and partitioned spaces use).
+Both must produce a valid SELL-64 space; where ties in the spatial keys are broken the same way
+(they are, on these meshes) the arrays agree element by element."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _spaces(mesh, deg, window):
+    from oasisx_amd import fem
+
+    os.environ["OX_SETUP"] = "torch"
+    try:
+        Vt = fem.FunctionSpace(mesh, deg, window=window)
+    finally:
+        os.environ.pop("OX_SETUP")
+    Vn = fem.FunctionSpace(mesh, deg, window=window)
+    assert Vt.native is None and Vn.native is not None
+    return Vt, Vn
+
+
+def _mesh(kind, N):
+    from oasisx_amd import mesh as M
+
+    if kind == "rect":
+        return M.create_rectangle(None, [[-1.0, -1.0], [1.0, 1.0]], [N, N + 3])
+    if kind == "box":
+        return M.create_box(None, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N + 1, N + 2])
+    # jittered, cell-permuted, orientation-flipped box: nothing structured left but the topology
+    m = M.create_box(None, [[0.0, 0.0, 0.0], [1.0, 1.3, 0.7]], [N, N, N], device="cpu")
+    g = torch.Generator().manual_seed(3)
+    x = m.coords.clone()
+    inner = ((x > 1e-9) & (x < torch.tensor([1.0, 1.3, 0.7]) - 1e-9)).all(dim=1)
+    x[inner] += (torch.rand(int(inner.sum()), 3, generator=g, dtype=torch.float64) - 0.5) * 0.3 / N
+    cells = m.cells[torch.randperm(m.num_cells, generator=g)]
+    flip = torch.rand(cells.shape[0], generator=g) < 0.5
+    cells[flip] = cells[flip][:, [1, 0, 2, 3]]
+    return M.from_arrays(x.numpy(), cells.numpy())
+
+
+@pytest.mark.parametrize("kind,N,deg,window", [("rect", 9, 1, 128), ("rect", 12, 2, 256), ("box", 5, 1, 64),
+                                                ("box", 6, 2, 4096), ("jitter", 5, 2, 512)])
+def test_native_space_is_valid_and_matches_the_torch_setup(hip, kind, N, deg, window):
+    mesh = _mesh(kind, N)
+    Vt, Vn = _spaces(mesh, deg, window)
+    n, nc, nd = Vn.num_dofs, mesh.num_cells, Vn.nd
+    assert n == Vt.num_dofs and Vn.pattern.nnz == Vt.pattern.nnz
+    # a valid numbering: a permutation; every cell keeps its vertices / edge midpoints
+    assert sorted(Vn._rank_initial.cpu().tolist()) == list(range(n))
+    cd = Vn.cell_dofs.cpu().numpy()
+    x = Vn.x.cpu().numpy()
+    cells_k = mesh.cells[Vn.local_cells].cpu().numpy()
+    xc = mesh.coords.cpu().numpy()
+    assert np.abs(x[cd[:, : mesh.gdim + 1]] - xc[cells_k]).max() == 0.0
+    # SELL layout invariants
+    P = Vn.pattern
+    rl = P.row_len.cpu().numpy()
+    sp = P.slice_ptr.cpu().numpy()
+    assert (np.diff(sp) == P.widths.astype(np.int64) * 64).all() and sp[-1] == P.size
+    for s in range(P.n_slices):
+        seg = rl[s * 64:(s + 1) * 64]
+        assert P.widths[s] >= seg.max() and P.widths[s] % 2 == 0
+    # rows sorted by decreasing length inside every window
+    for w0 in range(0, n, window):
+        seg = rl[w0:w0 + window]
+        assert (np.diff(seg) <= 0).all()
+    # the same operator pattern as the torch set-up, through the dof coordinates
+    def key(xx):
+        return [tuple(np.round(r * 1e9).astype(np.int64)) for r in xx]
+    kt = {k: i for i, k in enumerate(key(Vt.x.cpu().numpy()))}
+    perm = np.array([kt[k] for k in key(x)])  # torch index of native dof i
+    ones_n = Vn.pattern.to_csr(torch.ones(P.size, dtype=torch.float64, device="cuda"))
+    ones_t = Vt.pattern.to_csr(torch.ones(Vt.pattern.size, dtype=torch.float64, device="cuda"))
+    assert abs(ones_n - ones_t[perm][:, perm]).max() == 0
+    # adjacency: every (row, cell) pair once, positions point at the right columns
+    adj_cell = Vn.adj.adj_cell.cpu().numpy()
+    adj_loc = Vn.adj.adj_loc.cpu().numpy()
+    adj_pos = Vn.adj.adj_pos.cpu().numpy()
+    ap = Vn.adj.adj_ptr.cpu().numpy()
+    cols = P.cols.cpu().numpy()
+    seen = 0
+    rng = np.random.default_rng(0)
+    for s in rng.choice(P.n_slices, size=min(P.n_slices, 12), replace=False):
+        T = (ap[s + 1] - ap[s]) // 64
+        for lane in range(64):
+            r = s * 64 + lane
+            if r >= n:
+                continue
+            for t in range(T):
+                e = adj_cell[ap[s] + t * 64 + lane]
+                if e < 0:
+                    continue
+                seen += 1
+                assert cd[e, adj_loc[ap[s] + t * 64 + lane]] == r
+                for j in range(nd):
+                    k = int(adj_pos[ap[s] + t * 64 + lane, j])
+                    assert cols[sp[s] + (k // 2) * 128 + lane * 2 + (k % 2)] == cd[e, j]
+    assert seen > 0
+    assert int(Vn.adj_count.sum().item()) == nc * nd
+    # identical arrays where the numbering coincides (it does here: same keys, stable sorts)
+    if torch.equal(Vn.cell_dofs, Vt.cell_dofs):
+        assert torch.equal(Vn.x, Vt.x) and torch.equal(P.slice_ptr, Vt.pattern.slice_ptr)
+        assert torch.equal(P.cols, Vt.pattern.cols) and torch.equal(Vn.adj.adj_pos, Vt.adj.adj_pos)
+        assert torch.equal(Vn.adj.adj_cell, Vt.adj.adj_cell) and torch.equal(Vn.local_cells, Vt.local_cells)
+
+
+def test_native_rectangular_pattern_matches_the_torch_one(hip):
+    from oasisx_amd import fem
+
+    mesh = _mesh("box", 5)
+    (Vt, Vn), (Qt, Qn) = _spaces(mesh, 2, 256), _spaces(mesh, 1, 256)
+    for (Rt, Ct), (Rn, Cn) in (((Vt, Qt), (Vn, Qn)), ((Qt, Vt), (Qn, Vn))):
+        pt, post, pwt = fem.build_rect_pattern(Rt, Ct)
+        pn, posn, pwn = fem.build_rect_pattern(Rn, Cn)
+        assert pwt == pwn and pn.nnz == pt.nnz
+        if torch.equal(Rn.cell_dofs, Rt.cell_dofs) and torch.equal(Cn.cell_dofs, Ct.cell_dofs):
+            assert torch.equal(pn.cols, pt.cols) and torch.equal(pn.slice_ptr, pt.slice_ptr)
+            valid = (Rn.adj.adj_cell >= 0)
+            assert torch.equal(posn[valid], post[valid])
+
+
+def test_value_dictionary_against_torch_unique(hip):
+    import ctypes as C
+
+    from oasisx_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    pal = torch.randn(200, dtype=torch.float64, device="cuda", generator=g)
+    pal[7] = 0.0
+    pal[8] = -0.0
+    for ncomp in (1, 3):
+        vals = pal[torch.randint(0, 200, (50000 * ncomp,), device="cuda", generator=g)].contiguous()
+        codes = torch.zeros(50000, dtype=torch.uint8 if ncomp == 1 else torch.int32, device="cuda")
+        d = torch.zeros(256, dtype=torch.float64, device="cuda")
+        nd = C.c_int(0)
+        _lib.check(lib.ox_value_dictionary(_lib.ptr(vals), 50000, ncomp, _lib.ptr(codes), _lib.ptr(d), C.byref(nd), None), "dict")
+        u = torch.unique(vals.view(torch.int64))
+        assert nd.value == u.numel() and torch.equal(d[: nd.value].view(torch.int64), u)
+        v2 = vals.reshape(50000, ncomp)
+        for c in range(ncomp):
+            cc = (codes.to(torch.int64) >> (8 * c)) & 0xff
+            assert torch.equal(d[cc].view(torch.int64), v2[:, c].contiguous().view(torch.int64))
+    many = torch.randn(5000, dtype=torch.float64, device="cuda", generator=g)
+    nd = C.c_int(5)
+    _lib.check(lib.ox_value_dictionary(_lib.ptr(many), 5000, 1, _lib.ptr(torch.zeros(5000, dtype=torch.uint8, device="cuda")),
+                                       _lib.ptr(torch.zeros(256, dtype=torch.float64, device="cuda")), C.byref(nd), None), "dict")
+    assert nd.value == 0  # more than 256 distinct values: declined
