@@ -1,0 +1,42 @@
+"""GPU: one IPCS time step driven through the C ABI ALONE -- demo/cabi_ipcs_step.py: numpy arrays,
+ctypes and include/oasisx_hip.h; neither the oasisx_amd package (no fem.py) nor torch is imported in
+that process -- against the oracle on the same mesh with the oracle's own dof numbering (fields
+matched through the dof coordinates).  The mesh generator of the driver (alternating diagonals /
+5 tetrahedra per cube) is neither the product's nor the oracle's."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("dim,N,udeg", [(2, 12, 2), (3, 5, 2), (3, 6, 1)])
+def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg):
+    from oracle import ipcs_oracle as O
+    from oracle.cpu_baseline import match_by_coordinates
+    from tests.helpers import KRYLOV
+
+    out = str(tmp_path / "step.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "cabi_ipcs_step.py"), "--dim", str(dim), "-N", str(N),
+                        "--udeg", str(udeg), "--steps", "2", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = np.load(out)
+    assert not bool(g["imported_package"]) and not bool(g["imported_torch"])  # the C ABI was all it used
+    nu, dt = 0.01, 0.005
+    R, clock = O.taylor_green_problem(0, dim, u_deg=udeg, p_deg=1, nu=nu, dt=dt, solver_options=KRYLOV,
+                                      mesh=(g["coords"], g["cells"].astype(np.int64)))
+    t = 0.0
+    for _ in range(2):
+        t += dt
+        clock["t"] = t
+        R.solve(dt, nu, max_iter=1)
+    lo, hi = -np.ones(dim), np.ones(dim)
+    pv = match_by_coordinates(g["x_v"], R.F.x_v, lo, hi)
+    pq = match_by_coordinates(g["x_q"], R.F.x_q, lo, hi)
+    assert np.abs(g["u"][pv] - R.u1).max() < 1e-8
+    assert np.abs(g["p"][pq] - R.p).max() < 1e-7
+    assert abs(int(g["its_pressure"][0]) - int(np.max(np.atleast_1d(R.its["pressure"])))) <= 2
