@@ -547,11 +547,29 @@ struct ox_rect {
 
 namespace {
 
-KeySpec key_spec(const ox_mesh *M, int tb) {
+// bits per coordinate: 4 lattice steps per mean point spacing (fem.default_key_bits is the twin of
+// this integer arithmetic; OX_KEY_BITS overrides both)
+int default_key_bits(int64_t n_points, int d, int tb) {
+  const char *e = getenv("OX_KEY_BITS");
+  if (e) return atoi(e);
+  auto pw = [&](int64_t L) {
+    __int128 v = 1;
+    for (int k = 0; k < d; ++k) v *= L;
+    return v;
+  };
+  int64_t L = 1;
+  while (pw(L) < (__int128)n_points) L += L < 64 ? 1 : std::max<int64_t>(1, L / 64);
+  while (L > 1 && pw(L - 1) >= (__int128)n_points) --L;
+  int b = 0;
+  while (((int64_t)1 << b) < L) ++b;
+  return std::min(18, std::max(b + 2, tb + 1));
+}
+
+KeySpec key_spec(const ox_mesh *M, int tb, int64_t n_points) {
   KeySpec K;
   K.d = M->gdim;
   K.tb = tb;
-  int bits = 18;
+  int bits = default_key_bits(n_points, M->gdim, tb);
   while (bits > 4 && (K.d - 1) * tb + K.d * bits > 63) --bits;
   if (tb > bits) K.tb = bits;
   K.bits = bits;
@@ -703,7 +721,7 @@ extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const in
     }
   }
   M->tile_bits = tile_bits;
-  const KeySpec K = key_spec(M, tile_bits);
+  const KeySpec K = key_spec(M, tile_bits, n_cells);
   M->key_bits = K.bits;
   // kernel cell order: tiled order of the centroids (stable: ties keep the caller's order)
   {
@@ -818,7 +836,7 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {
-    const KeySpec K = key_spec(M, M->tile_bits);
+    const KeySpec K = key_spec(M, M->tile_bits, n);
     DevBuf k_in, k_out, v_in, perm1;
     OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));

@@ -172,6 +172,117 @@ def from_arrays(coords, cells, comm=None, device=None) -> Mesh:
     return Mesh(c, t, comm if comm is not None else COMM_WORLD)
 
 
+# ---- mesh files -----------------------------------------------------------------------------------
+
+
+def _read_medit(path):
+    """Medit ASCII ``.mesh``: ``Vertices`` (x y [z] ref), ``Triangles`` / ``Tetrahedra`` (1-based, ref)."""
+    tok = open(path).read().split()
+    i, dim, pts, tri, tet = 0, 3, None, None, None
+
+    def block(n, width):
+        nonlocal i
+        a = np.asarray(tok[i:i + n * width], dtype=np.float64).reshape(n, width)
+        i += n * width
+        return a
+
+    while i < len(tok):
+        w = tok[i].lower()
+        i += 1
+        if w == "dimension":
+            dim = int(tok[i])
+            i += 1
+        elif w == "vertices":
+            n = int(tok[i])
+            i += 1
+            pts = block(n, dim + 1)[:, :dim]
+        elif w == "triangles":
+            n = int(tok[i])
+            i += 1
+            tri = block(n, 4)[:, :3].astype(np.int64) - 1
+        elif w == "tetrahedra":
+            n = int(tok[i])
+            i += 1
+            tet = block(n, 5)[:, :4].astype(np.int64) - 1
+        elif w == "end":
+            break
+    if pts is None:
+        raise ValueError(f"{path}: no Vertices section")
+    cells = tet if tet is not None and len(tet) else tri
+    if cells is None:
+        raise ValueError(f"{path}: neither Tetrahedra nor Triangles")
+    if cells.shape[1] == 3 and pts.shape[1] == 3 and np.ptp(pts[:, 2]) == 0.0:
+        pts = pts[:, :2]  # a planar triangle mesh written with z = const
+    return pts, cells
+
+
+def _read_plain(path):
+    """Plain text: ``vertices <n> <gdim>`` + n coordinate lines, ``cells <m> <k>`` + m lines of k 0-based vertex ids
+    (``#`` starts a comment)."""
+    lines = [ln.split("#", 1)[0].split() for ln in open(path)]
+    lines = [ln for ln in lines if ln]
+    i, pts, cells = 0, None, None
+    while i < len(lines):
+        head = lines[i]
+        if head[0].lower() == "vertices":
+            n, d = int(head[1]), int(head[2])
+            pts = np.asarray(lines[i + 1:i + 1 + n], dtype=np.float64).reshape(n, d)
+            i += 1 + n
+        elif head[0].lower() == "cells":
+            m, k = int(head[1]), int(head[2])
+            cells = np.asarray(lines[i + 1:i + 1 + m], dtype=np.int64).reshape(m, k)
+            i += 1 + m
+        else:
+            raise ValueError(f"{path}: unexpected line {' '.join(head)!r}")
+    if pts is None or cells is None:
+        raise ValueError(f"{path}: needs a 'vertices' and a 'cells' section")
+    return pts, cells
+
+
+def read_mesh(filename: str, comm=None, device=None) -> Mesh:
+    """Simplicial mesh from a file: ``.npz`` (arrays ``points``/``coords`` and ``cells``), Medit ASCII ``.mesh``
+    or the plain text format of :func:`write_mesh`.  Cells may come in any order and orientation; unused
+    vertices are dropped.  No gmsh / XDMF / ADIOS2 dependency."""
+    ext = filename.rsplit(".", 1)[-1].lower()
+    if ext == "npz":
+        z = np.load(filename)
+        pts = np.asarray(z["points"] if "points" in z.files else z["coords"], dtype=np.float64)
+        cells = np.asarray(z["cells"], dtype=np.int64)
+    elif ext == "mesh":
+        pts, cells = _read_medit(filename)
+    else:
+        pts, cells = _read_plain(filename)
+    if cells.ndim != 2 or cells.shape[1] != pts.shape[1] + 1:
+        raise ValueError(f"{filename}: {cells.shape[1]}-vertex cells in {pts.shape[1]}-D: triangles in 2-D or tetrahedra in 3-D")
+    if cells.min() < 0 or cells.max() >= pts.shape[0]:
+        raise ValueError(f"{filename}: cell vertex index out of range")
+    used = np.zeros(pts.shape[0], dtype=bool)
+    used[cells.ravel()] = True
+    if not used.all():
+        new = np.cumsum(used) - 1
+        pts, cells = pts[used], new[cells]
+    return from_arrays(pts, cells, comm=comm, device=device)
+
+
+def write_mesh(mesh: Mesh, filename: str):
+    """Write ``mesh`` as ``.npz`` (points, cells) or as plain text (see :func:`read_mesh`)."""
+    pts, cells = mesh.coords.cpu().numpy(), mesh.cells.cpu().numpy()
+    if filename.lower().endswith(".npz"):
+        np.savez(filename, points=pts, cells=cells)
+        return
+    with open(filename, "w") as f:
+        f.write(f"# oasisx_amd mesh\nvertices {pts.shape[0]} {pts.shape[1]}\n")
+        np.savetxt(f, pts, fmt="%.17g")
+        f.write(f"cells {cells.shape[0]} {cells.shape[1]}\n")
+        np.savetxt(f, cells, fmt="%d")
+
+
+def import_mesh(filename: str) -> Mesh:
+    """The reference's ``oasisx.import_mesh`` (src/oasisx/mesh.py:13-15 -- a stub there that prints
+    the file name and returns a unit square): here it reads the file."""
+    return read_mesh(filename)
+
+
 # ---- generators (DOLFINx layouts) --------------------------------------------------------
 
 

@@ -7,8 +7,9 @@ ksp.py:77).  Here:
 
 * every rank generates the (global) mesh and computes the SAME partition metadata (cell ->
   rank, vertex/edge -> owner rank); nothing is communicated at set-up;
-* cells are cut into ``nparts`` slabs by centroid (z-major sort, equal counts); a dof belongs to
-  the lowest rank among the cells that contain it; a rank keeps every cell that touches one of
+* cells are dealt to ``nparts`` parts by recursive coordinate bisection of their centroids (equal
+  counts, compact parts, any ``nparts``; ``OX_PARTITION=slabs`` restores the r01 z-slabs); a dof
+  belongs to the lowest rank among the cells that contain it; a rank keeps every cell that touches one of
   its dofs (its own cells + one ghost layer), so every owned matrix row / vector entry is
   assembled locally and no matrix entries are ever communicated (PETSc's ``Mat.assemble``
   stash exchange disappears);
@@ -273,6 +274,49 @@ def init_comm() -> Comm:
     return Comm(rank, size, handle)
 
 
+def slab_partition(cen: torch.Tensor, coords: torch.Tensor, nparts: int) -> torch.Tensor:
+    """Cells cut into ``nparts`` slabs of equal counts in (z, y, x) order of the centroids."""
+    nc, d = cen.shape
+    lo = coords.min(dim=0).values
+    span = (coords.max(dim=0).values - lo).clamp_min(1e-300)
+    q = torch.round((cen - lo) / span * float(1 << 20)).to(torch.int64)
+    key = q[:, d - 1]
+    for k in range(d - 2, -1, -1):
+        key = key * (1 << 21) + q[:, k]
+    order = torch.argsort(key, stable=True)
+    cell_rank = torch.empty(nc, dtype=torch.int64, device=cen.device)
+    cell_rank[order] = torch.div(torch.arange(nc, device=cen.device) * nparts, nc, rounding_mode="floor")
+    return cell_rank
+
+
+def recursive_coordinate_bisection(cen: torch.Tensor, nparts: int) -> torch.Tensor:
+    """Geometric graph-free partition of points (cell centroids) into ``nparts`` parts of equal
+    counts: split the current set across its longest extent (ties: the highest axis, so box meshes
+    are first cut in z as the r01 slabs were) at the weighted median -- parts proportional to the
+    number of ranks on each side, so any ``nparts`` works -- and recurse.  The stand-in for the graph
+    partitioner DOLFINx calls for the reference ("any graph partition computed on
+    host"): compact parts (2 x 2 x 2 blocks on a cube at 8 ranks, a third of the slabs' interface
+    area), no adjacency needed, O(n log n) device sorts.  Deterministic (stable sorts), so every
+    rank derives the same map from the replicated mesh."""
+    n = cen.shape[0]
+    out = torch.zeros(n, dtype=torch.int64, device=cen.device)
+    todo = [(torch.arange(n, device=cen.device), 0, int(nparts))]  # (cell ids, first rank, ranks)
+    while todo:
+        ids, r0, k = todo.pop()
+        if k == 1 or ids.numel() == 0:
+            out[ids] = r0
+            continue
+        x = cen[ids]
+        ext = x.max(dim=0).values - x.min(dim=0).values
+        axis = int(max(range(cen.shape[1]), key=lambda a: (float(ext[a]) * (1.0 + 1e-12 * a), a)))
+        order = torch.argsort(x[:, axis], stable=True)
+        k_lo = k // 2
+        cut = (ids.numel() * k_lo) // k
+        todo.append((ids[order[:cut]], r0, k_lo))
+        todo.append((ids[order[cut:]], r0 + k_lo, k - k_lo))
+    return out
+
+
 class MeshPartition:
     """Replicated partition metadata of a (global) mesh for one rank."""
 
@@ -282,17 +326,15 @@ class MeshPartition:
         d = mesh.gdim
         cells = mesh.cells
         nc, nverts = mesh.num_cells, mesh.num_vertices
-        # ---- cells -> slabs by centroid (z, y, x) order, equal counts --------------------------
+        # ---- cells -> parts: recursive coordinate bisection of the centroids (OX_PARTITION=slabs: the
+        #      r01 z-slabs) -- replicated and deterministic: every rank computes the same map ------------
+        import os
+
         cen = mesh.coords[cells].mean(dim=1)
-        lo = mesh.coords.min(dim=0).values
-        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
-        q = torch.round((cen - lo) / span * float(1 << 20)).to(torch.int64)
-        key = q[:, d - 1]
-        for k in range(d - 2, -1, -1):
-            key = key * (1 << 21) + q[:, k]
-        order = torch.argsort(key, stable=True)
-        cell_rank = torch.empty(nc, dtype=torch.int64, device=dev)
-        cell_rank[order] = torch.div(torch.arange(nc, device=dev) * nparts, nc, rounding_mode="floor")
+        if os.environ.get("OX_PARTITION", "rcb").lower() == "slabs":
+            cell_rank = slab_partition(cen, mesh.coords, nparts)
+        else:
+            cell_rank = recursive_coordinate_bisection(cen, nparts)
         self.cell_rank = cell_rank
         # ---- edges (global ids) -------------------------------------------------------------
         ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)

@@ -42,7 +42,7 @@ def _halo_forward(V, x, rank):
             x[V.n_owned + b[1]:V.n_owned + b[2]] = b[0].numpy()
 
 
-def _worker(rank, world, port, dim, N, deg, out):
+def _worker(rank, world, port, dim, N, deg, out, kind="box"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,8 +54,14 @@ def _worker(rank, world, port, dim, N, deg, out):
 
         comm = init_comm()
         assert comm.rank == rank and comm.size == world and comm.handle is None
-        m = (M.create_rectangle(comm, [[-1, -1], [1, 1]], [N, N], device="cpu") if dim == 2
-             else M.create_box(comm, [[-1, -1, -1], [1, 1, 1]], [N, N, N], device="cpu"))
+        if kind == "delaunay":  # genuinely unstructured (irregular valence), any number of parts
+            from tests.helpers import delaunay_box_mesh
+
+            pts, tets = delaunay_box_mesh(N, dim, seed=1)
+            m = M.from_arrays(pts, tets, comm=comm, device="cpu")
+        else:
+            m = (M.create_rectangle(comm, [[-1, -1], [1, 1]], [N, N], device="cpu") if dim == 2
+                 else M.create_box(comm, [[-1, -1, -1], [1, 1, 1]], [N, N, N], device="cpu"))
         part = MeshPartition(m, rank, world)
         V = fem.FunctionSpace(m, deg, window=128, part=part)
         n_tot = torch.tensor([V.n_owned])
@@ -131,10 +137,50 @@ def _worker(rank, world, port, dim, N, deg, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dim,N,deg", [(2, 8, 2), (3, 4, 2), (3, 5, 1)])
-def test_partitioned_cg_over_gloo(dim, N, deg):
-    world = 2
+@pytest.mark.parametrize("dim,N,deg,kind,world", [(2, 8, 2, "box", 2), (3, 4, 2, "box", 2), (3, 5, 1, "box", 2),
+                                                  (3, 4, 2, "delaunay", 3), (2, 9, 2, "delaunay", 2)])
+def test_partitioned_cg_over_gloo(dim, N, deg, kind, world):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, out, kind), nprocs=world, join=True)
     assert all(out.get(r) == 1 for r in range(world))
+
+
+def test_recursive_coordinate_bisection_parts():
+    from oasisx_amd.parallel import recursive_coordinate_bisection
+    from tests.helpers import delaunay_box_mesh
+
+    pts, tets = delaunay_box_mesh(6, 3, seed=2)
+    cen = torch.from_numpy(pts[tets].mean(axis=1))
+    for k in (2, 3, 5, 8):
+        r = recursive_coordinate_bisection(cen, k)
+        cnt = torch.bincount(r, minlength=k)
+        assert int(cnt.max() - cnt.min()) <= 1 and int(cnt.sum()) == tets.shape[0]
+        assert torch.equal(r, recursive_coordinate_bisection(cen, k))  # deterministic
+    r8 = recursive_coordinate_bisection(cen, 8)  # compact: 2 x 2 x 2 octants of the cube
+    for q in range(8):
+        c = cen[r8 == q]
+        assert float((c.max(dim=0).values - c.min(dim=0).values).max()) < 1.4
+
+
+def test_mesh_files_round_trip(tmp_path):
+    from oasisx_amd import mesh as M
+    from tests.helpers import delaunay_box_mesh
+
+    pts, tets = delaunay_box_mesh(3, 3, seed=3)
+    m = M.from_arrays(pts, tets, device="cpu")
+    for name in ("m.npz", "m.txt"):
+        M.write_mesh(m, str(tmp_path / name))
+        r = M.import_mesh(str(tmp_path / name)) if name.endswith("npz") else M.read_mesh(str(tmp_path / name), device="cpu")
+        assert np.array_equal(r.cells.cpu().numpy(), tets) and np.abs(r.coords.cpu().numpy() - pts).max() == 0.0
+    # Medit ASCII (1-based, reference tags), with an unused vertex that must be dropped
+    with open(tmp_path / "m.mesh", "w") as f:
+        f.write("MeshVersionFormatted 1\nDimension 3\nVertices %d\n" % (pts.shape[0] + 1))
+        for p in pts:
+            f.write("%.17g %.17g %.17g 0\n" % tuple(p))
+        f.write("9 9 9 0\nTetrahedra %d\n" % tets.shape[0])
+        for t in tets:
+            f.write("%d %d %d %d 1\n" % tuple(t + 1))
+        f.write("End\n")
+    r = M.read_mesh(str(tmp_path / "m.mesh"), device="cpu")
+    assert r.num_vertices == pts.shape[0] and np.array_equal(r.cells.cpu().numpy(), tets)
