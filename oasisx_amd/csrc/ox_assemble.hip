@@ -6,6 +6,7 @@
 // so the rule is exact, as FFCx's is in the reference).
 #include "fe_tables.h"
 #include "ox_kernels.h"
+#include <stdlib.h>
 
 #define OX_KIND_MASS 0
 #define OX_KIND_STIFF 1
@@ -68,6 +69,72 @@ __device__ __forceinline__ const RtTab<GDIM, DEG> &rt() {
   else return RT32;
 }
 
+// Convection as a tensor contraction (assemble_first, fracstep.py:355-358).  With u_ab in the element's
+// own space, beta_b(x) = G[b] . u_ab(x) = sum_k phi_k(x) gam[k][b], gam[k][b] = G[b] . u_ab_k, and
+//   C[i][j] = |J| sum_b int phi_i beta_b d(phi_j)/d(lambda_b) = |J| sum_{(j,b)} sum_k T[i][(j,b)][k] gam[k][b]
+// where T[i][(j,b)][k] = int phi_i phi_k d(phi_j)/d(lambda_b) over the reference simplex -- computed at
+// compile time with the same degree-5 rule (exact: the integrand has degree 2+2+1), and only for the
+// (j, b) pairs whose derivative is not identically zero (16 of 40 for P2 tetrahedra).  A lane needs
+// row i of T for ITS row dof: 160 doubles read from an LDS copy, against 590 FMAs per (row, cell)
+// pair that the quadrature form spent on evaluating u_ab at the 14 points again for every row of
+// the cell (870 -> 280 FMAs per pair).
+template <int GDIM, int DEG>
+struct Combos {
+  static constexpr int MAXC = Elem<GDIM, DEG>::ND * (GDIM + 1);
+  int n;
+  int j[MAXC], b[MAXC];
+};
+template <int GDIM, int DEG>
+constexpr Combos<GDIM, DEG> make_combos() {
+  using E = Elem<GDIM, DEG>;
+  Combos<GDIM, DEG> c{};
+  for (int j = 0; j < E::ND; ++j)
+    for (int b = 0; b <= GDIM; ++b) {
+      bool nz = false;
+      for (int q = 0; q < E::NQ; ++q) nz = nz || (E::dphi(q, j, b) != 0.0);
+      if (nz) {
+        c.j[c.n] = j;
+        c.b[c.n] = b;
+        ++c.n;
+      }
+    }
+  return c;
+}
+template <int GDIM, int DEG>
+inline constexpr Combos<GDIM, DEG> COMBOS = make_combos<GDIM, DEG>();
+
+template <int GDIM, int DEG>
+struct ConvTab {
+  using E = Elem<GDIM, DEG>;
+  static constexpr int NCB = COMBOS<GDIM, DEG>.n;
+  double t[E::ND][E::ND][NCB];  // [row dof i][k][(j, b)]: read in this order, 16 independent chains per k
+};
+template <int GDIM, int DEG>
+constexpr ConvTab<GDIM, DEG> make_conv() {
+  using E = Elem<GDIM, DEG>;
+  ConvTab<GDIM, DEG> T{};
+  constexpr auto CB = COMBOS<GDIM, DEG>;
+  for (int i = 0; i < E::ND; ++i)
+    for (int m = 0; m < CB.n; ++m)
+      for (int k = 0; k < E::ND; ++k) {
+        double s = 0.0;
+        for (int q = 0; q < E::NQ; ++q) s += E::w(q) * E::phi(q, i) * E::phi(q, k) * E::dphi(q, CB.j[m], CB.b[m]);
+        T.t[i][k][m] = s;
+      }
+  return T;
+}
+__device__ const ConvTab<2, 1> CT21 = make_conv<2, 1>();
+__device__ const ConvTab<2, 2> CT22 = make_conv<2, 2>();
+__device__ const ConvTab<3, 1> CT31 = make_conv<3, 1>();
+__device__ const ConvTab<3, 2> CT32 = make_conv<3, 2>();
+template <int GDIM, int DEG>
+__device__ __forceinline__ const ConvTab<GDIM, DEG> &ct() {
+  if constexpr (GDIM == 2 && DEG == 1) return CT21;
+  else if constexpr (GDIM == 2 && DEG == 2) return CT22;
+  else if constexpr (GDIM == 3 && DEG == 1) return CT31;
+  else return CT32;
+}
+
 template <int GDIM>
 __device__ __forceinline__ void load_geom(const double *__restrict__ g, double (&G)[GDIM + 1][GDIM],
                                           double &adet) {
@@ -96,123 +163,178 @@ struct FirstArgs {
   const uint8_t *Mc, *Kc;
   const double *Md, *Kd;
   int nMd, nKd;
+  int dbg;  // tuning only (OX_AF_DBG): bit 0 skips the pair loop, bit 1 the epilogue -- wrong results
 };
 
-template <int GDIM, int DEG, int KIND, int PW, bool DICT = false>
-__global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
-                                                      ox_adj adj, const uint8_t *__restrict__ adj_pos,
-                                                      ox_sell A, FirstArgs F,
-                                                      const int32_t *__restrict__ slice_list) {
+template <int GDIM, int DEG, int KIND, int PW, bool DICT = false, int U = 1>
+__global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
+                                                       ox_adj adj, const uint8_t *__restrict__ adj_pos,
+                                                       ox_sell A, FirstArgs F,
+                                                       const int32_t *__restrict__ slice_list, int n_list,
+                                                       int bin_width) {
   using E = Elem<GDIM, DEG>;
   constexpr int ND = E::ND, NQ = E::NQ, GS = E::GS;
-  extern __shared__ double acc[];  // [width][64]
+  constexpr int NCB = COMBOS<GDIM, DEG>.n;
+  constexpr int TS = NCB * ND + 2;  // doubles per row dof in LDS: 16 B of padding put the rows of
+                                    // different i on different banks for the 16-byte reads
+  extern __shared__ double acc_all[];  // [4 waves][bin_width][64]
   __shared__ double dM[DICT ? 256 : 1], dK[DICT ? 256 : 1];
-  const int lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) double tconv[KIND == OX_KIND_CONV ? ND * TS : 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;  // 4 waves per block, fewer for very wide rows
   if constexpr (DICT) {
-    for (int i = lane; i < F.nMd; i += 64) dM[i] = F.Md[i];
-    for (int i = lane; i < F.nKd; i += 64) dK[i] = F.Kd[i];
-    __syncthreads();
+    for (int i = threadIdx.x; i < F.nMd; i += nthr) dM[i] = F.Md[i];
+    for (int i = threadIdx.x; i < F.nKd; i += nthr) dK[i] = F.Kd[i];
   }
-  const int slice = slice_list[blockIdx.x];
+  if constexpr (KIND == OX_KIND_CONV) {
+    const double *src = &ct<GDIM, DEG>().t[0][0][0];
+    constexpr int NT = ND * NCB * ND, PER = (NT + 63) / 64;  // loads per thread of a 64-thread block
+    double tv[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {  // all loads first (one memory round trip), then the LDS writes
+      const int idx = threadIdx.x + r * nthr;
+      tv[r] = idx < NT ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int idx = threadIdx.x + r * nthr;
+      if (idx < NT) {
+        const int i = idx / (NCB * ND);
+        tconv[i * TS + (idx - i * NCB * ND)] = tv[r];
+      }
+    }
+  }
+  if constexpr (DICT || KIND == OX_KIND_CONV) __syncthreads();
+  // 4 slices of the bin per block; blocks that share an XCD (equal blockIdx % 8) take one contiguous
+  // eighth of the bin's slices: the rows of a cell (its 4 vertices / 6 edges) then meet in ONE L2
+  // instead of being fetched by up to 8 (r01 PMC: 46.6 GB per assemble_first, every pair re-fetched
+  // its cell; with the chunked order 24.4 GB)
+  const int li = ox_xcd_remap(blockIdx.x, gridDim.x) * nwave + wave;
+  if (li >= n_list) return;
+  double *acc = acc_all + (size_t)wave * bin_width * 64;
+  const int slice = slice_list[li];
   const int64_t base = A.slice_ptr[slice];
   const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
   for (int k = 0; k < width; ++k) acc[k * 64 + lane] = 0.0;
   const int64_t abase = adj.adj_ptr[slice];
   const int T = (int)((adj.adj_ptr[slice + 1] - abase) >> 6);
   const auto &R = rt<GDIM, DEG>();
-  for (int t = 0; t < T; ++t) {
-    const int64_t pidx = abase + (int64_t)t * 64 + lane;
-    const int e = adj.adj_cell[pidx];
-    if (e < 0) continue;
-    const int i = adj.adj_loc[pidx];
-    uint8_t pos[PW];
-    if constexpr (PW == 16) {
-      *reinterpret_cast<uint4 *>(pos) = *reinterpret_cast<const uint4 *>(adj_pos + pidx * 16);
-    } else if constexpr (PW == 8) {
-      *reinterpret_cast<uint2 *>(pos) = *reinterpret_cast<const uint2 *>(adj_pos + pidx * 8);
-    } else {
-      *reinterpret_cast<uint32_t *>(pos) = *reinterpret_cast<const uint32_t *>(adj_pos + pidx * 4);
-    }
-    double G[GDIM + 1][GDIM], adet;
-    load_geom<GDIM>(cells.geom + (size_t)e * GS, G, adet);
-    double c[ND];
+  // U (row, cell) pairs per lane are in flight together, phase by phase: the three dependent memory
+  // rounds of a pair (adjacency -> cell dofs + geometry -> coefficient gathers) are paid once per U
+  // pairs.  The wide (vertex-row) bins run ONE wave per SIMD (their accumulators fill the LDS), so
+  // nothing else hides those ~3 us: with U = 1 the loop sat at 7 us per pair for 0.5 us of arithmetic.
+  for (int t0 = 0; t0 < ((F.dbg & 1) ? 0 : T); t0 += U) {
+    int e[U], iloc[U];
+    bool ok[U];
+    uint8_t pos[U][PW];
 #pragma unroll
-    for (int j = 0; j < ND; ++j) c[j] = 0.0;
-    if constexpr (KIND == OX_KIND_MASS) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const double wp = R.wphi[i][q];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) c[j] = fma(wp, E::phi(q, j), c[j]);
-      }
-    } else if constexpr (KIND == OX_KIND_STIFF) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        double gi[GDIM];
-#pragma unroll
-        for (int d = 0; d < GDIM; ++d) {
-          gi[d] = 0.0;
-#pragma unroll
-          for (int b = 0; b <= GDIM; ++b) gi[d] = fma(R.dphi[i][q][b], G[b][d], gi[d]);
-        }
-        // h[b] = w_q * G[b] . grad(phi_i)
-        double h[GDIM + 1];
-#pragma unroll
-        for (int b = 0; b <= GDIM; ++b) {
-          h[b] = 0.0;
-#pragma unroll
-          for (int d = 0; d < GDIM; ++d) h[b] = fma(G[b][d], gi[d], h[b]);
-          h[b] *= E::w(q);
-        }
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-#pragma unroll
-          for (int b = 0; b <= GDIM; ++b)
-            if (E::dphi(q, j, b) != 0.0) c[j] = fma(E::dphi(q, j, b), h[b], c[j]);
-      }
-    } else {
-      // convection row: C[i][j] = int (uab . grad phi_j) phi_i   (fracstep.py:355-358)
-      const int32_t *__restrict__ dd = cell_dofs + (size_t)e * ND;
-      double uc[ND][GDIM];
-#pragma unroll
-      for (int k = 0; k < ND; ++k) {
-        const double *up = F.uab + (size_t)dd[k] * GDIM;
-#pragma unroll
-        for (int d = 0; d < GDIM; ++d) uc[k][d] = up[d];
-      }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        double ub[GDIM];
-#pragma unroll
-        for (int d = 0; d < GDIM; ++d) {
-          ub[d] = 0.0;
-#pragma unroll
-          for (int k = 0; k < ND; ++k)
-            if (E::phi(q, k) != 0.0) ub[d] = fma(E::phi(q, k), uc[k][d], ub[d]);
-        }
-        const double wp = R.wphi[i][q];
-        double beta[GDIM + 1];
-#pragma unroll
-        for (int b = 0; b <= GDIM; ++b) {
-          beta[b] = 0.0;
-#pragma unroll
-          for (int d = 0; d < GDIM; ++d) beta[b] = fma(G[b][d], ub[d], beta[b]);
-          beta[b] *= wp;
-        }
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-#pragma unroll
-          for (int b = 0; b <= GDIM; ++b)
-            if (E::dphi(q, j, b) != 0.0) c[j] = fma(E::dphi(q, j, b), beta[b], c[j]);
+    for (int u = 0; u < U; ++u) {
+      const bool inb = t0 + u < T;  // wave-uniform
+      const int64_t pidx = abase + (int64_t)(inb ? t0 + u : t0) * 64 + lane;
+      e[u] = adj.adj_cell[pidx];
+      iloc[u] = adj.adj_loc[pidx];
+      ok[u] = inb && e[u] >= 0;
+      if (!ok[u]) e[u] = 0;  // loads stay unconditional (cell 0), the result is not accumulated
+      if constexpr (PW == 16) {
+        *reinterpret_cast<uint4 *>(pos[u]) = *reinterpret_cast<const uint4 *>(adj_pos + pidx * 16);
+      } else if constexpr (PW == 8) {
+        *reinterpret_cast<uint2 *>(pos[u]) = *reinterpret_cast<const uint2 *>(adj_pos + pidx * 8);
+      } else {
+        *reinterpret_cast<uint32_t *>(pos[u]) = *reinterpret_cast<const uint32_t *>(adj_pos + pidx * 4);
       }
     }
+    double G[U][GDIM + 1][GDIM], adet[U];
+    int32_t dd[U][KIND == OX_KIND_CONV ? ND : 1];
 #pragma unroll
-    for (int j = 0; j < ND; ++j)  // the slot is private to this lane: a no-return ds_add_f64 replaces read+add+write
-      __hip_atomic_fetch_add(&acc[(int)pos[j] * 64 + lane], adet * c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    for (int u = 0; u < U; ++u) {
+      load_geom<GDIM>(cells.geom + (size_t)e[u] * GS, G[u], adet[u]);
+      if constexpr (KIND == OX_KIND_CONV) {
+#pragma unroll
+        for (int k = 0; k < ND; ++k) dd[u][k] = cell_dofs[(size_t)e[u] * ND + k];
+      }
+    }
+    double uc[U][KIND == OX_KIND_CONV ? ND : 1][GDIM];
+    if constexpr (KIND == OX_KIND_CONV) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+#pragma unroll
+          for (int d = 0; d < GDIM; ++d) uc[u][k][d] = F.uab[(size_t)dd[u][k] * GDIM + d];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = iloc[u];
+      double c[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) c[j] = 0.0;
+      if constexpr (KIND == OX_KIND_MASS) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const double wp = R.wphi[i][q];
+#pragma unroll
+          for (int j = 0; j < ND; ++j) c[j] = fma(wp, E::phi(q, j), c[j]);
+        }
+      } else if constexpr (KIND == OX_KIND_STIFF) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double gi[GDIM];
+#pragma unroll
+          for (int d = 0; d < GDIM; ++d) {
+            gi[d] = 0.0;
+#pragma unroll
+            for (int b = 0; b <= GDIM; ++b) gi[d] = fma(R.dphi[i][q][b], G[u][b][d], gi[d]);
+          }
+          // h[b] = w_q * G[b] . grad(phi_i)
+          double h[GDIM + 1];
+#pragma unroll
+          for (int b = 0; b <= GDIM; ++b) {
+            h[b] = 0.0;
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) h[b] = fma(G[u][b][d], gi[d], h[b]);
+            h[b] *= E::w(q);
+          }
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+#pragma unroll
+            for (int b = 0; b <= GDIM; ++b)
+              if (E::dphi(q, j, b) != 0.0) c[j] = fma(E::dphi(q, j, b), h[b], c[j]);
+        }
+      } else {
+        // convection row: C[i][j] = int (uab . grad phi_j) phi_i   (fracstep.py:355-358), as the tensor
+        // contraction described at ConvTab
+        constexpr auto CB = COMBOS<GDIM, DEG>;
+        const double *__restrict__ ti = tconv + i * TS;
+        double cm[NCB];  // one accumulator per (j, b): NCB independent chains, summed per j at the end
+#pragma unroll
+        for (int m = 0; m < NCB; ++m) cm[m] = 0.0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+          double gam[GDIM + 1];
+#pragma unroll
+          for (int b = 0; b <= GDIM; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) v = fma(G[u][b][d], uc[u][k][d], v);
+            gam[b] = v;
+          }
+#pragma unroll
+          for (int m = 0; m < NCB; ++m) cm[m] = fma(ti[k * NCB + m], gam[CB.b[m]], cm[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < NCB; ++m) c[CB.j[m]] += cm[m];
+      }
+      if (ok[u]) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j)  // the slot is private to this lane: a no-return ds_add_f64 replaces read+add+write
+          __hip_atomic_fetch_add(&acc[(int)pos[u][j] * 64 + lane], adet[u] * c[j], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
   }
   // epilogue: stream the slice (coalesced 16-B values, 8-B columns)
   const int64_t row = (int64_t)slice * 64 + lane;
-  const int npair = width >> 1;
+  const int npair = (F.dbg & 2) ? 0 : width >> 1;
   double2 *__restrict__ av = reinterpret_cast<double2 *>(A.vals + base) + lane;
   if constexpr (KIND != OX_KIND_CONV) {
     for (int k = 0; k < npair; ++k) {
@@ -233,28 +355,49 @@ __global__ __launch_bounds__(64) void k_assemble_rows(ox_cells cells, const int3
         DICT ? reinterpret_cast<const unsigned short *>(F.Mc + base) + lane : nullptr;
     const unsigned short *__restrict__ kc =
         DICT ? reinterpret_cast<const unsigned short *>(F.Kc + base) + lane : nullptr;
-    for (int k = 0; k < npair; ++k) {
-      double2 m, kk;
-      if constexpr (DICT) {
-        const unsigned cm = mc[(size_t)k * 64], ck = kc[(size_t)k * 64];
-        m.x = dM[cm & 0xff], m.y = dM[cm >> 8];
-        kk.x = dK[ck & 0xff], kk.y = dK[ck >> 8];
-      } else {
-        m = mv[(size_t)k * 64], kk = kv[(size_t)k * 64];
-      }
-      const int2 col = cp[(size_t)k * 64];
-      const double c0 = acc[(2 * k) * 64 + lane], c1 = acc[(2 * k + 1) * 64 + lane];
-      // A = -0.5 C; A += (1/dt) M; A += (-0.5 nu) K        (fracstep.py:438-442)
-      const double ar0 = fma(mhnu, kk.x, fma(idt, m.x, -0.5 * c0));
-      const double ar1 = fma(mhnu, kk.y, fma(idt, m.y, -0.5 * c1));
-      const double *x0 = F.u1 + (size_t)col.x * GDIM, *x1 = F.u1 + (size_t)col.y * GDIM;
+    // 4 entry pairs per turn, phase by phase (codes + columns -> u1 gathers -> arithmetic in the
+    // original order -> stores): one turn pays the two dependent memory rounds once instead of 4 times
+    constexpr int EU = 4;
+    for (int k0 = 0; k0 < npair; k0 += EU) {
+      double2 m[EU], kk[EU];
+      int2 col[EU];
 #pragma unroll
-      for (int d = 0; d < GDIM; ++d) bf[d] = fma(ar1, x1[d], fma(ar0, x0[d], bf[d]));
-      // A = -A; A += (2/dt) M                               (fracstep.py:468-469)
-      double2 v;
-      v.x = fma(2.0 * idt, m.x, -ar0);
-      v.y = fma(2.0 * idt, m.y, -ar1);
-      av[(size_t)k * 64] = v;
+      for (int q = 0; q < EU; ++q) {
+        const int k = min(k0 + q, npair - 1);  // unconditional loads; the surplus is not used
+        if constexpr (DICT) {
+          const unsigned cm = mc[(size_t)k * 64], ck = kc[(size_t)k * 64];
+          m[q].x = dM[cm & 0xff], m[q].y = dM[cm >> 8];
+          kk[q].x = dK[ck & 0xff], kk[q].y = dK[ck >> 8];
+        } else {
+          m[q] = mv[(size_t)k * 64], kk[q] = kv[(size_t)k * 64];
+        }
+        col[q] = cp[(size_t)k * 64];
+      }
+      double x0[EU][GDIM], x1[EU][GDIM];
+#pragma unroll
+      for (int q = 0; q < EU; ++q)
+#pragma unroll
+        for (int d = 0; d < GDIM; ++d) {
+          x0[q][d] = F.u1[(size_t)col[q].x * GDIM + d];
+          x1[q][d] = F.u1[(size_t)col[q].y * GDIM + d];
+        }
+#pragma unroll
+      for (int q = 0; q < EU; ++q) {
+        const int k = k0 + q;
+        if (k < npair) {
+          const double c0 = acc[(2 * k) * 64 + lane], c1 = acc[(2 * k + 1) * 64 + lane];
+          // A = -0.5 C; A += (1/dt) M; A += (-0.5 nu) K        (fracstep.py:438-442)
+          const double ar0 = fma(mhnu, kk[q].x, fma(idt, m[q].x, -0.5 * c0));
+          const double ar1 = fma(mhnu, kk[q].y, fma(idt, m[q].y, -0.5 * c1));
+#pragma unroll
+          for (int d = 0; d < GDIM; ++d) bf[d] = fma(ar1, x1[q][d], fma(ar0, x0[q][d], bf[d]));
+          // A = -A; A += (2/dt) M                               (fracstep.py:468-469)
+          double2 v;
+          v.x = fma(2.0 * idt, m[q].x, -ar0);
+          v.y = fma(2.0 * idt, m[q].y, -ar1);
+          av[(size_t)k * 64] = v;
+        }
+      }
     }
     if (row < A.n_rows) {
 #pragma unroll
@@ -274,18 +417,48 @@ static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const 
       return launch_rows_t<GDIM, DEG, KIND, PW, true>(cells, cell_dofs, adj, adj_pos, A, F, n_bins, bin_ptr,
                                                       bin_slices, bin_width, st);
   }
-  auto kern = k_assemble_rows<GDIM, DEG, KIND, PW, DICT>;
+  // pairs in flight per lane (see the kernel): OX_ASSEMBLE_U overrides (tuning)
+  static int u_env = -1;
+  if (u_env < 0) {
+    const char *e = getenv("OX_ASSEMBLE_U");
+    u_env = e ? atoi(e) : 0;
+  }
   for (int b = 0; b < n_bins; ++b) {
     const int64_t cnt = bin_ptr[b + 1] - bin_ptr[b];
     if (cnt <= 0) continue;
-    const size_t lds = (size_t)bin_width[b] * 64 * sizeof(double);
-    if (lds > 160 * 1024) OX_FAIL("assemble: row width %d needs %zu B of LDS (> 160 KiB)", bin_width[b], lds);
-    if (lds > 64 * 1024)
-      OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(64), lds, st, *cells, cell_dofs, *adj, adj_pos,
-                       *A, F, bin_slices + bin_ptr[b]);
-    OX_LAUNCH_CHECK();
+    // wave-private accumulators [width][64]; 4 waves per block unless the rows are so wide (unstructured
+    // meshes: > 70 entries) that fewer fit beside the 17 KB of tables
+    static int nw_env = -1;
+    if (nw_env < 0) {
+      const char *e = getenv("OX_ASSEMBLE_NW");
+      nw_env = e ? atoi(e) : 0;
+    }
+    int nw = (nw_env == 1 || nw_env == 2 || nw_env == 4) ? nw_env : 4;
+    while (nw > 1 && (size_t)nw * bin_width[b] * 64 * sizeof(double) > 140 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * bin_width[b] * 64 * sizeof(double);
+    if (lds > 140 * 1024) OX_FAIL("assemble: row width %d needs %zu B of LDS", bin_width[b], lds);
+    // wide rows = many cells per row and one wave per SIMD: 3 pairs in flight; narrow rows: 2
+    // measured at 128^3 (tools/af_bench.py): U = 1 7.7 ms, 2: 9.0, 3: 9.3 -- the pair loop is bound by the
+    // address unit (every lane gathers from a different cell: ~30 divergent loads per pair), not by latency
+    int U = 1;
+    if (KIND == OX_KIND_CONV && u_env >= 1 && u_env <= 3) U = u_env;
+    auto go = [&](auto kern) -> int {
+      if (lds > 32 * 1024)
+        OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((cnt + nw - 1) / nw)), dim3(64 * nw), lds, st, *cells, cell_dofs, *adj,
+                         adj_pos, *A, F, bin_slices + bin_ptr[b], (int)cnt, (int)bin_width[b]);
+      OX_LAUNCH_CHECK();
+      return 0;
+    };
+    int rc;
+    if constexpr (KIND == OX_KIND_CONV) {
+      rc = U == 3 ? go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 3>)
+                  : (U == 2 ? go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 2>) : go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1>));
+    } else {
+      rc = go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1>);
+    }
+    if (rc) return rc;
   }
   return 0;
 }
@@ -336,8 +509,13 @@ extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_
   if (M->slice_ptr != A->slice_ptr || K->slice_ptr != A->slice_ptr)
     OX_FAIL("ox_assemble_first: M, K and A must share one sparsity pattern");
   if (!(dt > 0.0)) OX_FAIL("ox_assemble_first: dt=%g", dt);
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char *e = getenv("OX_AF_DBG");
+    dbg = e ? atoi(e) : 0;
+  }
   FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, 1.0 / dt, nu,
-              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict};
+              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict, dbg};
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
   const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
                                            bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
