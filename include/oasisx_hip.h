@@ -49,6 +49,8 @@ extern "C" {
 
 #define OX_KSP_CG 1      /* PETSc "cg"   */
 #define OX_KSP_BCGS 2    /* PETSc "bcgs" */
+#define OX_KSP_CG_SINGLE 3 /* PETSc "cg" with -ksp_cg_single_reduction: Chronopoulos-Gear recurrences, ONE
+                              merged reduction (one all-reduce in partitioned runs) per iteration */
 
 /* SELL-64 matrix: pattern + one value array (PETSc Mat on this path). */
 typedef struct {

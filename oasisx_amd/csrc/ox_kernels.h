@@ -12,7 +12,7 @@
 
 #define OX_SPMV_MAX_BLOCKS (1 << 22)  // one slice group per block (a cap of 2048 = persistent grid
                                       // measured 10 % slower: r01 notes in DESIGN.md)
-#define OX_MAX_NV 9             // most sums reduced at one synchronisation point (3 * OX_MAXC)
+#define OX_MAX_NV 12            // most sums reduced at one synchronisation point (4 * OX_MAXC: single-reduction CG init)
 
 static inline int ox_spmv_blocks(const ox_sell *A) {
   const int ngroups = (A->n_slices + 3) / 4;

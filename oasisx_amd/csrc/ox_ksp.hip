@@ -9,6 +9,7 @@
 // atomics): results are bit-reproducible run to run.
 #include "ox_kernels.h"
 #include "ox_p2p.h"
+#include <type_traits>
 
 struct KspState {
   double rz[OX_MAXC], alpha[OX_MAXC], beta[OX_MAXC], omega[OX_MAXC], rho[OX_MAXC];
@@ -29,7 +30,7 @@ struct KspParams {
   int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
 };
 
-enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3 };
+enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT };
 
 __device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P) {
   if (!(rn == rn) || isinf(rn)) return OX_DIVERGED_NANORINF;
@@ -83,6 +84,45 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
         S->rz[c] = s[c];
       }
     } else {
+      S->beta[c] = 0.0;
+    }
+  } else if (PH == PH_CGS_INIT) {  // s = {r.u, u.u, (Db).(Db), w.u}   (u = D^-1 r, w = A u)
+    S->rz[c] = s[c];
+    S->rn[c] = sqrt(s[NC + c]);
+    S->bn[c] = sqrt(s[2 * NC + c]);
+    S->its[c] = 0;
+    S->beta[c] = 0.0;
+    int r = ksp_test(S->rn[c], S->bn[c], P);
+    const double wu = s[3 * NC + c];
+    if (r == 0 && (wu == 0.0 || !(wu == wu))) r = (wu == wu) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
+    S->reason[c] = r;
+    S->active[c] = (r == 0);
+    S->alpha[c] = r == 0 ? s[c] / wu : 0.0;
+  } else if (PH == PH_CGS_IT) {  // s = {r.u, u.u (new residual), w.u}: the ONE reduction of the iteration
+    if (S->active[c]) {
+      S->its[c] += 1;
+      S->rn[c] = sqrt(s[NC + c]);
+      int r = ksp_test(S->rn[c], S->bn[c], P);
+      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
+      if (r == 0) {
+        // beta = gamma'/gamma;  alpha = gamma' / (delta - beta gamma'/alpha)   (Chronopoulos & Gear)
+        const double g = s[c], beta = g / S->rz[c];
+        const double den = s[2 * NC + c] - beta * g / S->alpha[c];
+        if (den == 0.0 || !(den == den)) r = (den == den) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
+        else {
+          S->beta[c] = beta;
+          S->alpha[c] = g / den;
+          S->rz[c] = g;
+        }
+      }
+      if (r) {
+        S->reason[c] = r;
+        S->active[c] = 0;
+        S->alpha[c] = 0.0;
+        S->beta[c] = 0.0;
+      }
+    } else {
+      S->alpha[c] = 0.0;
       S->beta[c] = 0.0;
     }
   } else if (PH == PH_BCGS_INIT) {  // s = {r.r, (Db).(Db)}  (r already preconditioned)
@@ -181,19 +221,43 @@ __device__ __forceinline__ void ksp_state_store(KspState *S, const KspState *sh)
 }
 
 // Fused: reduce per-block partials (fixed order) + scalar logic.  One wide block.
+// second partial array of a synchronisation point (the single-reduction CG merges the sums of the
+// update kernel and of the SpMV): its nv2 sums follow the first array's nv
+struct KspPart2 {
+  const double *partial;
+  int nparts, nv;
+};
+
+__device__ __forceinline__ void ksp_gather2(const double *__restrict__ partial, int nparts, int nv, const KspPart2 &B,
+                                            double (&v)[OX_MAX_NV]) {
+  ox_gather_partials(partial, nparts, nv, v);
+  if (B.nv > 0) {
+    double w[OX_MAX_NV];
+    ox_gather_partials(B.partial, B.nparts, B.nv, w);
+#pragma unroll
+    for (int i = 0; i < OX_MAX_NV; ++i)
+#pragma unroll
+      for (int j = 0; j < OX_MAX_NV; ++j)
+        if (j == i - nv && j < B.nv) v[i] = w[j];
+  }
+}
+
+constexpr bool ksp_is_init(int ph) { return ph == PH_CG_INIT || ph == PH_BCGS_INIT || ph == PH_CGS_INIT; }
+
 template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
                                                                const double *__restrict__ partial,
-                                                               int nparts, int nv, KspParams P) {
+                                                               int nparts, int nv, KspParams P, KspPart2 B) {
   __shared__ double red[16 * OX_MAX_NV];
   __shared__ KspState sh;
   // state and partials are loaded in ONE memory round trip; the done flag is looked at afterwards
   // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
   ksp_state_load(&sh, S);
   double v[OX_MAX_NV];
-  ox_gather_partials(partial, nparts, nv, v);
+  ksp_gather2(partial, nparts, nv, B, v);
+  nv += B.nv;
   ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
-  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done) return;  // uniform: nothing is stored
+  if (!ksp_is_init(PH) && sh.done) return;  // uniform: nothing is stored
   if (threadIdx.x == 0) {
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
     ksp_finish(&sh, P.nc_total);
@@ -208,19 +272,21 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
 template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
                                                                    const double *__restrict__ partial,
-                                                                   int nparts, int nv, KspParams P, ox_p2p_ar ar) {
+                                                                   int nparts, int nv, KspParams P, ox_p2p_ar ar,
+                                                                   KspPart2 B) {
   __shared__ double red[16 * OX_MAX_NV];
   __shared__ KspState sh;
   __shared__ double vals[OX_P2P_MAXV + 1];
   __shared__ double stage[64][OX_P2P_MAXV + 1];
   ksp_state_load(&sh, S);
   double v[OX_MAX_NV];
-  ox_gather_partials(partial, nparts, nv, v);
+  ksp_gather2(partial, nparts, nv, B, v);
+  nv += B.nv;
   ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
   // A queued sync point that runs after `done` still takes part in the exchange (the host has advanced
   // the sequence number for it; skipping would let two LIVE exchanges share a parity slot), it only
   // leaves the state alone.  `done` is the same on every rank (rank-ordered sums: identical bits).
-  const bool idle = PH != PH_CG_INIT && PH != PH_BCGS_INIT && sh.done;
+  const bool idle = !ksp_is_init(PH) && sh.done;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i)
@@ -244,7 +310,7 @@ template <int PH>
 __global__ __launch_bounds__(64) void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspParams P) {
   __shared__ KspState sh;
   __shared__ double sv[OX_MAX_NV];
-  if (PH != PH_CG_INIT && PH != PH_BCGS_INIT && S->done) return;
+  if (!ksp_is_init(PH) && S->done) return;
   ksp_state_load(&sh, S);
   if (threadIdx.x < OX_MAX_NV) sv[threadIdx.x] = sums[threadIdx.x];
   __syncthreads();
@@ -407,6 +473,90 @@ __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S
   });
 }
 
+// Single-reduction CG (Chronopoulos & Gear) init: r = b - q (q = A x0) or r = b, x = 0; u = D^-1 r;
+// p = s = 0;  partial = {r.u, u.u, (D^-1 b).(D^-1 b)}
+template <int NC>
+__global__ __launch_bounds__(256) void k_cgs_init(int64_t n, const double *__restrict__ b, double *x,
+                                                  const double *q, const double *__restrict__ dinv,
+                                                  double *vr, double *vu, double *vp, double *vs, int guess,
+                                                  double *partial) {
+  __shared__ double red[4 * 3 * NC];
+  double s[3 * NC];
+#pragma unroll
+  for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
+  OX_ROW_LOOP {
+    const double d = dinv[row];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t i = row * NC + c;
+      const double bi = b[i];
+      double ri = bi;
+      if (guess) ri -= q[i];
+      else x[i] = 0.0;
+      const double ui = d * ri, db = d * bi;
+      vr[i] = ri;
+      vu[i] = ui;
+      vp[i] = 0.0;
+      vs[i] = 0.0;
+      s[c] = fma(ri, ui, s[c]);
+      s[NC + c] = fma(ui, ui, s[NC + c]);
+      s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
+    }
+  }
+  ksp_store_partial<3 * NC>(s, red, partial);
+}
+
+// Single-reduction CG, the whole vector update of an iteration in one pass:
+//   p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = D^-1 r;   partial = {r.u, u.u}
+// (u_old = D^-1 r_old is recomputed, not read: 6 reads + 5 writes per entry, what the two update
+// kernels of the standard recurrences move together)
+template <int NC>
+__global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S, int c0, double *x, double *vr,
+                                                    double *vu, double *vp, double *vs,
+                                                    const double *__restrict__ vw,
+                                                    const double *__restrict__ dinv, double *partial) {
+  __shared__ double red[4 * 2 * NC];
+  if (S->done) return;
+  double alpha[NC], beta[NC], s[2 * NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    alpha[c] = S->alpha[c0 + c];
+    beta[c] = S->beta[c0 + c];
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
+  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t ra, int cb, int64_t rb, bool two) {
+    const double2 w = ox_ld2(vw, e, two);
+    double2 p = ox_ld2(vp, e, two), ss = ox_ld2(vs, e, two), xx = ox_ld2(x, e, two), r = ox_ld2(vr, e, two);
+    const double a0 = ox_sel<NC>(alpha, ca), a1 = ox_sel<NC>(alpha, cb);
+    const double b0 = ox_sel<NC>(beta, ca), b1 = ox_sel<NC>(beta, cb);
+    const double d0 = dinv[ra], d1 = two ? dinv[rb] : 0.0;
+    p.x = fma(b0, p.x, d0 * r.x);
+    p.y = fma(b1, p.y, d1 * r.y);
+    ss.x = fma(b0, ss.x, w.x);
+    ss.y = fma(b1, ss.y, w.y);
+    xx.x = fma(a0, p.x, xx.x);
+    xx.y = fma(a1, p.y, xx.y);
+    r.x = fma(-a0, ss.x, r.x);
+    r.y = fma(-a1, ss.y, r.y);
+    double2 u;
+    u.x = d0 * r.x;
+    u.y = d1 * r.y;
+    ox_st2(vp, e, p, two);
+    ox_st2(vs, e, ss, two);
+    ox_st2(x, e, xx, two);
+    ox_st2(vr, e, r, two);
+    ox_st2(vu, e, u, two);
+    ox_acc<NC>(s, 0, ca, r.x, u.x);
+    ox_acc<NC>(s, NC, ca, u.x, u.x);
+    if (two) {
+      ox_acc<NC>(s, 0, cb, r.y, u.y);
+      ox_acc<NC>(s, NC, cb, u.y, u.y);
+    }
+  });
+  ksp_store_partial<2 * NC>(s, red, partial);
+}
+
 // BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = v = 0
 // partial = {r.r, (D^-1 b).(D^-1 b)}
 template <int NC>
@@ -533,7 +683,7 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KspLayout {
-  size_t state, sums, partial, vec0, vec_stride, narrow0, narrow_stride, total;
+  size_t state, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
 };
 
@@ -543,11 +693,12 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   const int nblk_spmv = (n_slices + 3) / 4;
   const int nb8 = (nblk_spmv + 7) & ~7;
   L.nparts_max = nb8 > OX_VEC_MAX_BLOCKS ? nb8 : OX_VEC_MAX_BLOCKS;
-  L.nvec = ksp_type == OX_KSP_CG ? 4 : 6;
+  L.nvec = ksp_type == OX_KSP_CG ? 4 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   L.partial = L.sums + ox_align(sizeof(double) * 4 * OX_MAXC);
-  L.vec0 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
+  L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
+  L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * OX_MAXC);
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
   L.narrow0 = L.vec0 + L.vec_stride * L.nvec;
   L.narrow_stride = ox_align(sizeof(double) * (size_t)n_cols);
@@ -563,23 +714,26 @@ static KspState *g_state_host = nullptr;
 
 template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
-                          const KspParams &P, const ox_dist *dist, hipStream_t st) {
+                          const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
+  const int nmax = nparts > B.nparts ? nparts : B.nparts;
   if (!dist) {
-    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(ox_red_threads(nparts)), 0, st, S, partial, nparts, nv, P);
+    hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(ox_red_threads(nmax)), 0, st, S, partial, nparts, nv, P, B);
     OX_LAUNCH_CHECK();
     return 0;
   }
-  if (ox_prof_on) ox_prof_start(OX_TAG_SYNC_POINT, st, nv);
+  if (ox_prof_on) ox_prof_start(OX_TAG_SYNC_POINT, st, nv + B.nv);
   if (dist->p2p && dist->nranks > 1 && dist->nranks <= 64) {
-    int threads = ox_red_threads(nparts);
+    int threads = ox_red_threads(nmax);
     if (threads < 64) threads = 64;
     hipLaunchKernelGGL((k_ksp_scalar_p2p<PH>), dim3(1), dim3(threads), 0, st, S, partial, nparts, nv, P,
-                       ox_p2p_next_allreduce(dist));
+                       ox_p2p_next_allreduce(dist), B);
     if (ox_prof_on) ox_prof_stop(st);
     OX_LAUNCH_CHECK();
     return 0;
   }
   if (ox_reduce_partials(partial, nparts, nv, sums, st)) return -1;
+  if (B.nv > 0 && ox_reduce_partials(B.partial, B.nparts, B.nv, sums + nv, st)) return -1;
+  nv += B.nv;  // ONE all-reduce for both arrays
   if (ox_allreduce_impl(dist, sums, nv, st)) return -1;
   hipLaunchKernelGGL((k_ksp_logic<PH>), dim3(1), dim3(64), 0, st, S, sums, P);
   if (ox_prof_on) ox_prof_stop(st);
@@ -602,13 +756,14 @@ __global__ __launch_bounds__(256) void k_insert_col(int64_t n, const double *__r
 struct KspVecs {
   double *x, *r, *z, *p, *q;       // CG (z, q) ...
   double *rhat, *v, *s, *t;        // ... BiCGStab
+  double *u, *w;                   // single-reduction CG: u = D^-1 r, w = A u (s = A p by recurrence)
 };
 
 struct KspCtx {
   const ox_sell *A;
   const double *dinv;
   KspState *S;
-  double *sums, *partial;
+  double *sums, *partial, *partial2;
   const ox_dist *dist;
   hipStream_t st;
   int nb, nbs;
@@ -628,6 +783,25 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
     if (ksp_sync_point<PH_CG_B>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.z, V.p);
     OX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// Single-reduction CG: update kernel, SpMV with the w.u epilogue, ONE synchronisation point (one
+// all-reduce of {r.u, u.u, w.u} in a partitioned run) -- 3 kernels per iteration instead of 5.
+template <int NC>
+static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+  const int64_t n = C.A->n_rows;
+  const int *done = &C.S->done;
+  for (int k = 0; k < count; ++k) {
+    hipLaunchKernelGGL((k_cgs_update<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.u, V.p, V.s, V.w,
+                       C.dinv, C.partial);
+    OX_LAUNCH_CHECK();
+    if (C.dist && ox_halo_forward_impl(C.dist, V.u, NC, C.st)) return -1;
+    if (ox_spmv_launch(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.st)) return -1;
+    if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st,
+                                  KspPart2{C.partial2, C.nbs, NC}))
+      return -1;
   }
   return 0;
 }
@@ -673,6 +847,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.S = reinterpret_cast<KspState *>(work + L.state);
   C.sums = reinterpret_cast<double *>(work + L.sums);
   C.partial = reinterpret_cast<double *>(work + L.partial);
+  C.partial2 = reinterpret_cast<double *>(work + L.partial2);
   C.dist = dist;
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
@@ -680,10 +855,23 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, sizeof(KspState)));
-  const bool cg = ksp_type == OX_KSP_CG;
+  const bool cg = ksp_type == OX_KSP_CG, cgs = ksp_type == OX_KSP_CG_SINGLE;
   KspVecs V{};
   V.x = x;
-  if (cg) {
+  if (cgs) {
+    V.r = vec[0], V.u = vec[1], V.p = vec[2], V.s = vec[3], V.w = vec[4];
+    if (guess) {
+      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
+      if (ox_spmv_launch(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+    }
+    hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.w, dinv, V.r, V.u, V.p, V.s, guess,
+                       C.partial);
+    OX_LAUNCH_CHECK();
+    if (dist && ox_halo_forward_impl(dist, V.u, NC, st)) return -1;
+    if (ox_spmv_launch(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, st)) return -1;
+    if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
+      return -1;
+  } else if (cg) {
     V.r = vec[0], V.z = vec[1], V.p = vec[2], V.q = vec[3];
     if (guess) {
       if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
@@ -704,8 +892,13 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     OX_LAUNCH_CHECK();
     if (ksp_sync_point<PH_BCGS_INIT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, dist, st)) return -1;
   }
+  auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
+    constexpr int N_ = decltype(nc_tag)::value;
+    return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
+               : (cg ? cg_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every));
+  };
   for (int it = 0; it <= P.max_it; it += check_every) {
-    if ((cg ? cg_iterations<NC>(C, V, P, check_every) : bcgs_iterations<NC>(C, V, P, check_every))) return -1;
+    if (iterate(std::integral_constant<int, NC>{}, V, P)) return -1;
     if (ksp_read_state(C)) return -1;
     if (g_state_host->done) break;
     if (NC > 1) {
@@ -722,19 +915,27 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
         KspVecs W{};
         double *src[8] = {V.x, V.r, V.z, V.p, V.q, V.rhat, V.v, nullptr};
         double **dst[8] = {&W.x, &W.r, &W.z, &W.p, &W.q, &W.rhat, &W.v, nullptr};
+        if (cgs) {  // x, r, u, p, s (a recurrence: carried over), w
+          src[2] = V.u, dst[2] = &W.u;
+          src[4] = V.s, dst[4] = &W.s;
+          src[5] = V.w, dst[5] = &W.w;
+          src[6] = nullptr;
+        }
         for (int i = 0; i < 7; ++i) {
           *dst[i] = cv[i];
           if (!src[i]) continue;
           hipLaunchKernelGGL(k_extract_col, dim3(C.nb), dim3(256), 0, st, n, src[i], NC, live, cv[i]);
           OX_LAUNCH_CHECK();
         }
-        W.s = cv[2];  // BiCGStab temporaries share the slots CG uses for z and q
-        W.t = cv[4];
+        if (!cgs) {
+          W.s = cv[2];  // BiCGStab temporaries share the slots CG uses for z and q
+          W.t = cv[4];
+        }
         KspParams P1 = P;
         P1.nc = 1;
         P1.c0 = live;
         for (; it <= P.max_it; it += check_every) {
-          if ((cg ? cg_iterations<1>(C, W, P1, check_every) : bcgs_iterations<1>(C, W, P1, check_every))) return -1;
+          if (iterate(std::integral_constant<int, 1>{}, W, P1)) return -1;
           if (ksp_read_state(C)) return -1;
           if (g_state_host->done) break;
         }
@@ -759,7 +960,8 @@ extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, 
                             int nonzero_guess, int check_every, int max_restarts, void *work,
                             size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
-  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS) OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
+  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE)
+    OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
   if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))
     OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes,

@@ -7,6 +7,9 @@ Option mapping (PETSc string keys, as the reference passes them):
             method run to ``direct_rtol`` (there is no sparse LU on the device; the converged
             reason reported is KSP_CONVERGED_ITS = 4 as PETSc's preonly does)
   pc_type   jacobi (also what lu/ilu/none/unset map to: the only preconditioner on the device)
+  ksp_cg_single_reduction  PETSc's option name: the Chronopoulos-Gear recurrences with one merged
+            reduction (one all-reduce) per iteration; default: true on mesh-partitioned operators,
+            false (PETSc's default, faster there) on a single GPU
   ksp_rtol, ksp_atol, ksp_max_it, ksp_initial_guess_nonzero: as in PETSc (defaults 1e-5,
             1e-50, 10000, false -> the solution vector is zeroed before the solve)
   ksp_bcgs_restarts (extension): BiCGStab restarts allowed after a rho/omega breakdown; default 0
@@ -82,12 +85,22 @@ class KSPSolver:
         o = self._options
         kt = str(o.get("ksp_type", "")).lower()
         direct = kt == "preonly"
+        # "cg" on a mesh-partitioned operator runs the single-reduction recurrences (PETSc's
+        # -ksp_cg_single_reduction, Chronopoulos-Gear: ONE merged reduction = one all-reduce per iteration,
+        # 3 kernels instead of 5); same Krylov space, same convergence test, iteration counts within +-2 of
+        # the standard recurrences (rounding only).  On ONE GPU the standard recurrences stay the default:
+        # measured at 128^3 the pressure iteration takes 93.8 us single-reduction against 80.7 us standard
+        # (one more vector: matrix + vectors no longer fit the 256 MB Infinity Cache between iterations).
+        # The option forces either.
+        dflt = self._A is not None and self._A.pattern.dist is not None
+        single = o.get("ksp_cg_single_reduction", dflt) not in (False, 0, "false", "0", "False")
+        cg = _lib.KSP_CG_SINGLE if single else _lib.KSP_CG
         if kt == "cg":
-            meth = _lib.KSP_CG
+            meth = cg
         elif kt in ("bcgs", "bicgstab"):
             meth = _lib.KSP_BCGS
         else:
-            meth = _lib.KSP_CG if (self._A is not None and self._A.symmetric) else _lib.KSP_BCGS
+            meth = cg if (self._A is not None and self._A.symmetric) else _lib.KSP_BCGS
         if direct:
             return meth, DIRECT_RTOL, 1e-50, 20000, True
         return (meth, float(o.get("ksp_rtol", 1e-5)), float(o.get("ksp_atol", 1e-50)),
