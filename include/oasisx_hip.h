@@ -70,6 +70,13 @@ typedef struct {
    * meshes of congruent cells): vals[e] == vdict[vcode[e]] bit for bit; used with cols16 */
   const uint8_t *vcode;      /* device [slice_ptr[n_slices]]                                */
   const double *vdict;       /* device [n_dict]                                             */
+  /* optional, mesh-partitioned operators: the slices listed with the INTERIOR ones first (no ghost
+   * column in any of their rows), then the boundary ones.  With it the distributed mat-vecs start
+   * the halo exchange, multiply the interior slices while it is in flight, and finish with the
+   * boundary slices (DOLFINx/PETSc do the same inside MatMult; reference fracstep.py:453,497,632). */
+  const int32_t *ib_slices;  /* device [n_slices] or NULL                                   */
+  int32_t n_interior;        /* leading entries of ib_slices that are interior              */
+  int32_t reserved2;
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */

@@ -34,6 +34,9 @@ class ox_sell(C.Structure):
         ("cbase", C.c_void_p),
         ("vcode", C.c_void_p),
         ("vdict", C.c_void_p),
+        ("ib_slices", C.c_void_p),
+        ("n_interior", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 

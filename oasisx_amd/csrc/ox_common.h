@@ -62,6 +62,9 @@ struct ox_dist {
   int (*allreduce_cb)(void *user, double *buf_dev, int n);
   void *user;
   ox_p2p *p2p;  // non-NULL: halo exchange and all-reduce go over the xGMI windows
+  // RCCL transport, overlapped exchange: the pack + send/recv run on a side stream between two events
+  hipStream_t side;
+  hipEvent_t ev_begin, ev_done;
 };
 
 // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give every XCD a
@@ -98,4 +101,8 @@ static inline hipStream_t ox_stream(void *s) { return reinterpret_cast<hipStream
 
 // Internal launchers shared between translation units.
 int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st);
+// the same exchange in two halves: work enqueued on `st` between begin and end overlaps with it and
+// must not touch the ghost block of x
+int ox_halo_begin_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st);
+int ox_halo_end_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st);
 int ox_allreduce_impl(const ox_dist *d, double *buf, int n, hipStream_t st);

@@ -322,7 +322,7 @@ ox_p2p_ar ox_p2p_next_allreduce(const ox_dist *d) {
   return a;
 }
 
-static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
+static int p2p_halo_push(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
   ox_p2p *q = d->p2p;
   const unsigned long long seq = ++q->hseq;
   const int parity = (int)(seq & 1);
@@ -332,6 +332,13 @@ static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t 
   hipLaunchKernelGGL(k_halo_push, dim3(nblk), dim3(256), 0, st, x, d->send_idx, ns, ncomp, q->send_off_dev,
                      d->n_peers, q->r_stage, q->r_off, q->r_hflag, parity, seq, q->ticket);
   OX_LAUNCH_CHECK();
+  return 0;
+}
+
+static int p2p_halo_pull(const ox_dist *d, double *x, int ncomp, hipStream_t st) {  // of the latest push
+  ox_p2p *q = d->p2p;
+  const unsigned long long seq = q->hseq;
+  const int parity = (int)(seq & 1);
   const P2pLayout L = p2p_layout(d->nranks, d->n_ghost);
   const int64_t ng = d->n_ghost * ncomp;
   unsigned nb2 = (unsigned)((ng + 255) / 256);
@@ -345,6 +352,11 @@ static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t 
   return 0;
 }
 
+static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
+  if (p2p_halo_push(d, x, ncomp, st)) return -1;
+  return p2p_halo_pull(d, x, ncomp, st);
+}
+
 static int p2p_allreduce(const ox_dist *d, double *buf, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(64), 0, st, buf, n, ox_p2p_next_allreduce(d));
   OX_LAUNCH_CHECK();
@@ -355,6 +367,12 @@ extern "C" int ox_dist_destroy(ox_dist *d) {
   if (!d) return 0;
   ox_dist_disable_p2p(d);
   if (d->send_buf) (void)hipFree(d->send_buf);
+  if (d->side) {
+    (void)hipStreamSynchronize(d->side);
+    (void)hipEventDestroy(d->ev_begin);
+    (void)hipEventDestroy(d->ev_done);
+    (void)hipStreamDestroy(d->side);
+  }
   free(d->peers);
   free(d->send_off);
   free(d->recv_off);
@@ -379,6 +397,32 @@ int ox_halo_forward_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st)
   const int rc = d->p2p ? p2p_halo_forward(d, x, ncomp, st) : halo_forward_rccl_or_cb(d, x, ncomp, st);
   if (ox_prof_on) ox_prof_stop(st);
   return rc;
+}
+
+int ox_halo_begin_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
+  if (!d || d->n_peers == 0) return 0;
+  if (d->p2p) return p2p_halo_push(d, x, ncomp, st);
+  if (d->halo_cb || !d->comm) return halo_forward_rccl_or_cb(d, x, ncomp, st);  // synchronous transport: all of it now
+  // RCCL: pack + grouped send/recv on the side stream, behind everything enqueued on `st` so far
+  ox_dist *m = const_cast<ox_dist *>(d);
+  if (!m->side) {
+    OX_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    OX_HIP(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
+    OX_HIP(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+  }
+  OX_HIP(hipEventRecord(m->ev_begin, st));
+  OX_HIP(hipStreamWaitEvent(m->side, m->ev_begin, 0));
+  if (halo_forward_rccl_or_cb(d, x, ncomp, m->side)) return -1;
+  OX_HIP(hipEventRecord(m->ev_done, m->side));
+  return 0;
+}
+
+int ox_halo_end_impl(const ox_dist *d, double *x, int ncomp, hipStream_t st) {
+  if (!d || d->n_peers == 0) return 0;
+  if (d->p2p) return p2p_halo_pull(d, x, ncomp, st);
+  if (d->halo_cb || !d->comm) return 0;
+  OX_HIP(hipStreamWaitEvent(st, d->ev_done, 0));
+  return 0;
 }
 
 static int halo_forward_rccl_or_cb(const ox_dist *d, double *x, int ncomp, hipStream_t st) {

@@ -14,12 +14,13 @@
                                       // measured 10 % slower: r01 notes in DESIGN.md)
 #define OX_MAX_NV 12            // most sums reduced at one synchronisation point (4 * OX_MAXC: single-reduction CG init)
 
-static inline int ox_spmv_blocks(const ox_sell *A) {
-  const int ngroups = (A->n_slices + 3) / 4;
+static inline int ox_spmv_blocks_n(int n_slices) {
+  const int ngroups = (n_slices + 3) / 4;
   if (ngroups == 0) return 0;
   const int g8 = (ngroups + 7) & ~7;
   return g8 > OX_SPMV_MAX_BLOCKS ? OX_SPMV_MAX_BLOCKS : g8;
 }
+static inline int ox_spmv_blocks(const ox_sell *A) { return ox_spmv_blocks_n(A->n_slices); }
 
 static inline int ox_vec_blocks(int64_t n) {
   int64_t b = (n / 2 + 255) / 256;
@@ -89,6 +90,11 @@ __device__ __forceinline__ void ox_block_sum_wide(double (&v)[OX_MAX_NV], int nv
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
                    hipStream_t st);
+// distributed mat-vec (halo exchange overlapped with the interior slices where the operator carries the
+// interior / boundary split) and the number of per-block partials its fused epilogue writes
+int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
+                 double *partial, const int *done, const ox_dist *dist, hipStream_t st);
+int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist);
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st);
 
 // ---- optional per-kernel HIP-event timing (bench.py: roofline.achieved is measured live, on the

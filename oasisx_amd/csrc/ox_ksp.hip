@@ -692,7 +692,7 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   const int n_slices = (int)((n_rows + 63) / 64);
   const int nblk_spmv = (n_slices + 3) / 4;
   const int nb8 = (nblk_spmv + 7) & ~7;
-  L.nparts_max = nb8 > OX_VEC_MAX_BLOCKS ? nb8 : OX_VEC_MAX_BLOCKS;
+  L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
   L.nvec = ksp_type == OX_KSP_CG ? 4 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
@@ -774,8 +774,7 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    if (C.dist && ox_halo_forward_impl(C.dist, V.p, NC, C.st)) return -1;
-    if (ox_spmv_launch(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.st)) return -1;
+    if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_CG_A>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.z, V.p, V.q,
                        C.dinv, C.partial);
@@ -797,8 +796,7 @@ static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
     hipLaunchKernelGGL((k_cgs_update<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.u, V.p, V.s, V.w,
                        C.dinv, C.partial);
     OX_LAUNCH_CHECK();
-    if (C.dist && ox_halo_forward_impl(C.dist, V.u, NC, C.st)) return -1;
-    if (ox_spmv_launch(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.st)) return -1;
+    if (ox_spmv_dist(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st,
                                   KspPart2{C.partial2, C.nbs, NC}))
       return -1;
@@ -813,13 +811,11 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
-    if (C.dist && ox_halo_forward_impl(C.dist, V.p, NC, C.st)) return -1;
-    if (ox_spmv_launch(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.st)) return -1;
+    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
-    if (C.dist && ox_halo_forward_impl(C.dist, V.s, NC, C.st)) return -1;
-    if (ox_spmv_launch(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.st)) return -1;
+    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGS_2>(C.S, C.partial, C.nbs, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
                        V.t, C.partial);
@@ -851,7 +847,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.dist = dist;
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
-  C.nbs = ox_spmv_blocks(A);
+  C.nbs = ox_spmv_dist_nparts(A, dist);
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, sizeof(KspState)));
@@ -861,21 +857,18 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   if (cgs) {
     V.r = vec[0], V.u = vec[1], V.p = vec[2], V.s = vec[3], V.w = vec[4];
     if (guess) {
-      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
-      if (ox_spmv_launch(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+      if (ox_spmv_dist(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
     hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.w, dinv, V.r, V.u, V.p, V.s, guess,
                        C.partial);
     OX_LAUNCH_CHECK();
-    if (dist && ox_halo_forward_impl(dist, V.u, NC, st)) return -1;
-    if (ox_spmv_launch(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, st)) return -1;
+    if (ox_spmv_dist(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, dist, st)) return -1;
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
       return -1;
   } else if (cg) {
     V.r = vec[0], V.z = vec[1], V.p = vec[2], V.q = vec[3];
     if (guess) {
-      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
-      if (ox_spmv_launch(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+      if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
     hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.q, dinv, V.r, V.z, V.p, guess,
                        C.partial);
@@ -884,8 +877,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   } else {
     V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
     if (guess) {
-      if (dist && ox_halo_forward_impl(dist, x, NC, st)) return -1;
-      if (ox_spmv_launch(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st)) return -1;
+      if (ox_spmv_dist(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
     hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.t, dinv, V.r, V.rhat, V.p, V.v,
                        guess, C.partial);

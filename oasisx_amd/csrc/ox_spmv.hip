@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
                                               const double *__restrict__ dinv,
                                               const double *__restrict__ aux,
                                               double *__restrict__ partial,
-                                              const int *__restrict__ done_flag) {
+                                              const int *__restrict__ done_flag,
+                                              const int32_t *__restrict__ slice_list, int n_list) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
   __shared__ double red[4 * NV];
   __shared__ double dict[(VAR & 4) ? 256 : 1];
@@ -47,7 +48,9 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   // Persistent grid (<= OX_SPMV_MAX_BLOCKS blocks, a multiple of 8): the blocks that share an XCD
   // (equal blockIdx % 8) stride together over ONE contiguous eighth of the slice groups, so
   // at any time an XCD's L2 serves a compact window of rows and of x.
-  const int ngroups = (A.n_slices + 3) >> 2;
+  // slice_list (interior / boundary split of a partitioned operator): the launch covers that list
+  const int n_sl = slice_list ? n_list : A.n_slices;
+  const int ngroups = (n_sl + 3) >> 2;
   const int per = gridDim.x >> 3;
   const int chunk = (ngroups + 7) >> 3;
   const int xcd = blockIdx.x & 7;
@@ -58,8 +61,9 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 #pragma unroll
   for (int i = 0; i < NV; ++i) s[i] = 0.0;
   for (int g = g_begin + (blockIdx.x >> 3); g < g_end; g += per) {
-    const int slice = __builtin_amdgcn_readfirstlane(g * 4 + wave);  // wave-uniform: scalar loads below
-    if (slice >= A.n_slices) continue;
+    const int li = g * 4 + wave;
+    if (li >= n_sl) continue;
+    const int slice = __builtin_amdgcn_readfirstlane(slice_list ? slice_list[li] : li);  // wave-uniform: scalar loads below
     const int64_t row = (int64_t)slice * 64 + lane;
     double acc[NC];
 #pragma unroll
@@ -163,10 +167,10 @@ extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench
   return 0;
 }
 
-int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
-                   const double *dinv, const double *aux, double *partial, const int *done,
-                   hipStream_t st) {
-  const int nblk = ox_spmv_blocks(A);
+static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
+                            const double *dinv, const double *aux, double *partial, const int *done,
+                            hipStream_t st, const int32_t *list, int n_list) {
+  const int nblk = list ? ox_spmv_blocks_n(n_list) : ox_spmv_blocks(A);
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
@@ -177,7 +181,7 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
-  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done)
+  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
@@ -201,16 +205,51 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   OX_FAIL("ox_spmv: unsupported ncomp=%d epi=%d", ncomp, epi);
 }
 
+int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
+                   const double *dinv, const double *aux, double *partial, const int *done,
+                   hipStream_t st) {
+  return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, nullptr, 0);
+}
+
+static int g_overlap = -1;
+static bool ox_overlap_on(const ox_sell *A, const ox_dist *dist) {
+  if (g_overlap < 0) {
+    const char *e = getenv("OX_HALO_OVERLAP");
+    g_overlap = e ? atoi(e) : 1;
+  }
+  return g_overlap && dist && dist->n_peers > 0 && A->ib_slices && A->n_interior > 0;
+}
+
+int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist) {
+  if (!ox_overlap_on(A, dist)) return ox_spmv_blocks(A);
+  return ox_spmv_blocks_n(A->n_interior) + ox_spmv_blocks_n(A->n_slices - A->n_interior);
+}
+
+// y = A x with the ghost block of x refreshed: halo exchange started, interior slices multiplied
+// while it is in flight, boundary slices after it has landed (or exchange-then-multiply without the split)
+int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
+                 double *partial, const int *done, const ox_dist *dist, hipStream_t st) {
+  if (!ox_overlap_on(A, dist)) {
+    if (dist && ox_halo_forward_impl(dist, x, ncomp, st)) return -1;
+    return ox_spmv_launch(A, x, y, ncomp, epi, dinv, aux, partial, done, st);
+  }
+  if (ox_prof_on) ox_prof_start(OX_TAG_HALO, st, ncomp);
+  if (ox_halo_begin_impl(dist, x, ncomp, st)) return -1;
+  if (ox_prof_on) ox_prof_stop(st);
+  const int nv = (epi == OX_EPI_NONE) ? 0 : (epi == OX_EPI_BCGS_T ? 2 * ncomp : ncomp);
+  const int nb_int = ox_spmv_blocks_n(A->n_interior);
+  if (spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, A->ib_slices, A->n_interior)) return -1;
+  if (ox_halo_end_impl(dist, x, ncomp, st)) return -1;
+  return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial ? partial + (size_t)nb_int * nv : nullptr, done, st,
+                          A->ib_slices + A->n_interior, A->n_slices - A->n_interior);
+}
+
 extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
                        const ox_dist *dist, void *stream) {
   if (!A || !x || !y) OX_FAIL("ox_spmv: null argument");
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_spmv: ncomp=%d out of range", ncomp);
   hipStream_t st = ox_stream(stream);
-  if (dist) {
-    int rc = ox_halo_forward_impl(dist, const_cast<double *>(x), ncomp, st);
-    if (rc) return rc;
-  }
-  return ox_spmv_launch(A, x, y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, st);
+  return ox_spmv_dist(A, const_cast<double *>(x), y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -137,6 +137,7 @@ class SellPattern:
         self.dist = None  # ox_dist* (halo plan) of the column space, mesh-partitioned runs
         self.cols16 = self.cbase = None  # 16-bit column stream, built by struct() on the GPU
         self.frac16 = 0.0
+        self.ib_slices, self.n_interior = None, 0  # interior / boundary split (split_interior)
         # width bins for the LDS-accumulating row kernels
         w = torch.from_numpy(widths.astype(np.int64))
         order = torch.argsort(w, stable=True)
@@ -145,6 +146,21 @@ class SellPattern:
         self.bin_width = uw.numpy().astype(np.int32)
         self.bin_ptr = np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64)
         self.bin_slices = order.to(torch.int32).to(self.device)
+
+    def split_interior(self, n_owned: int):
+        """Mesh-partitioned operators: list the slices with the interior ones first (no ghost column,
+        i.e. no column >= n_owned, in any row), then the boundary ones -- the distributed mat-vecs
+        multiply the former while the halo exchange is in flight (``ox_sell.ib_slices``)."""
+        if self.n_slices == 0 or self.size == 0:
+            return
+        width = torch.from_numpy(self.widths.astype(np.int64)).to(self.device) * SLICE
+        sl = torch.repeat_interleave(torch.arange(self.n_slices, device=self.device), width)
+        ghost = torch.zeros(self.n_slices, dtype=torch.int32, device=self.device)
+        ghost.index_put_((sl,), (self.cols >= n_owned).to(torch.int32), accumulate=True)
+        interior = torch.nonzero(ghost == 0).reshape(-1)
+        boundary = torch.nonzero(ghost > 0).reshape(-1)
+        self.ib_slices = torch.cat([interior, boundary]).to(torch.int32).contiguous()
+        self.n_interior = int(interior.shape[0])
 
     def new_values(self) -> torch.Tensor:
         return torch.zeros(self.size, dtype=torch.float64, device=self.device)
@@ -166,8 +182,11 @@ class SellPattern:
                                                              _lib.current_stream()), "ox_sell_compress_cols")
                 self.frac16 = n16.value / self.size  # share of the stored entries read as 16 bit
             c16, cb = self.cols16.data_ptr(), self.cbase.data_ptr()
-        return _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
-                            self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
+        S = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(),
+                         self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
+        if self.ib_slices is not None:
+            S.ib_slices, S.n_interior = self.ib_slices.data_ptr(), self.n_interior
+        return S
 
     def bins_args(self):
         return (int(self.bin_width.shape[0]), self.bin_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
@@ -507,6 +526,7 @@ class FunctionSpace:
         def host_transport():
             self.dist = comm.make_transport(self)
             self.pattern.dist = self.dist
+            self.pattern.split_interior(self.n_owned)
             self.check_halo()
             comm.active[self.degree] = "host"
 
@@ -523,6 +543,7 @@ class FunctionSpace:
         if want in ("auto", "p2p") and comm.enable_p2p(self, out):
             self.dist = out
             self.pattern.dist = out
+            self.pattern.split_interior(self.n_owned)
             comm.active[self.degree] = "p2p"
             return
         if want == "p2p":
@@ -535,6 +556,7 @@ class FunctionSpace:
             return
         self.dist = out
         self.pattern.dist = out
+        self.pattern.split_interior(self.n_owned)
         self.check_halo()
         comm.active[self.degree] = "rccl"
 
