@@ -536,11 +536,13 @@ def main():
         print(json.dumps({"pmc_child": True, "kernel_prefix": f"voidk_spmv<1,1,{var}>", "grid_size": grid}), flush=True)
         return
 
-    transport_check = None
+    transport_check = transport_us = None
     if world > 1:  # the transports once more after the timed steps: every ghost dof must still get its owner's value
         S._Vi[0][0].check_halo()
         S._Q.check_halo()
         transport_check = "halo self-test passed after the timed steps"
+        # both device transports' exchange times, measured here (collective)
+        transport_us = {"velocity_space": comm.time_transports(S._Vi[0][0]), "pressure_space": comm.time_transports(S._Q)}
     nnz_glob = [Pu.nnz, Pp.nnz]
     if world > 1:
         import torch.distributed as dist
@@ -567,7 +569,7 @@ def main():
                                      "/".join(sorted(set(comm.active.values()))) or "none")
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
                        if world > 1 else None,
-                       "transport_check": transport_check},
+                       "transport_check": transport_check, "transport_exchange_us": transport_us},
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,

@@ -166,6 +166,65 @@ class Comm:
                    "ox_dist_p2p_timeout")
         return True
 
+    def time_transports(self, V, reps: int = 200) -> dict:
+        """Exchange micro-benchmark of the halo plan of ``V`` on every transport this job can bring up
+        (collective; bench.py's N > 1 line): microseconds per halo exchange (one and gdim components) and
+        per 9-value all-reduce, HIP-event timed, back to back.  The active plan is timed as it is; the
+        other device transport (RCCL <-> xGMI windows) on a temporary plan."""
+        import torch
+
+        lib = _lib.load()
+        if V.halo is None or V.dist is None:
+            return {}
+        dev = V.mesh.device
+        d = V.mesh.gdim
+        st = _lib.current_stream()
+
+        def timed(plan):
+            X = V.x.clone().contiguous()
+            x1 = X[:, 0].contiguous()
+            buf = torch.ones(9, dtype=torch.float64, device=dev)
+            out = {}
+            for name, call in (("halo_1comp_us", lambda: lib.ox_halo_forward(plan, _lib.ptr(x1), 1, st)),
+                               (f"halo_{d}comp_us", lambda: lib.ox_halo_forward(plan, _lib.ptr(X), d, st)),
+                               ("allreduce_9_us", lambda: lib.ox_allreduce_sum(plan, _lib.ptr(buf), 9, st))):
+                for _ in range(10):
+                    _lib.check(call(), name)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    buf.fill_(1.0)
+                    _lib.check(call(), name)
+                e1.record()
+                torch.cuda.synchronize()
+                out[name] = 1e3 * e0.elapsed_time(e1) / reps
+            _lib.check(lib.ox_dist_status(plan), "ox_dist_status")
+            return out
+
+        active = self.active.get(V.degree, "?")
+        res = {active: timed(V.dist)}
+        h = V.halo
+        other = "p2p" if active == "rccl" else ("rccl" if active == "p2p" and self.handle is not None else None)
+        if other is not None:
+            tmp = C.c_void_p()
+            _lib.check(lib.ox_dist_create(self.handle, self.rank, self.size, int(h["peers"].shape[0]),
+                                          h["peers"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                          h["send_off"].ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(h["send_idx"]),
+                                          h["recv_off"].ctypes.data_as(C.POINTER(C.c_int64)), V.n_owned,
+                                          V.n_local - V.n_owned, C.byref(tmp)), "ox_dist_create")
+            keep = V.dist
+            try:
+                if other == "rccl":
+                    res["rccl"] = timed(tmp)
+                elif self.enable_p2p(V, tmp):  # self-tested, collectively agreed
+                    res["p2p"] = timed(tmp)
+                else:
+                    res["p2p"] = {"error": getattr(self, "p2p_error", "a peer rank failed")}
+            finally:
+                V.dist = keep
+                lib.ox_dist_destroy(tmp)
+        return res
+
     def allreduce(self, v, op=None):
         import torch.distributed as dist
 
