@@ -77,6 +77,19 @@ typedef struct {
   const int32_t *ib_slices;  /* device [n_slices] or NULL                                   */
   int32_t n_interior;        /* leading entries of ib_slices that are interior              */
   int32_t reserved2;
+  /* optional pair-slot stream of a value-dictionary matrix (ox_pair_stream_size / _fill; all NULL =
+   * not built).  A slot multiplies TWO adjacent columns: y += vdict[a] * x[col] + vdict[b] * x[col+1],
+   * one 16-byte gather instead of two 8-byte ones -- the SpMV on these matrices is bound by the number
+   * of vector-memory instructions (16 cycles of the address unit each), not by bytes.
+   * Slots keep the stored order of the row's entries (an entry whose successor is the next column
+   * shares its slot; any other entry gets b = the code of 0.0), so sums are bit-identical. */
+  const int64_t *ps_ptr;     /* device [n_slices+1], offsets into ps_code, multiples of 256;
+                                bit 0 set by _fill: that slice is read from cols / vcode      */
+  const uint32_t *ps_code;   /* device [ps_ptr[n_slices]]; slot j of lane l of slice s at
+                                ps_ptr[s] + (j/4)*256 + l*4 + j%4: bits 0-14 column offset, bit 15
+                                which base, bits 16-23 code a, bits 24-31 code b                */
+  const int32_t *ps_base;    /* device [ps_ptr[n_slices] / 256][2] column bases per group of 4
+                                slots x 64 lanes                                                */
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */
@@ -180,6 +193,15 @@ int ox_rect_destroy(ox_rect *rect);
  * slot, ncomp 2..3: one uint32 per slot, byte c = code of component c).  More: *n_dict = 0. */
 int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *codes, double *dict, int *n_dict,
                         void *stream);
+/* Pair-slot stream of a matrix that carries a value dictionary (A->vcode, A->vdict, ncomp == 1) whose
+ * dictionary contains 0.0.  row_len: device [n_rows] entries per row (ox_pattern_info.row_len).
+ * _size writes ps_ptr (device [n_slices+1]) and returns the number of uint32 codes in *n_codes (0: not
+ * available for this matrix); _fill writes ps_code [n_codes] and ps_base [n_codes/256][2], marks in
+ * ps_ptr (bit 0) the slices whose columns do not fit two 15-bit windows per group -- they keep their
+ * int32 columns -- and returns their number in *n_wide.  Then set A->ps_ptr / ps_code / ps_base. */
+int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, void *stream);
+int ox_pair_stream_fill(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, uint32_t *ps_code,
+                        int32_t *ps_base, int64_t *n_wide, void *stream);
 /* plain device memory for callers without a device array library (numpy + ctypes) */
 int ox_malloc(size_t bytes, void **out);
 int ox_free(void *p);

@@ -37,6 +37,9 @@ class ox_sell(C.Structure):
         ("ib_slices", C.c_void_p),
         ("n_interior", C.c_int32),
         ("reserved2", C.c_int32),
+        ("ps_ptr", C.c_void_p),
+        ("ps_code", C.c_void_p),
+        ("ps_base", C.c_void_p),
     ]
 
 
@@ -147,6 +150,8 @@ SIGNATURES = {
     "ox_rect_view": (_I, [_P, C.POINTER(ox_rect_info)]),
     "ox_rect_destroy": (_I, [_P]),
     "ox_value_dictionary": (_I, [_P, _L, _I, _P, _P, C.POINTER(_I), _P]),
+    "ox_pair_stream_size": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _P]),
+    "ox_pair_stream_fill": (_I, [C.POINTER(ox_sell), _P, _P, _P, _P, C.POINTER(_L), _P]),
     "ox_malloc": (_I, [C.c_size_t, C.POINTER(_P)]),
     "ox_free": (_I, [_P]),
     "ox_memset": (_I, [_P, _I, C.c_size_t, _P]),

@@ -1136,6 +1136,168 @@ extern "C" int ox_value_dictionary(const double *vals, int64_t n_slots, int ncom
   return 0;
 }
 
+// ---- pair-slot stream (include/oasisx_hip.h, ox_sell.ps_*) -----------------------------------------------
+namespace {
+__device__ __forceinline__ int ps_wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int ps_wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// entry k of lane `lane` of the slice that starts at `base`
+__device__ __forceinline__ int64_t ps_slot(int64_t base, int k, int lane) {
+  return base + (int64_t)(k / KV) * (SLICE * KV) + lane * KV + (k % KV);
+}
+
+// one wave per slice, lane = row: walk the row's stored entries, an entry whose successor is the next
+// column shares its slot.  FILL = false: slots of the slice (max over its rows, padded to 4) * 64.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *__restrict__ row_len, int zero_code,
+                                                     int64_t *__restrict__ ps_len, int64_t *__restrict__ ps_ptr,
+                                                     uint32_t *__restrict__ ps_code, int32_t *__restrict__ ps_base,
+                                                     unsigned long long *__restrict__ n_wide) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); slice < A.n_slices; slice += (int64_t)gridDim.x * 4) {
+    const int64_t row = slice * SLICE + lane;
+    const int len = row < A.n_rows ? row_len[row] : 0;
+    const int64_t base = A.slice_ptr[slice];
+    if (!FILL) {
+      int slots = 0;
+      for (int k = 0; k < len; ++slots) {
+        const int c = A.cols[ps_slot(base, k, lane)];
+        k += (k + 1 < len && A.cols[ps_slot(base, k + 1, lane)] == c + 1) ? 2 : 1;
+      }
+      const int m = ps_wave_max(slots);
+      if (lane == 0) ps_len[slice] = (int64_t)((m + 3) & ~3) * SLICE;
+      continue;
+    }
+    const int64_t pb = ps_ptr[slice] & ~(int64_t)255;  // (a neighbour may already carry its flag bit)
+    const int ngroups = (int)(((ps_ptr[slice + 1] & ~(int64_t)255) - pb) >> 8);
+    const int BIG = 0x7fffffff;
+    const int pad_col = (int)min(max(row, (int64_t)0), A.n_cols - 2);  // x[pad_col], x[pad_col+1] exist
+    bool ok = true;
+    int k = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      int c[4];
+      unsigned vv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k < len) {
+          int cc = A.cols[ps_slot(base, k, lane)];
+          unsigned a = A.vcode[ps_slot(base, k, lane)], b = (unsigned)zero_code;
+          if (k + 1 < len && A.cols[ps_slot(base, k + 1, lane)] == cc + 1) {
+            b = A.vcode[ps_slot(base, k + 1, lane)];
+            k += 2;
+          } else {
+            k += 1;
+            if (cc == A.n_cols - 1) {  // x[cc+1] does not exist: the slot starts one column earlier, a = 0
+              cc -= 1;
+              b = a;
+              a = (unsigned)zero_code;
+            }
+          }
+          c[j] = cc;
+          vv[j] = a | (b << 8);
+        } else {
+          c[j] = pad_col;
+          vv[j] = (unsigned)zero_code | ((unsigned)zero_code << 8);
+        }
+      }
+      const int lo = ps_wave_min(min(min(c[0], c[1]), min(c[2], c[3])));
+      bool far[4];
+      int mn = BIG, mx = -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        far[j] = c[j] - lo >= 32768;
+        if (far[j]) {
+          mn = min(mn, c[j]);
+          mx = max(mx, c[j]);
+        }
+      }
+      const int lo2 = ps_wave_min(mn), hi2 = ps_wave_max(mx);
+      const bool fits = (lo2 == BIG) || (hi2 - lo2 < 32768);
+      ok = ok && fits;
+      uint4 out;
+      unsigned *o = reinterpret_cast<unsigned *>(&out);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned off = !fits ? 0u : (far[j] ? (0x8000u | (unsigned)(c[j] - lo2)) : (unsigned)(c[j] - lo));
+        o[j] = off | (vv[j] << 16);
+      }
+      reinterpret_cast<uint4 *>(ps_code + pb)[(int64_t)g * SLICE + lane] = out;
+      if (lane == 0) {
+        ps_base[((pb >> 8) + g) * 2] = lo;
+        ps_base[((pb >> 8) + g) * 2 + 1] = lo2 == BIG ? lo : lo2;
+      }
+    }
+    if (lane == 0 && ngroups > 0 && !ok) {  // the kernel learns it with the offset: one round trip less
+      ps_ptr[slice] = pb | 1;
+      atomicAdd(n_wide, 1ull);
+    }
+  }
+}
+
+// code of +0.0 in the matrix's dictionary, or -1
+int ps_zero_code(const ox_sell *A, hipStream_t st) {
+  if (!A->vdict || A->n_dict < 1 || A->n_dict > 256) return -1;
+  long long h[256];
+  if (hipMemcpyAsync(h, A->vdict, sizeof(long long) * A->n_dict, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  for (int i = 0; i < A->n_dict; ++i)
+    if (h[i] == 0) return i;
+  return -1;
+}
+}  // namespace
+
+extern "C" int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes,
+                                   void *stream) {
+  if (!A || !row_len || !ps_ptr || !n_codes) OX_FAIL("ox_pair_stream_size: null argument");
+  hipStream_t st = ox_stream(stream);
+  *n_codes = 0;
+  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2) return 0;
+  const int zc = ps_zero_code(A, st);
+  if (zc < 0) return 0;  // no 0.0 in the dictionary: singles cannot be expressed
+  DevBuf len;
+  OX_TRY(len.alloc(sizeof(int64_t) * ((size_t)A->n_slices + 1)));
+  OX_HIP(hipMemsetAsync(len.p, 0, len.bytes, st));
+  const unsigned nb = (unsigned)std::min<int64_t>(((int64_t)A->n_slices + 3) / 4, 1 << 20);
+  hipLaunchKernelGGL(k_pair_stream<false>, dim3(nb), dim3(256), 0, st, *A, row_len, zc, len.as<int64_t>(), nullptr, nullptr,
+                     nullptr, nullptr);
+  OX_LAUNCH_CHECK();
+  OX_TRY(exclusive_scan_i64(len.as<int64_t>(), ps_ptr, (size_t)A->n_slices + 1, st));
+  int64_t total = 0;
+  OX_HIP(hipMemcpyAsync(&total, ps_ptr + A->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  *n_codes = total;
+  return 0;
+}
+
+extern "C" int ox_pair_stream_fill(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, uint32_t *ps_code,
+                                   int32_t *ps_base, int64_t *n_wide, void *stream) {
+  if (!A || !row_len || !ps_ptr || !ps_code || !ps_base) OX_FAIL("ox_pair_stream_fill: null argument");
+  hipStream_t st = ox_stream(stream);
+  if (n_wide) *n_wide = 0;
+  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2) OX_FAIL("ox_pair_stream_fill: matrix has no value codes");
+  const int zc = ps_zero_code(A, st);
+  if (zc < 0) OX_FAIL("ox_pair_stream_fill: no 0.0 in the value dictionary");
+  DevBuf cnt;
+  OX_TRY(cnt.alloc(sizeof(unsigned long long)));
+  OX_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes, st));
+  const unsigned nb = (unsigned)std::min<int64_t>(((int64_t)A->n_slices + 3) / 4, 1 << 20);
+  hipLaunchKernelGGL(k_pair_stream<true>, dim3(nb), dim3(256), 0, st, *A, row_len, zc, nullptr, ps_ptr, ps_code, ps_base,
+                     cnt.as<unsigned long long>());
+  OX_LAUNCH_CHECK();
+  unsigned long long h = 0;
+  OX_HIP(hipMemcpyAsync(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  if (n_wide) *n_wide = (int64_t)h;
+  return 0;
+}
+
 // ---- plain device memory for callers without a device array library (numpy + ctypes) ----------------
 extern "C" int ox_malloc(size_t bytes, void **out) {
   if (!out) OX_FAIL("ox_malloc: null argument");

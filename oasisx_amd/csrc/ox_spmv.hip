@@ -158,12 +158,184 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   }
 }
 
-// bit 0: nontemporal matrix stream; bit 1: 16-bit column stream, bit 2: 1-byte value codes, each
-// where the matrix carries them (measured: tools/spmv_bench.py)
-#define OX_SPMV_DEFAULT_VARIANT 7
+
+// ---------------------------------------------------------------------------------------
+// k_spmv_ps: y = A x from the pair-slot stream of a value-dictionary matrix (ox_sell.ps_*).
+// What bounds k_spmv<., ., 7>: the address unit takes ~16-20 cycles per vector-memory instruction of a
+// wave whatever its width (tools/ubench/dispatch_rate.hip: 16 loads per wave cost 20.5 us on this grid
+// as ushort, dword, dwordx2 or dwordx4, from L1, L2 or the Infinity Cache alike), and a 64-row slice of
+// the pressure matrix issues 35 of them (16 gathers of 8 B, 8 + 8 code loads, epilogue): 34 us at
+// 128^3 however the wave is scheduled; without the gathers 16 us.  So: fewer, wider instructions.
+// One slot = two adjacent columns = one 16-B gather (NC = 1); four slots = one 16-B code load.
+// The same per-row order of fused multiply-adds as k_spmv: bit-identical results.
+// A wave's dependent memory rounds: (A) done flag, ps_ptr, dictionary, epilogue operands;
+// (B) codes + bases of the first two groups; (C) gathers; dictionary reads from a wave-private LDS
+// copy (no block barrier).
+// ---------------------------------------------------------------------------------------
+template <int NC, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__restrict__ x,
+                                                 double *__restrict__ y,
+                                                 const double *__restrict__ dinv,
+                                                 const double *__restrict__ aux,
+                                                 double *__restrict__ partial,
+                                                 const int *__restrict__ done_flag /* never null */,
+                                                 const int32_t *__restrict__ slice_list, int n_list) {
+  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-B load from an 8-B aligned address
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[4 * NV];
+  __shared__ double dict[4 * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_sl = slice_list ? n_list : A.n_slices;
+  const int ngroups_l = (n_sl + 3) >> 2;
+  const int per = gridDim.x >> 3;
+  const int chunk = (ngroups_l + 7) >> 3;
+  const int g_begin = (blockIdx.x & 7) * chunk;
+  const int g_end = min(ngroups_l, g_begin + chunk);
+  int g = g_begin + (blockIdx.x >> 3);
+  // ---- round A
+  const int dn = *done_flag;
+  int li = g * 4 + wave;
+  bool valid = g < g_end && li < n_sl;
+  int slice = valid ? (slice_list ? slice_list[li] : li) : 0;
+  int64_t base = A.ps_ptr[slice], next = A.ps_ptr[slice + 1];  // bit 0: slice kept in the entry stream
+  const int nd = A.n_dict;
+  double *md = dict + wave * 256;
+  {
+    const double d0 = A.vdict[min(lane, nd - 1)];
+    if (nd > 64) {
+      const double d1 = A.vdict[min(lane + 64, nd - 1)], d2 = A.vdict[min(lane + 128, nd - 1)],
+                   d3 = A.vdict[min(lane + 192, nd - 1)];
+      md[lane + 64] = d1;
+      md[lane + 128] = d2;
+      md[lane + 192] = d3;
+    }
+    md[lane] = d0;
+  }
+  double s[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s[i] = 0.0;
+  if (dn) valid = false;
+  while (valid) {
+    const bool wide = (base & 1) != 0;
+    base &= ~(int64_t)255;
+    const int ng = (int)(((next & ~(int64_t)255) - base) >> 8);  // groups of 4 slots x 64 lanes
+    const int64_t row = (int64_t)slice * 64 + lane;
+    const int64_t rowc = min(row, A.n_rows - 1);
+    double xe[NC], ae[NC], de = 1.0;  // epilogue operands: requested now, used after the products
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      xe[c] = (EPI == OX_EPI_DOT || EPI == OX_EPI_BCGS_T) ? x[rowc * NC + c] : 0.0;
+      ae[c] = (EPI == OX_EPI_BCGS_V) ? aux[rowc * NC + c] : 0.0;
+    }
+    if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) de = dinv[rowc];
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    const u4 *__restrict__ cp = reinterpret_cast<const u4 *>(A.ps_code + base) + lane;
+    const int2 *__restrict__ bp = reinterpret_cast<const int2 *>(A.ps_base) + (base >> 8);
+    // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B (NC = 1)
+    // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B per component; the fused
+    // multiply-adds in the stored order of the entries
+    auto group = [&](const u4 code, const int2 b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned cj = code[j];
+        const int col = ((cj & 0x8000u) ? b.y : b.x) + (int)(cj & 0x7fffu);
+        const double va = md[(cj >> 16) & 0xffu], vb = md[cj >> 24];
+        const double *xp = x + (size_t)col * NC;
+        d2u xv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xv[c] = *reinterpret_cast<const d2u *>(xp + 2 * c);
+        // x[col][0..NC-1] then x[col+1][0..NC-1] are the 2*NC doubles of xv[0..NC-1]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma(va, (c & 1) ? xv[c >> 1].y : xv[c >> 1].x, acc[c]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma(vb, ((NC + c) & 1) ? xv[(NC + c) >> 1].y : xv[(NC + c) >> 1].x, acc[c]);
+      }
+    };
+    if (ng > 0) {
+      if (!wide) {
+        // ---- rounds B, C: two groups per turn (measured: eight gathers in flight per wave at 100
+        // registers, or slices padded to whole turns, are 25 % slower than this)
+        for (int q = 0; q < ng; q += 2) {
+          const int q1 = min(q + 1, ng - 1);
+          const u4 ca = __builtin_nontemporal_load(cp + (size_t)q * 64);
+          const u4 cb2 = __builtin_nontemporal_load(cp + (size_t)q1 * 64);
+          const int2 ba = bp[q], bb = bp[q1];
+          group(ca, ba);
+          if (q + 1 < ng) group(cb2, bb);
+        }
+      } else {  // this slice's pair columns did not fit two 15-bit windows (rare): entry stream
+        const int64_t eb = A.slice_ptr[slice];
+        const int npair = (int)((A.slice_ptr[slice + 1] - eb) >> 7);
+        const int2 *__restrict__ ecp = reinterpret_cast<const int2 *>(A.cols + eb) + lane;
+        const unsigned short *__restrict__ vcp = reinterpret_cast<const unsigned short *>(A.vcode + eb) + lane;
+        for (int k = 0; k < npair; ++k) {
+          const unsigned c2 = vcp[(size_t)k * 64];
+          const int2 c = ecp[(size_t)k * 64];
+          const double va = md[c2 & 0xff], vb = md[c2 >> 8];
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(va, x[(size_t)c.x * NC + cc], acc[cc]);
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(vb, x[(size_t)c.y * NC + cc], acc[cc]);
+        }
+      }
+    }
+    if (row < A.n_rows) {
+      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] *= de;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) y[row * NC + c] = acc[c];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (EPI == OX_EPI_DOT) s[c] = fma(xe[c], acc[c], s[c]);
+        if (EPI == OX_EPI_BCGS_V) s[c] = fma(ae[c], acc[c], s[c]);
+        if (EPI == OX_EPI_BCGS_T) {
+          s[c] = fma(acc[c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], xe[c], s[NC + c]);
+        }
+      }
+    }
+    g += per;
+    li = g * 4 + wave;
+    valid = g < g_end && li < n_sl;
+    if (valid) {
+      slice = slice_list ? slice_list[li] : li;
+      base = A.ps_ptr[slice];
+      next = A.ps_ptr[slice + 1];
+    }
+  }
+  if (EPI != OX_EPI_NONE) {
+    ox_block_sum_256<NV>(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+    }
+  }
+}
+
+// a device int that is always 0: stands in for a null done flag so the kernel can load it unconditionally
+static const int *ox_zero_flag() {
+  static thread_local int *z[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!z[dev]) {
+    if (hipMalloc(&z[dev], 64) != hipSuccess) return nullptr;
+    if (hipMemset(z[dev], 0, 64) != hipSuccess) return nullptr;
+  }
+  return z[dev];
+}
+
+// bit 0: nontemporal matrix stream; bit 1: 16-bit column stream, bit 2: 1-byte value codes, bit 3: the
+// pair-slot stream, each where the matrix carries them (measured: tools/spmv_bench.py)
+#define OX_SPMV_DEFAULT_VARIANT 15
 static int g_spmv_variant = -1;
 extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 7;
+  g_spmv_variant = v & 15;
   return 0;
 }
 
@@ -174,9 +346,11 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   if (nblk == 0) return 0;
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 7 : OX_SPMV_DEFAULT_VARIANT;
+    g_spmv_variant = e ? atoi(e) & 15 : OX_SPMV_DEFAULT_VARIANT;
   }
-  int var = (A->cols16 && A->cbase) ? g_spmv_variant : (g_spmv_variant & 1);
+  int var = (A->cols16 && A->cbase) ? (g_spmv_variant & 7) : (g_spmv_variant & 1);
+  // bit 3 off: ignore the pair-slot stream (tools/spmv_bench.py A/B)
+  const bool pairs = (g_spmv_variant & 8) && A->ps_ptr && A->ps_code && A->ps_base;
   // value codes ride on the 16-bit column stream (one kernel family: 7 = all three)
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
@@ -185,7 +359,11 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
-    if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                                     \
+    if (var == 7 && pairs) {                                                                    \
+      const int *dz = done ? done : ox_zero_flag();                                             \
+      if (!dz) OX_FAIL("ox_spmv: no device flag");                                              \
+      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list); \
+    } else if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                              \
     else if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                \
     else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \
     else if (var == 1) OX_SPMV_LAUNCH(NC, E, 1);                                                \

@@ -101,7 +101,7 @@ def test_three_groups_fall_back_and_spmv_is_bit_identical():
             y = torch.zeros_like(x)
             A.mult(x, y, nc)
             ys.append(y.cpu().numpy())
-        lib.ox_set_spmv_variant(3)
+        lib.ox_set_spmv_variant(15)
         np.testing.assert_array_equal(ys[0], ys[1])
         ref = P.to_csr(A.vals) @ x.cpu().numpy()
         np.testing.assert_allclose(ys[1], ref, rtol=1e-13, atol=1e-13)
@@ -126,13 +126,14 @@ def test_value_dictionary_is_bit_identical_and_drops_when_values_change():
         for nc in (1, 3):
             x = torch.randn(n, nc, dtype=torch.float64, device="cuda").contiguous()
             ys = []
-            for var in (3, 7):
+            for var in (3, 7, 15):
                 lib.ox_set_spmv_variant(var)
                 y = torch.zeros(A.pattern.n_rows, nc, dtype=torch.float64, device="cuda")
                 A.mult(x, y, nc)
                 ys.append(y.cpu().numpy())
-            lib.ox_set_spmv_variant(7)
+            lib.ox_set_spmv_variant(15)
             np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
+            np.testing.assert_array_equal(ys[0].view(np.int64), ys[2].view(np.int64))
     # the assembled convective matrix has no small dictionary
     S.assemble_first(0.005, 0.01)
     assert not S._A.freeze()
@@ -176,8 +177,99 @@ def test_rectangular_operators_with_value_codes_are_bit_identical():
             y = torch.zeros(ny, dtype=torch.float64, device="cuda")
             Mat.mult(v2s, C.c_void_p(x.data_ptr()), None, 0.5, C.c_void_p(y.data_ptr()))
             ys.append(y.cpu().numpy())
-        lib.ox_set_spmv_variant(7)
+        lib.ox_set_spmv_variant(15)
         np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
         assert np.abs(ys[0]).max() > 0
     S6, _, _ = make_hip_problem(3, 6, u_deg=2, low_memory=False)
     assert S6._p_vdxi_Mat.vcode is None and S6._divu_Mat.vcode is None  # no dictionary: f64 path, same results
+
+
+@pytest.mark.parametrize("dim,N,deg,force", [(2, 256, 1, False), (3, 12, 1, True), (3, 6, 2, True), (2, 12, 2, True)])
+def test_pair_slot_stream_decodes_to_the_entries_and_spmv_is_bit_identical(dim, N, deg, force):
+    """ox_pair_stream_size / _fill (la.SellMatrix.freeze): every slot (col, a, b) stands for the
+    entries (col, vdict[a]) and (col + 1, vdict[b]); in stored order they are the row's entries, zeros
+    apart.  The mat-vec from the stream equals the entry-stream one bit for bit, for 1..3 columns and
+    through the Krylov epilogues."""
+    import ctypes as C
+
+    from oasisx_amd import _lib, fem, mesh as M
+    from oasisx_amd.fem import cell_geometry
+    from oasisx_amd.la import SellMatrix
+
+    lo, hi = [-1.0] * dim, [1.0] * dim
+    mesh = M.create_box(None, [lo, hi], [N] * dim) if dim == 3 else M.create_rectangle(None, [lo, hi], [N] * dim)
+    V = fem.FunctionSpace(mesh, deg)
+    A = SellMatrix(V.pattern)
+    lib = _lib.load()
+    geom = V.native.nmesh.geom if getattr(V, "native", None) is not None else cell_geometry(mesh, V.local_cells)
+    cells = _lib.ox_cells(mesh.gdim, 0, int(geom.shape[0]), geom.data_ptr())
+    adj = V.adj.struct()
+    nb, bptr, bsl, bw = V.pattern.bins_args()
+    _lib.check(lib.ox_assemble_matrix(0, V.degree, C.byref(cells), _lib.ptr(V.cell_dofs), C.byref(adj), _lib.ptr(V.adj.adj_pos),
+                                      V.adj.pw, A.ref(), nb, bptr, bsl, bw, _lib.current_stream()), "ox_assemble_matrix")  # mass: SPD
+    A.version += 1
+    assert A.freeze(pairs="always" if force else "auto")
+    assert A.ps_code is not None
+    P = V.pattern
+    # decode on the host
+    ps_ptr = A.ps_ptr.cpu().numpy()
+    code = A.ps_code.cpu().numpy().view(np.uint32)
+    base = A.ps_base.cpu().numpy().reshape(-1, 2)
+    vdict = A.vdict.cpu().numpy()
+    ref = P.to_csr(A.vals).tocsr()
+    import scipy.sparse as sp
+    rows, cols, vals = [], [], []
+    for s in range(P.n_slices):
+        if ps_ptr[s] & 1:
+            continue  # kept in the entry stream
+        b0 = ps_ptr[s] & ~255
+        ng = ((ps_ptr[s + 1] & ~255) - b0) // 256
+        blk = code[b0:b0 + ng * 256].reshape(ng, 64, 4)
+        for g in range(ng):
+            bb = base[b0 // 256 + g]
+            for lane in range(64):
+                r = s * 64 + lane
+                if r >= P.n_rows:
+                    continue
+                for j in range(4):
+                    cj = int(blk[g, lane, j])
+                    col = int(bb[1] if cj & 0x8000 else bb[0]) + (cj & 0x7fff)
+                    rows += [r, r]
+                    cols += [col, col + 1]
+                    vals += [vdict[(cj >> 16) & 0xff], vdict[cj >> 24]]
+    wide = [s for s in range(P.n_slices) if ps_ptr[s] & 1]
+    dec = sp.coo_matrix((vals, (rows, cols)), shape=(P.n_rows, P.n_cols)).tocsr()
+    keep = np.ones(P.n_rows, dtype=bool)
+    for s in wide:
+        keep[s * 64:(s + 1) * 64] = False
+    d = (dec - ref)[keep]
+    assert abs(d).max() == 0.0 if d.nnz else True
+    for nc in (1, 2, 3):
+        x = torch.randn(P.n_cols, nc, dtype=torch.float64, device="cuda").contiguous()
+        ys = []
+        for var in (7, 15):
+            lib.ox_set_spmv_variant(var)
+            y = torch.zeros(P.n_rows, nc, dtype=torch.float64, device="cuda")
+            A.mult(x, y, nc)
+            ys.append(y)
+        lib.ox_set_spmv_variant(15)
+        assert torch.equal(ys[0], ys[1])
+    # Krylov epilogues (CG: p.Ap; BiCGStab: D^-1 A with rhat.v and t.t, t.s): same iterates bit for bit
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+
+    for nc in (1, 3):
+        rhs = torch.randn(P.n_rows, nc, dtype=torch.float64, device="cuda")
+        for kind in ("cg", "bcgs"):
+            sols = []
+            for var in (7, 15):
+                lib.ox_set_spmv_variant(var)
+                ks = KSPSolver(None, {"ksp_type": kind, "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-30,
+                                      "ksp_max_it": 25})
+                ks.setOperators(A)
+                B, X = FieldStorage(P.n_rows, nc, "cuda"), FieldStorage(P.n_rows, nc, "cuda")
+                B.dev().copy_(rhs)
+                ks.solve_block(B, X)
+                sols.append((X.dev().clone(), ks.iterations))
+            lib.ox_set_spmv_variant(15)
+            assert sols[0][1] == sols[1][1] and torch.equal(sols[0][0], sols[1][0]), (kind, nc)

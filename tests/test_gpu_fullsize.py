@@ -78,13 +78,15 @@ def test_symmetry_and_bit_identity_of_the_compressed_streams(problem):
         x = torch.randn(n, 1, dtype=torch.float64, device="cuda", generator=g)
         z = torch.randn(n, 1, dtype=torch.float64, device="cuda", generator=g)
         ys = []
-        for var in (1, 3, 7):  # int32 columns + f64 values; 16-bit columns; + 1-byte value codes
+        for var in (1, 3, 7, 15):  # int32 columns + f64 values; 16-bit columns; + 1-byte value codes; pair slots
             lib.ox_set_spmv_variant(var)
             y = _vec(n)
             A.mult(x, y, 1)
             ys.append(y)
-        lib.ox_set_spmv_variant(7)
-        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+        lib.ox_set_spmv_variant(15)
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]) and torch.equal(ys[0], ys[3])
+        if A is S._Ap:
+            assert A.ps_code is not None, "the P1 stiffness matrix pairs up well: the pair-slot stream must exist"
         w = _vec(n)
         A.mult(z, w, 1)
         a, b = float((z * ys[0]).sum()), float((x * w).sum())
