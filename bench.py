@@ -400,8 +400,12 @@ def main():
     def stored_bytes(A, nc=1):
         """Bytes one SpMV launch streams from this SELL-64 storage: f64 values (or 1-byte value codes
         where the matrix has a dictionary), 16-bit column codes where the pattern carries them (int32
-        elsewhere), the per-pair bases, slice offsets and the x / y vectors -- padding included."""
+        elsewhere), the per-pair bases, slice offsets and the x / y vectors -- padding included.  A matrix
+        with a pair-slot stream is read from that instead (4 B per slot of two adjacent columns)."""
         P = A.pattern
+        if getattr(A, "ps_code", None) is not None:  # pair-slot stream: 4 B per slot, per-group bases, slice offsets
+            n = A.ps_code.numel()
+            return int(4 * n + 8 * (n // 256) + 8 * (P.n_slices + 1) + nc * 8 * (P.n_cols + P.n_rows))
         cols = P.size * (2 * P.frac16 + 4 * (1.0 - P.frac16))
         bases = 8 * (P.size // 128) if P.frac16 > 0 else 0
         vals = (1 if A.vcode is not None else 8) * P.size
@@ -447,16 +451,22 @@ def main():
     cg = kernels.get("pressure_cg_spmv")
     roofline = None
     if cg:
-        roofline = {"kernel": "k_spmv<1,OX_EPI_DOT,*> (pressure-Poisson CG SpMV, SELL-64, f64)", "bound": "hbm",
+        roofline = {"kernel": ("k_spmv_ps<1,OX_EPI_DOT> (pressure-Poisson CG SpMV, SELL-64 pair-slot stream, f64)"
+                               if S._Ap.ps_code is not None else
+                               "k_spmv<1,OX_EPI_DOT,*> (pressure-Poisson CG SpMV, SELL-64, f64)"), "bound": "hbm",
                     # bytes the kernel really streams per launch (its stored matrix + x + y) / HIP-event time
                     "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg["frac_of_hbm_peak"],
                     "traffic": None, "traffic_detail": None,
                     "bytes_moved_per_launch": cg["bytes_moved"], "avg_launch_us": cg["avg_us"], "launches": cg["launches"],
                     "csr_bytes_per_launch": b_p, "csr_equivalent_gbs": cg["csr_equivalent_gbs"],
                     "cols16_fraction": Pp.frac16, "value_dictionary_entries": int(S._Ap._struct.n_dict),
+                    "pair_slots_per_row": (S._Ap.ps_code.numel() / 64 / max(Pp.n_slices, 1)) if S._Ap.ps_code is not None else None,
+                    "address_unit_note": "on compressed storage this kernel is bound by vector-memory instructions per "
+                                         "slice (16-20 cycles of the address unit each, any width), not by bytes: "
+                                         "tools/ubench/dispatch_rate.hip, DESIGN.md section 3",
                     "note": "achieved = stored bytes (lossless 16-bit column codes and, with a dictionary, 1-byte value "
                             "codes; f64 arithmetic) / time; csr_equivalent_gbs prices the same launch at the metric's "
-                            "12 B per nonzero and is NOT a fraction of anything.  At 128^3 the 139 MB matrix fits the "
+                            "12 B per nonzero and is NOT a fraction of anything.  At 128^3 the stored matrix fits the "
                             "256 MB Infinity Cache between CG iterations: see past_cache for the HBM-resident size"}
         if traffic is not None:
             if "error" in traffic:
@@ -533,7 +543,8 @@ def main():
     if args.pmc_child:  # what the parent needs to find this run's pressure SpMV in the counter CSV
         var = 7 if S._Ap.vcode is not None else (3 if Pp.frac16 > 0 else 1)
         grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)
-        print(json.dumps({"pmc_child": True, "kernel_prefix": f"voidk_spmv<1,1,{var}>", "grid_size": grid}), flush=True)
+        prefix = "voidk_spmv_ps<1,1>" if S._Ap.ps_code is not None else f"voidk_spmv<1,1,{var}>"
+        print(json.dumps({"pmc_child": True, "kernel_prefix": prefix, "grid_size": grid}), flush=True)
         return
 
     transport_check = transport_us = None

@@ -682,6 +682,25 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
 // ------------------------------- host driver ---------------------------------------------
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// One block reads partials at ~45 GB/s: the 66 312 x 6 partials of a velocity SpMV (3.2 MB) kept the
+// scalar kernel of that synchronisation point busy for 79 us.  From OX_PRERED_MIN doubles on, blocks of
+// OX_PRERED_CHUNK partial rows are summed first (fixed order) and the scalar kernel reads their sums.
+#define OX_PRERED_CHUNK 256
+#define OX_PRERED_MIN 16384
+#define OX_PRERED_OFFSET 64  // doubles of the sums region kept for the sums themselves
+__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ partial, int nparts, int nv,
+                                                   double *__restrict__ out) {
+  __shared__ double red[16 * OX_MAX_NV];
+  const int r0 = blockIdx.x * OX_PRERED_CHUNK;
+  const int cnt = min(OX_PRERED_CHUNK, nparts - r0);
+  double v[OX_MAX_NV];
+  ox_gather_partials(partial + (size_t)r0 * nv, cnt, nv, v);
+  ox_block_sum_wide(v, nv, red);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nv; ++i) out[(size_t)blockIdx.x * nv + i] = v[i];
+}
+static inline int ksp_prered_rows(int nparts) { return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK; }
+
 struct KspLayout {
   size_t state, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
@@ -696,7 +715,8 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   L.nvec = ksp_type == OX_KSP_CG ? 4 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
-  L.partial = L.sums + ox_align(sizeof(double) * 4 * OX_MAXC);
+  // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
+  L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (size_t)(ksp_prered_rows(L.nparts_max) + 1) * OX_MAX_NV));
   L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
   L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * OX_MAXC);
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
@@ -712,9 +732,26 @@ extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, i
 
 static KspState *g_state_host = nullptr;
 
+
 template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
                           const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
+  {
+    double *scr = sums + OX_PRERED_OFFSET;
+    if ((int64_t)nparts * nv >= OX_PRERED_MIN) {
+      const int g = ksp_prered_rows(nparts);
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, scr);
+      partial = scr;
+      nparts = g;
+      scr += (size_t)g * nv;
+    }
+    if (B.nv > 0 && (int64_t)B.nparts * B.nv >= OX_PRERED_MIN) {
+      const int g = ksp_prered_rows(B.nparts);
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, scr);
+      B.partial = scr;
+      B.nparts = g;
+    }
+  }
   const int nmax = nparts > B.nparts ? nparts : B.nparts;
   if (!dist) {
     hipLaunchKernelGGL((k_ksp_scalar<PH>), dim3(1), dim3(ox_red_threads(nmax)), 0, st, S, partial, nparts, nv, P, B);
