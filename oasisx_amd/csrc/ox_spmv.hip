@@ -888,6 +888,7 @@ __global__ __launch_bounds__(256) void k_jacobi(ox_sell A, double *dinv) {
     const int2 c = cp[(size_t)k * 64];
     if (kd < 0 && c.x == row) kd = 2 * k;
     if (kd < 0 && c.y == row) kd = 2 * k + 1;
+    if (__all(kd >= 0 || row >= A.n_rows)) break;  // every row of the slice has found its diagonal
   }
   if (row < A.n_rows) {
     const double d = kd >= 0 ? A.vals[ox_entry(base, kd, lane)] : 0.0;
