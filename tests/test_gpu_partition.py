@@ -228,5 +228,26 @@ def test_overlapped_spmv_on_the_rccl_self_loop(hip):
         xf[n_owned:] = x[torch.tensor(send, device="cuda")]
         assert torch.equal(x[n_owned:], xf[n_owned:])
         assert (y - dense @ xf).abs().max() < 1e-13
+    # the same through the pair-slot stream of a frozen matrix (interior / boundary slice lists included)
+    pal = torch.tensor([0.25, 0.5, 0.75, 1.0, 1.5, 2.0], dtype=torch.float64, device="cuda")
+    csr.data[:] = pal[torch.randint(0, 6, (csr.nnz,), device="cuda", generator=g)].cpu().numpy()
+    A.vals.copy_(P.values_from_csr(csr))
+    A.version += 1
+    assert A.freeze(pairs="always") and A.ps_code is not None
+    dense = torch.from_numpy(csr.toarray()).cuda()
+    for nc in (1, 3):
+        x = torch.zeros(n_cols, nc, dtype=torch.float64, device="cuda")
+        x[:n_owned] = torch.rand(n_owned, nc, dtype=torch.float64, device="cuda", generator=g)
+        ys = []
+        for var in (7, 15):
+            hip.ox_set_spmv_variant(var)
+            x[n_owned:] = float("nan")
+            y = torch.zeros(n_owned, nc, dtype=torch.float64, device="cuda")
+            A.mult(x, y, nc)
+            torch.cuda.synchronize()
+            ys.append(y)
+        hip.ox_set_spmv_variant(15)
+        assert torch.equal(ys[0], ys[1])
+        assert (ys[1] - dense @ x).abs().max() < 1e-13
     _lib.check(hip.ox_dist_destroy(d), "ox_dist_destroy")
     _lib.check(hip.ox_comm_destroy(comm), "ox_comm_destroy")
