@@ -297,6 +297,17 @@ int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dof
                       int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
                       const int32_t *bin_width_host, void *stream);
 
+/* The same, and a_u1 (device [n_rows][gdim], may be NULL) = (the assembled A) @ u1 row by row, with the
+ * entry order and operations of ox_spmv: where u1 is also the initial guess of the tentative-velocity
+ * solve (fracstep.py:521 with -ksp_initial_guess_nonzero) it is that solve's first mat-vec
+ * (ox_ksp_solve_ax0), once the rows ox_zero_rows turns into identity rows have been set to u1. */
+int ox_assemble_first_au(int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                         const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                         const ox_sell *M, const ox_sell *K, const double *uab,
+                         const double *u1, const double *b0, double *b_first, double dt, double nu,
+                         int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
+                         const int32_t *bin_width_host, void *stream, double *a_u1);
+
 /* ---- A6 / A8: assemble_vector(p * v.dx(i) * dx) and (dp.dx(i) * v * dx), all i at once
  *      (fracstep.py:487-497 and :618).  kind 0: out[r][i] = base[r][i] + scale * int p d_i(phi_r)
  *      kind 1: out[r][i] = base[r][i] + scale * int d_i(p) phi_r.  base may be NULL (=0). */
@@ -324,6 +335,13 @@ int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const doubl
                  int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
                  int check_every, int max_restarts, void *work, size_t work_bytes,
                  ox_ksp_result *result, const ox_dist *dist, void *stream);
+/* The same with A x0 supplied by the caller (nonzero_guess only; NULL = computed here): the velocity
+ * update has M u* at hand from its right-hand side (fracstep.py:615,634), so the solver's first
+ * mat-vec is skipped.  ax0: device [n_rows][ncomp], the product with the x passed in. */
+int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
+                     int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
+                     int check_every, int max_restarts, void *work, size_t work_bytes,
+                     ox_ksp_result *result, const ox_dist *dist, void *stream, const double *ax0);
 /* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
  * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
  * continue, at most that many times per component (used when a direct solver was asked for). */

@@ -172,6 +172,9 @@ SIGNATURES = {
     "ox_assemble_first": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
                                C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
                                _D, _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
+    "ox_assemble_first_au": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
+                                  C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
+                                  _D, _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P, _P]),
     "ox_assemble_grad_vector": (_I, [_I, _I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P,
                                      _P, _D, _P, _P]),
     "ox_assemble_div_vector": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P, _D,
@@ -180,6 +183,8 @@ SIGNATURES = {
     "ox_ksp_work_bytes": (C.c_size_t, [_L, _L, _I, _I]),
     "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
                           C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
+    "ox_ksp_solve_ax0": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
+                              C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
     "ox_profile_begin": (_I, [_I, _I]),

@@ -158,6 +158,7 @@ __device__ __forceinline__ void load_geom(const double *__restrict__ g, double (
 struct FirstArgs {
   const double *Mv, *Kv, *uab, *u1, *b0;
   double *b_first;
+  double *a_u1;  // optional: (new A) @ u1 per row, the same sums an SpMV with the assembled A makes
   double idt, nu;
   // value dictionaries of M and K (la.SellMatrix.freeze): 1-byte codes instead of the f64 values
   const uint8_t *Mc, *Kc;
@@ -348,9 +349,10 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
     const double2 *__restrict__ kv = reinterpret_cast<const double2 *>(F.Kv + base) + lane;
     const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
     const double idt = F.idt, mhnu = -0.5 * F.nu;
-    double bf[GDIM];
+    double bf[GDIM], af[GDIM];
 #pragma unroll
-    for (int d = 0; d < GDIM; ++d) bf[d] = 0.0;
+    for (int d = 0; d < GDIM; ++d) bf[d] = af[d] = 0.0;
+    const bool want_au = F.a_u1 != nullptr;
     const unsigned short *__restrict__ mc =
         DICT ? reinterpret_cast<const unsigned short *>(F.Mc + base) + lane : nullptr;
     const unsigned short *__restrict__ kc =
@@ -396,6 +398,10 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
           v.x = fma(2.0 * idt, m[q].x, -ar0);
           v.y = fma(2.0 * idt, m[q].y, -ar1);
           av[(size_t)k * 64] = v;
+          if (want_au) {  // entry order and operations of k_spmv: bit-identical to A.mult(u1)
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) af[d] = fma(v.y, x1[q][d], fma(v.x, x0[q][d], af[d]));
+          }
         }
       }
     }
@@ -403,6 +409,10 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
 #pragma unroll
       for (int d = 0; d < GDIM; ++d)
         F.b_first[row * GDIM + d] = bf[d] + F.b0[row * GDIM + d];  // + b0 (fracstep.py:456)
+      if (want_au) {
+#pragma unroll
+        for (int d = 0; d < GDIM; ++d) F.a_u1[row * GDIM + d] = af[d];
+      }
     }
   }
 }
@@ -496,13 +506,13 @@ extern "C" int ox_assemble_matrix(int kind, int degree, const ox_cells *cells, c
   OX_FAIL("ox_assemble_matrix: kind=%d", kind);
 }
 
-extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dofs,
-                                 const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
-                                 const ox_sell *M, const ox_sell *K, const double *uab,
-                                 const double *u1, const double *b0, double *b_first, double dt,
-                                 double nu, int n_bins, const int64_t *bin_ptr_host,
-                                 const int32_t *bin_slices, const int32_t *bin_width_host,
-                                 void *stream) {
+extern "C" int ox_assemble_first_au(int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                                    const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                                    const ox_sell *M, const ox_sell *K, const double *uab,
+                                    const double *u1, const double *b0, double *b_first, double dt,
+                                    double nu, int n_bins, const int64_t *bin_ptr_host,
+                                    const int32_t *bin_slices, const int32_t *bin_width_host,
+                                    void *stream, double *a_u1) {
   if (!cells || !cell_dofs || !adj || !adj_pos || !A || !M || !K || !M->vals || !K->vals || !uab || !u1 ||
       !b0 || !b_first)
     OX_FAIL("ox_assemble_first: null argument");
@@ -514,13 +524,24 @@ extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_
     const char *e = getenv("OX_AF_DBG");
     dbg = e ? atoi(e) : 0;
   }
-  FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, 1.0 / dt, nu,
+  FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, a_u1, 1.0 / dt, nu,
               M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict, dbg};
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
   const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
                                            bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
   if (ox_prof_on) ox_prof_stop(ox_stream(stream));
   return rc;
+}
+
+extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                                 const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A,
+                                 const ox_sell *M, const ox_sell *K, const double *uab,
+                                 const double *u1, const double *b0, double *b_first, double dt,
+                                 double nu, int n_bins, const int64_t *bin_ptr_host,
+                                 const int32_t *bin_slices, const int32_t *bin_width_host,
+                                 void *stream) {
+  return ox_assemble_first_au(degree, cells, cell_dofs, adj, adj_pos, pw, A, M, K, uab, u1, b0, b_first, dt, nu, n_bins,
+                              bin_ptr_host, bin_slices, bin_width_host, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------

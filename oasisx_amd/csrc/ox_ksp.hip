@@ -871,7 +871,7 @@ static int ksp_read_state(const KspCtx &C) {
 template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
-                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st) {
+                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0) {
   const int64_t n = A->n_rows;
   const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type);
   KspCtx C;
@@ -893,31 +893,31 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   V.x = x;
   if (cgs) {
     V.r = vec[0], V.u = vec[1], V.p = vec[2], V.s = vec[3], V.w = vec[4];
-    if (guess) {
+    if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.w, dinv, V.r, V.u, V.p, V.s, guess,
-                       C.partial);
+    hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.w, dinv, V.r, V.u,
+                       V.p, V.s, guess, C.partial);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, dist, st)) return -1;
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
       return -1;
   } else if (cg) {
     V.r = vec[0], V.z = vec[1], V.p = vec[2], V.q = vec[3];
-    if (guess) {
+    if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.q, dinv, V.r, V.z, V.p, guess,
-                       C.partial);
+    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r, V.z,
+                       V.p, guess, C.partial);
     OX_LAUNCH_CHECK();
     if (ksp_sync_point<PH_CG_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st)) return -1;
   } else {
     V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
-    if (guess) {
+    if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, V.t, dinv, V.r, V.rhat, V.p, V.v,
-                       guess, C.partial);
+    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
+                       V.rhat, V.p, V.v, guess, C.partial);
     OX_LAUNCH_CHECK();
     if (ksp_sync_point<PH_BCGS_INIT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, dist, st)) return -1;
   }
@@ -984,10 +984,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   return 0;
 }
 
-extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
-                            double *x, int ncomp, double rtol, double atol, int max_it,
-                            int nonzero_guess, int check_every, int max_restarts, void *work,
-                            size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream) {
+extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
+                                double *x, int ncomp, double rtol, double atol, int max_it,
+                                int nonzero_guess, int check_every, int max_restarts, void *work,
+                                size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
+                                const double *ax0) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
   if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE)
     OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
@@ -1002,8 +1003,16 @@ extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, 
   hipStream_t st = ox_stream(stream);
   char *w = static_cast<char *>(work);
   switch (ncomp) {
-    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
-    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
-    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st);
+    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
+    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
+    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
   }
+}
+
+extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
+                            double *x, int ncomp, double rtol, double atol, int max_it,
+                            int nonzero_guess, int check_every, int max_restarts, void *work,
+                            size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream) {
+  return ox_ksp_solve_ax0(ksp_type, A, dinv, b, x, ncomp, rtol, atol, max_it, nonzero_guess, check_every, max_restarts,
+                          work, work_bytes, result, dist, stream, nullptr);
 }

@@ -275,11 +275,19 @@ class FractionalStep_AB_CN:
         _lib.check(lib.ox_axpby(n, 1.5, self._U1.ptr(), -0.5, self._U2.ptr(), self._UAB.ptr(), st), "ox_axpby")
         Vi = self._Vi[0][0]
         nb, bptr, bsl, bw = Vi.pattern.bins_args()
-        _lib.check(lib.ox_assemble_first(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
-                                         C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
-                                         self._A.ref(), self._M.ref(), self._K.ref(),
-                                         self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
-                                         float(dt), float(nu), nb, bptr, bsl, bw, st), "ox_assemble_first")
+        # With a nonzero initial guess the tentative solve starts from u (= u1 bit for bit unless someone
+        # wrote to it since the last step): its first mat-vec A @ u1 falls out of the fused kernel's
+        # epilogue (same entry order and operations as the SpMV).  Kept in the block of b3, free until
+        # velocity_update.
+        self._AU1_valid = False
+        want_au = bool(self._solver_u._options.get("ksp_initial_guess_nonzero", False)) and \
+            str(self._solver_u._options.get("ksp_type", "")).lower() != "preonly"
+        _lib.check(lib.ox_assemble_first_au(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
+                                            C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
+                                            self._A.ref(), self._M.ref(), self._K.ref(),
+                                            self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
+                                            float(dt), float(nu), nb, bptr, bsl, bw, st,
+                                            self._B3.ptr() if want_au else None), "ox_assemble_first")
         self._A.version += 1
         # outlet terms int h n_i dv/dx_i ds (:445-446, :461-465)
         for bcp in self._bcs_p:
@@ -288,6 +296,10 @@ class FractionalStep_AB_CN:
         # NOTE (reference :470): rows of the FIRST component's BCs only
         for bcu in self._bcs_u[0]:
             self._A.zero_rows(bcu._rows_dev, 1.0)
+            if want_au:  # identity rows: (A @ u1)[row] = u1[row]
+                rows = bcu._rows_dev.to(torch.int64)
+                self._B3.dev()[rows] = self._U1.dev()[rows]
+        self._AU1_valid = want_au
 
     def velocity_tentative_assemble(self):
         """rhs1_k = b_first_k + int p* dv/dx_k (reference fracstep.py:474-506)."""
@@ -310,7 +322,13 @@ class FractionalStep_AB_CN:
                 bc.apply(self._rhs1[i].x)
         n = self._n_u * gdim
         _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._WRK.ptr(), st), "ox_axpby")
-        errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U), dtype=np.int32)
+        ax0 = None
+        if getattr(self, "_AU1_valid", False):  # one use per assemble_first, and only if u still is u1
+            self._AU1_valid = False
+            no = self._no_u
+            if torch.equal(self._U.dev()[:no], self._U1.dev()[:no]):
+                ax0 = self._B3
+        errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U, ax0=ax0), dtype=np.int32)
         # diff = sum_i || u_i^old - u_i ||_2 (:523-524)
         _lib.check(lib.ox_axpby(n, 1.0, self._WRK.ptr(), -1.0, self._U.ptr(), self._WRK.ptr(), st), "ox_axpby")
         out = (C.c_double * 4)()
@@ -364,15 +382,18 @@ class FractionalStep_AB_CN:
         lib, st = self._lib, _lib.current_stream()
         Vi, Q = self._Vi[0][0], self._Q
         gdim = self._gdim
-        self._M.mult(self._U.dev(), self._B3.dev(), gdim)
-        if not self._low_memory:  # b3 -= dt * G_i.mult(dp) (:642-645)
-            self._grad_p_Mat.mult(False, self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr())
+        # M u* is kept (in the work block of the tentative solve, free here): with a nonzero initial
+        # guess it is the solver's first mat-vec A x0, which is then skipped
+        MU = self._WRK
+        self._M.mult(self._U.dev(), MU.dev(), gdim)
+        if not self._low_memory:  # b3 = M u* - dt * G_i.mult(dp) (:642-645)
+            self._grad_p_Mat.mult(False, self._DP.ptr(), MU.ptr(), -float(dt), self._B3.ptr())
         else:
             _lib.check(lib.ox_assemble_grad_vector(1, Vi.degree, Q.degree, C.byref(self._cells),
                                                    _lib.ptr(Q.cell_dofs), C.byref(self._adj_u), Vi.n_owned,
-                                                   self._DP.ptr(), self._B3.ptr(), -float(dt), self._B3.ptr(), st),
+                                                   self._DP.ptr(), MU.ptr(), -float(dt), self._B3.ptr(), st),
                        "ox_assemble_grad_vector")
-        return np.asarray(self._solver_c.solve_block(self._B3, self._U), dtype=np.int32)
+        return np.asarray(self._solver_c.solve_block(self._B3, self._U, ax0=MU), dtype=np.int32)
 
     def solve(self, dt: float, nu: float, max_error: float = 1e-12, max_iter: int = 10):
         """Propagate the splitting scheme one time step (reference fracstep.py:660-696)."""

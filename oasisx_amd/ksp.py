@@ -106,9 +106,11 @@ class KSPSolver:
         return (meth, float(o.get("ksp_rtol", 1e-5)), float(o.get("ksp_atol", 1e-50)),
                 int(o.get("ksp_max_it", 10000)), False)
 
-    def solve_block(self, B: FieldStorage, X: FieldStorage):
+    def solve_block(self, B: FieldStorage, X: FieldStorage, ax0: FieldStorage | None = None):
         """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
-        Returns the list of per-component converged reasons."""
+        Returns the list of per-component converged reasons.  ``ax0``: the product A X of the initial
+        guess where the caller has it at hand (used with ``ksp_initial_guess_nonzero`` only): the
+        solver's first mat-vec is skipped, same iterates."""
         if self._A is None:
             raise RuntimeError("KSPSolver.solve called before setOperators")
         lib = _lib.load()
@@ -148,9 +150,10 @@ class KSPSolver:
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
-        _lib.check(lib.ox_ksp_solve(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
-                                    max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
-                                    int(self._work.shape[0]), C.byref(res), A.pattern.dist, st),
+        _lib.check(lib.ox_ksp_solve_ax0(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
+                                        max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
+                                        int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
+                                        ax0.ptr() if (ax0 is not None and guess) else None),
                    "ox_ksp_solve")
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
             _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")

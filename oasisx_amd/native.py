@@ -7,6 +7,7 @@ mesh-partitioned spaces."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -40,12 +41,16 @@ def host_array(ptr, n, ctype, dtype) -> np.ndarray:
 
 
 class _Handle:
+    """Owner of a library object.  It is destroyed in the process that created it only: a forked child
+    (multiprocessing) inherits a copy of this wrapper but has no GPU context, and its garbage collector
+    must not call into HIP."""
+
     def __init__(self, ptr, destroy):
-        self.ptr, self._destroy = ptr, destroy
+        self.ptr, self._destroy, self._pid = ptr, destroy, os.getpid()
 
     def __del__(self):
         try:
-            if self.ptr:
+            if self.ptr and os.getpid() == self._pid:
                 self._destroy(self.ptr)
         except Exception:
             pass

@@ -81,3 +81,64 @@ def test_single_reduction_cg_nonzero_guess_and_max_it(hip):
     ksp.setOperators(A)
     X = FieldStorage(n, 1, "cuda")
     assert ksp.solve_block(B, X)[0] == -3 and ksp.iterations[0] == 5
+
+
+@pytest.mark.parametrize("kind,single", [("cg", False), ("cg", True), ("bcgs", False)])
+def test_supplied_first_matvec_gives_the_same_iterates(hip, kind, single):
+    """ox_ksp_solve_ax0: with A x0 handed in (the velocity update has M u* from its right-hand side,
+    the tentative solve gets A u1 from the fused assembly) the solver skips its first mat-vec and
+    produces the same iterates bit for bit."""
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+
+    V, A, _ = _system(3, 8, 2)
+    n, nc = V.num_dofs, 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rhs = torch.randn(n, nc, dtype=torch.float64, device="cuda", generator=g)
+    x0 = torch.randn(n, nc, dtype=torch.float64, device="cuda", generator=g)
+    res = []
+    for give in (False, True):
+        ks = KSPSolver(None, {"ksp_type": kind, "pc_type": "jacobi", "ksp_rtol": 1e-9, "ksp_atol": 1e-30,
+                              "ksp_initial_guess_nonzero": True, "ksp_cg_single_reduction": single})
+        ks.setOperators(A)
+        B, X, AX = FieldStorage(n, nc, "cuda"), FieldStorage(n, nc, "cuda"), FieldStorage(n, nc, "cuda")
+        B.dev().copy_(rhs)
+        X.dev().copy_(x0)
+        if give:
+            A.mult(X.dev(), AX.dev(), nc)
+        reasons = ks.solve_block(B, X, ax0=AX if give else None)
+        assert all(r > 0 for r in reasons)
+        res.append((X.dev().clone(), ks.iterations))
+    assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0])
+
+
+def test_fused_assembly_returns_the_first_matvec_of_the_tentative_solve(hip):
+    """ox_assemble_first_au: (A @ u1) from the epilogue of the fused kernel equals A.mult(u1) bit for
+    bit (identity rows included), and the time step that uses it equals the one that does not."""
+    from tests.helpers import KRYLOV, make_hip_problem
+
+    opts = {k: dict(v, ksp_initial_guess_nonzero=True) for k, v in KRYLOV.items()}
+    S, clock, mesh = make_hip_problem(3, 6, u_deg=2, solver_options=opts)
+    dt, nu = 0.005, 0.01
+    for _ in range(2):  # the second step starts from u == u1
+        clock["t"] += dt
+        S.solve(dt, nu)
+    clock["t"] += dt
+    for bcu in S._bcs_u:
+        for bc in bcu:
+            bc.update_bc()
+    S.assemble_first(dt, nu)
+    assert S._AU1_valid and torch.equal(S._U.dev(), S._U1.dev())
+    ref = torch.zeros_like(S._B3.dev())
+    S._A.mult(S._U1.dev(), ref, S._gdim)
+    assert torch.equal(ref, S._B3.dev())
+    # the whole step with and without the shortcut
+    S.velocity_tentative_assemble()
+    u_before = S._U.dev().clone()
+    _, err = S.velocity_tentative_solve()
+    its_with, u_with = list(S._solver_u.iterations), S._U.dev().clone()
+    S._U.dev().copy_(u_before)
+    S._AU1_valid = False
+    _, err2 = S.velocity_tentative_solve()
+    assert (err > 0).all() and (err2 > 0).all()
+    assert its_with == list(S._solver_u.iterations) and torch.equal(u_with, S._U.dev())
