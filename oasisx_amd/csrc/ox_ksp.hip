@@ -384,12 +384,12 @@ __device__ __forceinline__ void ox_acc(double (&s)[NV], int off, int c, double a
   for (int k = 0; k < NC; ++k) s[off + k] = (c == k) ? fma(a, b, s[off + k]) : s[off + k];
 }
 
-// CG init: r = b - q (q = A x0) or r = b, x = 0;  z = D^-1 r;  p = z
+// CG init: r = b - q (q = A x0) or r = b, x = 0;  z = D^-1 r (not stored);  p = z
 // partial = {r.z, z.z, (D^-1 b).(D^-1 b)}
 template <int NC>
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__restrict__ b, double *x,
                                                  const double *q, const double *__restrict__ dinv,
-                                                 double *vr, double *vz, double *vp, int guess,
+                                                 double *vr, double *vp, int guess,
                                                  double *partial) {
   __shared__ double red[4 * 3 * NC];
   double s[3 * NC];
@@ -406,7 +406,6 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
       else x[i] = 0.0;
       const double zi = d * ri, db = d * bi;
       vr[i] = ri;
-      vz[i] = zi;
       vp[i] = zi;
       s[c] = fma(ri, zi, s[c]);
       s[NC + c] = fma(zi, zi, s[NC + c]);
@@ -416,11 +415,11 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
   ksp_store_partial<3 * NC>(s, red, partial);
 }
 
-// CG: x += alpha p; r -= alpha q; z = D^-1 r; partial = {r.z, z.z}
+// CG, first vector kernel of an iteration: r -= alpha q; z = D^-1 r (not stored); partial = {r.z, z.z}.
+// x waits for the second kernel, which reads p anyway: 10 vector passes per iteration instead of 11,
+// no z vector; every element sees the same operations as in the textbook order.
 template <int NC>
-__global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *x,
-                                                    double *vr, double *vz,
-                                                    const double *__restrict__ vp,
+__global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *vr,
                                                     const double *__restrict__ vq,
                                                     const double *__restrict__ dinv,
                                                     double *partial) {
@@ -432,20 +431,16 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
   ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t ra, int cb, int64_t rb, bool two) {
-    const double2 p = ox_ld2(vp, e, two), qq = ox_ld2(vq, e, two);
-    double2 xx = ox_ld2(x, e, two), r = ox_ld2(vr, e, two);
+    const double2 qq = ox_ld2(vq, e, two);
+    double2 r = ox_ld2(vr, e, two);
     const double a0 = ox_sel<NC>(alpha, ca), a1 = ox_sel<NC>(alpha, cb);
     const double d0 = dinv[ra], d1 = two ? dinv[rb] : 0.0;
-    xx.x = fma(a0, p.x, xx.x);
-    xx.y = fma(a1, p.y, xx.y);
     r.x = fma(-a0, qq.x, r.x);
     r.y = fma(-a1, qq.y, r.y);
     double2 z;
     z.x = d0 * r.x;
     z.y = d1 * r.y;
-    ox_st2(x, e, xx, two);
     ox_st2(vr, e, r, two);
-    ox_st2(vz, e, z, two);
     ox_acc<NC>(s, 0, ca, r.x, z.x);
     ox_acc<NC>(s, NC, ca, z.x, z.x);
     if (two) {
@@ -456,19 +451,30 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
   ksp_store_partial<2 * NC>(s, red, partial);
 }
 
-// CG: p = z + beta p
+// CG, second vector kernel: x += alpha p (the iteration's alpha, still in the state); p = D^-1 r + beta p.
+// When the test after the first kernel ends the solve this kernel is skipped like every queued one:
+// the host then runs it once with `finish` set so that x receives its last update.
 template <int NC>
-__global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S, int c0,
-                                                    const double *__restrict__ vz, double *vp) {
-  if (S->done) return;
-  double beta[NC];
+__global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S, int c0, double *x,
+                                                    const double *__restrict__ vr,
+                                                    const double *__restrict__ dinv, double *vp, int finish) {
+  if (!finish && S->done) return;
+  double alpha[NC], beta[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) beta[c] = S->beta[c0 + c];
-  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t, int cb, int64_t, bool two) {
-    const double2 z = ox_ld2(vz, e, two);
-    double2 p = ox_ld2(vp, e, two);
-    p.x = fma(ox_sel<NC>(beta, ca), p.x, z.x);
-    p.y = fma(ox_sel<NC>(beta, cb), p.y, z.y);
+  for (int c = 0; c < NC; ++c) {
+    alpha[c] = S->alpha[c0 + c];
+    beta[c] = S->beta[c0 + c];
+  }
+  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t ra, int cb, int64_t rb, bool two) {
+    const double2 r = ox_ld2(vr, e, two);
+    double2 p = ox_ld2(vp, e, two), xx = ox_ld2(x, e, two);
+    const double d0 = dinv[ra], d1 = two ? dinv[rb] : 0.0;
+    xx.x = fma(ox_sel<NC>(alpha, ca), p.x, xx.x);
+    xx.y = fma(ox_sel<NC>(alpha, cb), p.y, xx.y);
+    const double z0 = d0 * r.x, z1 = d1 * r.y;
+    p.x = fma(ox_sel<NC>(beta, ca), p.x, z0);
+    p.y = fma(ox_sel<NC>(beta, cb), p.y, z1);
+    ox_st2(x, e, xx, two);
     ox_st2(vp, e, p, two);
   });
 }
@@ -712,7 +718,7 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   const int nblk_spmv = (n_slices + 3) / 4;
   const int nb8 = (nblk_spmv + 7) & ~7;
   L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
-  L.nvec = ksp_type == OX_KSP_CG ? 4 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
+  L.nvec = ksp_type == OX_KSP_CG ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
@@ -813,11 +819,10 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
   for (int k = 0; k < count; ++k) {
     if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_CG_A>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
-    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.z, V.p, V.q,
-                       C.dinv, C.partial);
+    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial);
     OX_LAUNCH_CHECK();
     if (ksp_sync_point<PH_CG_B>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
-    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.z, V.p);
+    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.dinv, V.p, 0);
     OX_LAUNCH_CHECK();
   }
   return 0;
@@ -903,11 +908,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
       return -1;
   } else if (cg) {
-    V.r = vec[0], V.z = vec[1], V.p = vec[2], V.q = vec[3];
+    V.r = vec[0], V.p = vec[1], V.q = vec[2];
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r, V.z,
+    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
                        V.p, guess, C.partial);
     OX_LAUNCH_CHECK();
     if (ksp_sync_point<PH_CG_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st)) return -1;
@@ -926,6 +931,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
                : (cg ? cg_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every));
   };
+  bool cg_finished = false;
   for (int it = 0; it <= P.max_it; it += check_every) {
     if (iterate(std::integral_constant<int, NC>{}, V, P)) return -1;
     if (ksp_read_state(C)) return -1;
@@ -944,6 +950,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
         KspVecs W{};
         double *src[8] = {V.x, V.r, V.z, V.p, V.q, V.rhat, V.v, nullptr};
         double **dst[8] = {&W.x, &W.r, &W.z, &W.p, &W.q, &W.rhat, &W.v, nullptr};
+        if (cg) src[2] = nullptr;  // no z vector: the second update kernel forms D^-1 r itself
         if (cgs) {  // x, r, u, p, s (a recurrence: carried over), w
           src[2] = V.u, dst[2] = &W.u;
           src[4] = V.s, dst[4] = &W.s;
@@ -968,6 +975,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           if (ksp_read_state(C)) return -1;
           if (g_state_host->done) break;
         }
+        if (cg) {  // the last x += alpha p (see k_cg_update2)
+          hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, dinv, W.p, 1);
+          OX_LAUNCH_CHECK();
+        }
+        cg_finished = true;
         hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.x, NC, live, x);
         OX_LAUNCH_CHECK();
         break;
@@ -975,6 +987,10 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     }
   }
   if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
+  if (cg && !cg_finished) {  // the last x += alpha p (see k_cg_update2)
+    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, dinv, V.p, 1);
+    OX_LAUNCH_CHECK();
+  }
   for (int c = 0; c < NC; ++c) {
     result->reason[c] = g_state_host->reason[c];
     result->its[c] = g_state_host->its[c];
