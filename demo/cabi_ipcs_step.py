@@ -104,7 +104,7 @@ class IPCS:
     """FractionalStep_AB_CN for Dirichlet velocity data on the whole boundary, no pressure condition,
     low_memory_version=True, Jacobi-BiCGStab / Jacobi-CG -- every operation a C-ABI call."""
 
-    def __init__(self, coords, cells, u_deg, rtol=1e-11):
+    def __init__(self, coords, cells, u_deg, rtol=1e-11, compress=False):
         self.L, self.lib = L, lib = load_binding()
         self.dev = dev = Device(L, lib)
         self.gdim = d = coords.shape[1]
@@ -128,6 +128,12 @@ class IPCS:
         self._assemble(0, self.vv, self.M)
         self._assemble(1, self.vv, self.K)
         self._assemble(1, self.qv, self.Ap)
+        # optional storage levels of the constant matrices (bit-identical results): 1-byte value codes where
+        # the matrix has <= 256 distinct values, and on top of them the pair-slot stream
+        self.compressed = {}
+        if compress:
+            for name, A, pat in (("M", self.M, self.vv.pattern), ("K", self.K, self.vv.pattern), ("Ap", self.Ap, self.qv.pattern)):
+                self.compressed[name] = self._compress(A, pat, pairs=(name == "Ap"))
         self.wq = dev.zeros(self.n_q)
         ck(lib.ox_assemble_weights(1, C.byref(self.mv.cells_struct), C.byref(self.qv.adj), self.n_q, self.wq, None),
            "ox_assemble_weights")
@@ -162,6 +168,26 @@ class IPCS:
         C.memmove(C.byref(A), C.byref(pat.sell), C.sizeof(A))
         A.vals = self.dev.zeros(int(pat.size)).value
         return A
+
+    def _compress(self, A, pat, pairs):
+        """ox_value_dictionary, then ox_pair_stream_size / _fill; returns what was built."""
+        dev, lib, ck = self.dev, self.lib, self.L.check
+        n = int(pat.size)
+        codes, vdict, nd = dev.zeros(n, np.uint8), dev.zeros(256), C.c_int(0)
+        ck(lib.ox_value_dictionary(A.vals, n, 1, codes, vdict, C.byref(nd), None), "ox_value_dictionary")
+        if nd.value == 0:
+            return {"n_dict": 0, "pair_codes": 0}
+        A.vcode, A.vdict, A.n_dict = codes.value, vdict.value, nd.value
+        built = {"n_dict": int(nd.value), "pair_codes": 0}
+        if pairs:
+            ps_ptr, ncodes = dev.zeros(int(A.n_slices) + 1, np.int64), C.c_int64(0)
+            ck(lib.ox_pair_stream_size(C.byref(A), pat.row_len, ps_ptr, C.byref(ncodes), None), "ox_pair_stream_size")
+            if ncodes.value > 0:
+                code, base, wide = dev.zeros(ncodes.value, np.uint32), dev.zeros(2 * (ncodes.value // 256), np.int32), C.c_int64(0)
+                ck(lib.ox_pair_stream_fill(C.byref(A), pat.row_len, ps_ptr, code, base, C.byref(wide), None), "ox_pair_stream_fill")
+                A.ps_ptr, A.ps_code, A.ps_base = ps_ptr.value, code.value, base.value
+                built.update(pair_codes=int(ncodes.value), wide_slices=int(wide.value))
+        return built
 
     def _assemble(self, kind, sv, A):
         p = sv.pattern
@@ -239,9 +265,9 @@ def tg(dim, nu):
     return [u, v, w][:dim], p
 
 
-def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11):
+def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=False):
     coords, cells = box_mesh(dim, N)
-    S = IPCS(coords, cells, u_deg, rtol)
+    S = IPCS(coords, cells, u_deg, rtol, compress)
     fns, pf = tg(dim, nu)
     X, Xq = S.x_v.T, S.x_q.T
     S.set_field(S.U2, np.stack([f(X, -dt) for f in fns], axis=1))
@@ -254,7 +280,8 @@ def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11):
         S.step(dt, nu, np.stack([f(Xb, t) for f in fns]))
     out = {"coords": coords, "cells": cells, "x_v": S.x_v, "x_q": S.x_q, "u": S.dev.download(S.U1, (S.n_u, dim)),
            "p": S.dev.download(S.P, (S.n_q,)), "its_pressure": np.asarray(S.its["pressure"]), "t": t,
-           "imported_package": np.asarray("oasisx_amd" in sys.modules), "imported_torch": np.asarray("torch" in sys.modules)}
+           "imported_package": np.asarray("oasisx_amd" in sys.modules), "imported_torch": np.asarray("torch" in sys.modules),
+           "compressed": np.asarray(repr(S.compressed))}
     S.close()
     return out
 
@@ -266,8 +293,9 @@ if __name__ == "__main__":
     ap.add_argument("--udeg", type=int, default=2)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--compress", action="store_true", help="value dictionaries and the pair-slot stream for M, K, Ap")
     a = ap.parse_args()
-    r = run(a.dim, a.N, a.udeg, a.steps)
+    r = run(a.dim, a.N, a.udeg, a.steps, compress=a.compress)
     ex = [f(r["x_v"].T, r["t"]) for f in tg(a.dim, 0.01)[0]]
     print("C-ABI step: n_u", r["x_v"].shape[0], "n_p", r["x_q"].shape[0], "max |u - u_exact| =",
           float(max(np.abs(r["u"][:, i] - ex[i]).max() for i in range(a.dim))), "pressure iterations", r["its_pressure"])

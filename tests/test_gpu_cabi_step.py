@@ -14,17 +14,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dim,N,udeg", [(2, 12, 2), (3, 5, 2), (3, 6, 1)])
-def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg):
+@pytest.mark.parametrize("dim,N,udeg,compress", [(2, 12, 2, False), (3, 5, 2, False), (3, 6, 1, False), (3, 6, 2, True),
+                                                 (2, 16, 1, True)])
+def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress):
     from oracle import ipcs_oracle as O
     from oracle.cpu_baseline import match_by_coordinates
     from tests.helpers import KRYLOV
 
     out = str(tmp_path / "step.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "cabi_ipcs_step.py"), "--dim", str(dim), "-N", str(N),
-                        "--udeg", str(udeg), "--steps", "2", "--out", out], capture_output=True, text=True, timeout=600)
+                        "--udeg", str(udeg), "--steps", "2", "--out", out] + (["--compress"] if compress else []),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     g = np.load(out)
+    if compress:  # ox_value_dictionary and ox_pair_stream_size/_fill were driven through the binding
+        built = eval(str(g["compressed"]))
+        # (the P2 matrices of this two-shape mesh have more than 256 distinct values: declined, as designed)
+        assert built["Ap"]["n_dict"] > 0 and built["Ap"]["pair_codes"] > 0 and set(built) == {"M", "K", "Ap"}, built
     assert not bool(g["imported_package"]) and not bool(g["imported_torch"])  # the C ABI was all it used
     nu, dt = 0.01, 0.005
     R, clock = O.taylor_green_problem(0, dim, u_deg=udeg, p_deg=1, nu=nu, dt=dt, solver_options=KRYLOV,
