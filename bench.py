@@ -104,7 +104,8 @@ def host_cores():
 def pmc_traffic(args, log):
     """Run this same command (1 warm-up + 1 timed step, nothing else) twice under
     ``rocprofv3 --pmc`` -- FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md's
-    HBM section prescribes -- and return the per-launch averages for the pressure CG SpMV.
+    HBM section prescribes -- and once under ``--kernel-trace``, and return the per-launch averages
+    for the pressure CG SpMV.
     Must run BEFORE this process touches the GPU (the children are started as ordinary child
     processes; nothing is exec'ed from a GPU-initialised process).  FETCH_SIZE counts 128-B requests
     as 64 B on gfx950: a streamed read is 2 x FETCH_SIZE (same section)."""
@@ -119,9 +120,10 @@ def pmc_traffic(args, log):
     res = {}
     t0 = time.perf_counter()
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "KERNEL_TRACE"):
             out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+            mode = ["--kernel-trace"] if counter == "KERNEL_TRACE" else ["--pmc", counter]
+            cmd = [exe, *mode, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--pmc-child", "-N", str(args.N), "--udeg", str(args.udeg),
                    "--workload", args.workload, "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol)]
             for flag, on in (("--zero-guess", args.zero_guess), ("--matrix-free", args.matrix_free),
@@ -141,6 +143,15 @@ def pmc_traffic(args, log):
             if child is None:
                 return {"error": f"rocprofv3 --pmc {counter}: the child printed no record"}
             vals = []
+            if counter == "KERNEL_TRACE":  # the same kernel's duration as rocprofv3 sees it (no event bubbles)
+                for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if (r["Kernel_Name"].replace(" ", "").startswith(child["kernel_prefix"])
+                                and int(r["Grid_Size_X"]) == child["grid_size"]):
+                            vals.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+                if vals:
+                    res["KERNEL_TRACE"] = {"dispatches": len(vals), "avg_us": sum(vals) / len(vals)}
+                continue
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if (r["Counter_Name"] == counter and r["Kernel_Name"].replace(" ", "").startswith(child["kernel_prefix"])
@@ -159,6 +170,7 @@ def pmc_traffic(args, log):
     log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
     return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel": res["kernel"],
             "dispatches": res["FETCH_SIZE"]["dispatches"],
+            "rocprofv3_avg_launch_us": (res.get("KERNEL_TRACE") or {}).get("avg_us"),
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command "
                       "(FETCH_SIZE x 2: gfx950 counts 128-B requests as 64 B)", "seconds": time.perf_counter() - t0}
 
@@ -474,6 +486,12 @@ def main():
             else:
                 roofline["traffic"] = traffic["bytes_per_launch"]
                 roofline["traffic_detail"] = traffic
+                if traffic.get("rocprofv3_avg_launch_us"):
+                    # the HIP-event figure above contains the bubbles of its own event pair (~3 us on a 30 us
+                    # kernel); rocprofv3's kernel trace of the same command (a third child pass) does not
+                    us_r = traffic["rocprofv3_avg_launch_us"]
+                    roofline["rocprofv3"] = {"avg_launch_us": us_r, "achieved": cg["bytes_moved"] / (1e3 * us_r),
+                                             "frac": cg["bytes_moved"] / (1e3 * us_r) / HBM_PEAK_GBS}
 
     # ---- variant legs on the same solver (reported beside the headline, never instead of it) -------
     variants = {}
