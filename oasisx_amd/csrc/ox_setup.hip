@@ -1178,7 +1178,12 @@ __global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *_
     const int64_t pb = ps_ptr[slice] & ~(int64_t)255;  // (a neighbour may already carry its flag bit)
     const int ngroups = (int)(((ps_ptr[slice + 1] & ~(int64_t)255) - pb) >> 8);
     const int BIG = 0x7fffffff;
-    const int pad_col = (int)min(max(row, (int64_t)0), A.n_cols - 2);  // x[pad_col], x[pad_col+1] exist
+    // A slot reads x[col] AND x[col+1], the second possibly with a zero coefficient: it must be a finite,
+    // settled number.  Columns >= n_rows of a partitioned operator are ghosts -- stale (or NaN) while the
+    // halo exchange that overlaps the interior slices is in flight -- so a zero-coefficient read never
+    // crosses from the owned block into the ghost block, nor past the last column.
+    const int64_t n_own = min(A.n_rows, A.n_cols);
+    const int pad_col = (int)min(max(row, (int64_t)0), n_own - 2);  // x[pad_col], x[pad_col+1]: owned
     bool ok = true;
     int k = 0;
     for (int g = 0; g < ngroups; ++g) {
@@ -1194,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *_
             k += 2;
           } else {
             k += 1;
-            if (cc == A.n_cols - 1) {  // x[cc+1] does not exist: the slot starts one column earlier, a = 0
+            if (cc + 1 == A.n_cols || cc + 1 == n_own) {  // x[cc+1] is missing or a ghost: start one column earlier, a = 0
               cc -= 1;
               b = a;
               a = (unsigned)zero_code;
@@ -1258,7 +1263,7 @@ extern "C" int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int
   if (!A || !row_len || !ps_ptr || !n_codes) OX_FAIL("ox_pair_stream_size: null argument");
   hipStream_t st = ox_stream(stream);
   *n_codes = 0;
-  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2) return 0;
+  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2 || A->n_rows < 2) return 0;
   const int zc = ps_zero_code(A, st);
   if (zc < 0) return 0;  // no 0.0 in the dictionary: singles cannot be expressed
   DevBuf len;
@@ -1281,7 +1286,8 @@ extern "C" int ox_pair_stream_fill(const ox_sell *A, const int32_t *row_len, int
   if (!A || !row_len || !ps_ptr || !ps_code || !ps_base) OX_FAIL("ox_pair_stream_fill: null argument");
   hipStream_t st = ox_stream(stream);
   if (n_wide) *n_wide = 0;
-  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2) OX_FAIL("ox_pair_stream_fill: matrix has no value codes");
+  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2 || A->n_rows < 2)
+    OX_FAIL("ox_pair_stream_fill: matrix has no value codes");
   const int zc = ps_zero_code(A, st);
   if (zc < 0) OX_FAIL("ox_pair_stream_fill: no 0.0 in the value dictionary");
   DevBuf cnt;

@@ -197,6 +197,8 @@ def test_overlapped_spmv_on_the_rccl_self_loop(hip):
     rows, cols = [], []
     for r in range(n_owned):
         cs = {r, (r + 1) % n_owned, (r * 7 + 3) % n_owned}
+        if r == 5:
+            cs.add(n_owned - 1)  # an INTERIOR row next to the ghost block: a pair slot must not read x[n_owned]
         if r >= 64:
             cs.add(n_owned + r % ng)
         for c in sorted(cs):
@@ -234,6 +236,18 @@ def test_overlapped_spmv_on_the_rccl_self_loop(hip):
     A.vals.copy_(P.values_from_csr(csr))
     A.version += 1
     assert A.freeze(pairs="always") and A.ps_code is not None
+    # invariant of the stream: a slot reads x[col] and x[col+1]; in an INTERIOR slice (multiplied while the
+    # exchange is in flight) neither may be a ghost column, not even with a zero coefficient
+    ps_ptr, code = A.ps_ptr.cpu().numpy(), A.ps_code.cpu().numpy().view(np.uint32)
+    base = A.ps_base.cpu().numpy().reshape(-1, 2)
+    for sl in P.ib_slices[: P.n_interior].tolist():
+        b0 = int(ps_ptr[sl]) & ~255
+        ng_ = ((int(ps_ptr[sl + 1]) & ~255) - b0) // 256
+        blk = code[b0:b0 + ng_ * 256].reshape(ng_, 64, 4)
+        for g_ in range(ng_):
+            lo_hi = base[b0 // 256 + g_]
+            cols_ = np.where(blk[g_] & 0x8000, lo_hi[1], lo_hi[0]) + (blk[g_] & 0x7fff)
+            assert int(cols_.max()) + 1 < n_owned, (sl, g_, int(cols_.max()))
     dense = torch.from_numpy(csr.toarray()).cuda()
     for nc in (1, 3):
         x = torch.zeros(n_cols, nc, dtype=torch.float64, device="cuda")
