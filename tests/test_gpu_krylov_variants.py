@@ -81,6 +81,16 @@ def test_single_reduction_cg_nonzero_guess_and_max_it(hip):
     ksp.setOperators(A)
     X = FieldStorage(n, 1, "cuda")
     assert ksp.solve_block(B, X)[0] == -3 and ksp.iterations[0] == 5
+    # ... and x is the fifth iterate (its last update is applied by the host once the device reports the end)
+    for single in (False, True):
+        ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-14, "ksp_max_it": 5,
+                               "ksp_cg_single_reduction": single})
+        ksp.setOperators(A)
+        X = FieldStorage(n, 1, "cuda")
+        assert ksp.solve_block(B, X)[0] == -3
+        x5, r5, i5, _ = O.jacobi_cg(Acsr, b, rtol=1e-14, atol=1e-50, max_it=5)
+        assert r5 == -3 and i5 == 5
+        assert np.abs(X.dev()[:, 0].cpu().numpy() - x5).max() < 1e-12 * max(np.abs(x5).max(), 1.0)
 
 
 @pytest.mark.parametrize("kind,single", [("cg", False), ("cg", True), ("bcgs", False)])
