@@ -173,7 +173,9 @@ typedef struct {
 } ox_rect_info;
 
 /* coords [n_vertices][gdim] f64, cells [n_cells][gdim+1] int32 (any order, any orientation);
- * on_device: the two pointers are device pointers; tile_bits < 0: default. */
+ * on_device: the two pointers are device pointers; tile_bits < 0: default.
+ * Cells (and later the dofs) are ordered for the kernels: a lattice mesh (few distinct values per
+ * coordinate) by y-z tiles of whole x-lines, any other mesh along a Z-order curve. */
 int ox_mesh_create(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
                    int on_device, int tile_bits, ox_mesh **out);
 int ox_mesh_view(const ox_mesh *mesh, ox_mesh_info *view);
