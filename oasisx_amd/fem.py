@@ -50,14 +50,11 @@ def default_tile_bits(mesh: Mesh) -> int:
 
 
 def default_key_bits(n_points: int, gdim: int, tile_bits: int) -> int:
-    """Bits per coordinate of ``locality_key``: 4 lattice steps per mean point spacing
+    """Bits per coordinate of ``locality_key``'s tiled order: 4 lattice steps per mean point spacing
     (L = ceil(n_points^(1/gdim)) "lines", bits = ceil(log2 L) + 2, in integer arithmetic so that the
-    library's C++ twin agrees bit for bit).  Fine enough that the lines of a lattice mesh stay
-    distinct and ordered exactly; coarse enough that on an UNSTRUCTURED mesh points of one spacing
-    fall into the same (z, y) bucket and are ordered along x inside it -- with 18 bits every point
-    has its own z bucket and a tile is swept in pure z order, i.e. in no spatial order at all.
-    (Measured: no difference on a 575 K-row Delaunay mesh, whose SpMV is bound by its few 120-entry
-    rows, tools/irregular_report.py; identical order on the lattice meshes.)  OX_KEY_BITS overrides."""
+    library's C++ twin agrees bit for bit): fine enough that the lines of a lattice mesh stay distinct
+    and ordered exactly.  (Meshes that are not lattices do not use the tiled order: ``mesh_is_lattice``.)
+    OX_KEY_BITS overrides."""
     env = _os.environ.get("OX_KEY_BITS")
     if env is not None:
         return int(env)
@@ -108,7 +105,8 @@ def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bit
     * rows that an XCD works on at one time form one compact y-z tile, so their gather footprint
       (tile + halo) stays near the 4 MiB L2 instead of ~5 whole lattice planes (8 MB) under
       plane-by-plane lexicographic order.
-    A full Z-order (Morton) curve was measured 15 % slower: it destroys the coalescing."""
+    On these LATTICE meshes a full Z-order (Morton) curve was measured 15 % slower: it destroys the
+    coalescing.  ``curve=True`` (meshes that are not lattices, ``mesh_is_lattice``) is that Z-order curve."""
     d = x.shape[1]
     if curve:  # Z-order curve (unstructured meshes, mesh_is_lattice): 18 bits per coordinate
         bits = min(18, 63 // d)
