@@ -873,6 +873,48 @@ static int ksp_read_state(const KspCtx &C) {
   return C.dist ? ox_dist_status(C.dist) : 0;  // a timed-out peer wait fails the solve
 }
 
+// One-column solves (the pressure CG, the narrowed tail of the velocity solves) run ONE BATCH AHEAD of
+// the state the host looks at: batch k+1 is queued before the copy of the state after batch k is waited
+// for, so the GPU never idles for the ~30 us of a read-back (the "host reads" of SURVEY section 7).  The
+// price is one batch of no-op kernels after convergence, hence small batches.  g_state_host[1], [2] are
+// the two copies in flight; the final state ends up in g_state_host[0].
+static hipEvent_t g_state_ev[2] = {nullptr, nullptr};
+template <class Iterate>
+static int ksp_run_ahead(const KspCtx &C, Iterate &&iterate, int batch, int &it, int max_it) {
+  for (int i = 0; i < 2; ++i)
+    if (!g_state_ev[i]) OX_HIP(hipEventCreateWithFlags(&g_state_ev[i], hipEventDisableTiming));
+  auto copy = [&](int slot) -> int {
+    OX_HIP(hipMemcpyAsync(g_state_host + 1 + slot, C.S, sizeof(KspState), hipMemcpyDeviceToHost, C.st));
+    OX_HIP(hipEventRecord(g_state_ev[slot], C.st));
+    return 0;
+  };
+  if (iterate(batch)) return -1;
+  it += batch;
+  if (copy(0)) return -1;
+  int cur = 0;
+  for (;;) {
+    const bool more = it <= max_it;  // (the kernels stop by themselves at max_it: reason DIVERGED_ITS)
+    if (more) {
+      if (iterate(batch)) return -1;
+      it += batch;
+      if (copy(1 - cur)) return -1;
+    }
+    OX_HIP(hipEventSynchronize(g_state_ev[cur]));
+    if (C.dist && ox_dist_status(C.dist)) return -1;
+    if (g_state_host[1 + cur].done || !more) {
+      OX_HIP(hipStreamSynchronize(C.st));  // the batch queued ahead (no-ops after `done`) and its copy
+      if (!more && !g_state_host[1 + cur].done) {  // ran out of batches: take the newest state
+        OX_HIP(hipMemcpyAsync(g_state_host, C.S, sizeof(KspState), hipMemcpyDeviceToHost, C.st));
+        OX_HIP(hipStreamSynchronize(C.st));
+        return 0;
+      }
+      g_state_host[0] = g_state_host[1 + cur];
+      return 0;
+    }
+    cur = 1 - cur;
+  }
+}
+
 template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
@@ -892,7 +934,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.nbs = ox_spmv_dist_nparts(A, dist);
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
-  if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, sizeof(KspState)));
+  if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
   const bool cg = ksp_type == OX_KSP_CG, cgs = ksp_type == OX_KSP_CG_SINGLE;
   KspVecs V{};
   V.x = x;
@@ -932,7 +974,19 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
                : (cg ? cg_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every));
   };
   bool cg_finished = false;
-  for (int it = 0; it <= P.max_it; it += check_every) {
+  static int run_ahead = -1;
+  if (run_ahead < 0) run_ahead = getenv("OX_KSP_RUN_AHEAD") ? atoi(getenv("OX_KSP_RUN_AHEAD")) : 1;
+  auto batch_of = [&](int every) { return every > 4 ? 4 : every; };  // small batches: the tail of no-ops is one batch
+  if (NC == 1 && run_ahead) {
+    int it = 0;
+    const int bsz = batch_of(check_every);
+    auto it1 = [&](int count) -> int {
+      return cgs ? cgs_iterations<1>(C, V, P, count)
+                 : (cg ? cg_iterations<1>(C, V, P, count) : bcgs_iterations<1>(C, V, P, count));
+    };
+    if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
+  }
+  for (int it = 0; !(NC == 1 && run_ahead) && it <= P.max_it; it += check_every) {
     if (iterate(std::integral_constant<int, NC>{}, V, P)) return -1;
     if (ksp_read_state(C)) return -1;
     if (g_state_host->done) break;
@@ -970,10 +1024,20 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
         KspParams P1 = P;
         P1.nc = 1;
         P1.c0 = live;
-        for (; it <= P.max_it; it += check_every) {
-          if (iterate(std::integral_constant<int, 1>{}, W, P1)) return -1;
-          if (ksp_read_state(C)) return -1;
-          if (g_state_host->done) break;
+        if (run_ahead) {
+          const int bsz = batch_of(check_every);
+          auto it1 = [&](int count) -> int {
+            return cgs ? cgs_iterations<1>(C, W, P1, count)
+                       : (cg ? cg_iterations<1>(C, W, P1, count) : bcgs_iterations<1>(C, W, P1, count));
+          };
+          it += check_every;
+          if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
+        } else {
+          for (it += check_every; it <= P.max_it; it += check_every) {
+            if (iterate(std::integral_constant<int, 1>{}, W, P1)) return -1;
+            if (ksp_read_state(C)) return -1;
+            if (g_state_host->done) break;
+          }
         }
         if (cg) {  // the last x += alpha p (see k_cg_update2)
           hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, dinv, W.p, 1);
