@@ -84,6 +84,8 @@ def parse():
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the product path); "
                          "gloo = rehearsal of the same partitioned path through the library's host-staged "
                          "callback transport (several ranks may then share one GPU)")
+    ap.add_argument("--profile-every", type=int, default=32,
+                    help="HIP-event pair around every n-th launch of a kernel tag inside the timed region")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -372,9 +374,9 @@ def main():
             step()
             log("warmup step", S.iteration_counts())
         barrier()
-        # HIP events on the launching stream around every 8th launch of each kernel tag (an event pair
-        # costs ~12 us of stream bubbles; every launch would slow the 150 us pressure iteration by 8 %)
-        _lib.check(lib.ox_profile_begin(200000, 8), "ox_profile_begin")
+        # HIP events on the launching stream around every --profile-every-th launch of each kernel tag (an
+        # event pair costs ~12 us of stream bubbles; every launch would slow the 75 us pressure iteration by 16 %)
+        _lib.check(lib.ox_profile_begin(200000, args.profile_every), "ox_profile_begin")
         phase_events["_on"] = main_run
         t0 = time.perf_counter()
         its = []
