@@ -976,7 +976,9 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   bool cg_finished = false;
   static int run_ahead = -1;
   if (run_ahead < 0) run_ahead = getenv("OX_KSP_RUN_AHEAD") ? atoi(getenv("OX_KSP_RUN_AHEAD")) : 1;
-  auto batch_of = [&](int every) { return every > 4 ? 4 : every; };  // small batches: the tail of no-ops is one batch
+  // small batches (the tail of no-ops after convergence is about one batch), large enough for the host
+  // to stay ahead: 8 pressure-CG iterations are 40 launches for 600 us of GPU time
+  auto batch_of = [&](int every) { return every > 8 ? 8 : every; };
   if (NC == 1 && run_ahead) {
     int it = 0;
     const int bsz = batch_of(check_every);
