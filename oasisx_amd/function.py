@@ -4,17 +4,23 @@ solver (reference src/oasisx/function.py:13-143).
 The reference projects an arbitrary UFL expression; without UFL the right-hand side
 ``int function * v dx`` comes from the object passed as ``function``:
 
-* a :class:`oasisx_amd.fem.Function` on the same space -> ``b = M f`` (one SpMV), or
+* a :class:`oasisx_amd.fem.Function` on the same space -> ``b = M f`` (one SpMV),
 * any object with ``assemble_rhs_into(storage)`` that fills the device block with the assembled
   linear form -- ``FractionalStep_AB_CN`` passes the rotational pressure update
-  ``p + dp - xi nu div(u)`` this way (reference fracstep.py:237-247).
+  ``p + dp - xi nu div(u)`` this way (reference fracstep.py:237-247), or
+* a callable ``f(x)`` with ``x`` of shape (3, npts) -> (npts,) (what ``ufl`` expressions of the
+  coordinates are in the reference's ``test_projector.py``): ``int f v dx`` by a Gauss-Jacobi rule exact
+  for polynomials of degree ``2 * quadrature_points - 1`` times the test function.
 """
 from __future__ import annotations
 
 import ctypes as C
 
 from . import _lib
-from .fem import FieldStorage, Function, FunctionSpace, cell_geometry
+import numpy as np
+import torch
+
+from .fem import SLICE, FieldStorage, Function, FunctionSpace, _simplex_rule, cell_geometry, local_edges
 from .ksp import KSPSolver
 from .la import SellMatrix
 
@@ -29,6 +35,7 @@ class Projector:
         lib = _lib.load()
         self._function = function
         self._space = space
+        self._metadata = metadata or {}
         mesh = space.mesh
         self._geom = cell_geometry(mesh, space.local_cells)
         cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
@@ -55,8 +62,12 @@ class Projector:
             self._A.mult(f._storage.dev(), self._B.dev(), 1)
         elif hasattr(f, "assemble_rhs_into"):
             f.assemble_rhs_into(self._B)
+        elif callable(f):
+            self._B.dev()[: self._space.n_local, 0] = load_vector(self._space, f, self._geom,
+                                                                 (metadata_points(self._metadata, self._space.degree)))
         else:
-            raise TypeError("Projector: `function` must be a Function on the space or provide assemble_rhs_into()")
+            raise TypeError("Projector: `function` must be a Function on the space, a callable f(x) or provide "
+                            "assemble_rhs_into()")
 
     def solve(self, assemble_rhs: bool = True):
         """Compute the projection; returns the KSP converged reason (function.py:121-135)."""
@@ -67,6 +78,73 @@ class Projector:
     @property
     def x(self):
         return self._x
+
+
+def metadata_points(metadata: dict, degree: int) -> int:
+    """Points per direction of the Gauss-Jacobi rule: ``metadata["quadrature_degree"]`` (the reference's
+    form-compiler metadata) if given, else exact for a degree ``degree + 3`` integrand times the test function."""
+    q = metadata.get("quadrature_degree")
+    if q is None:
+        q = 2 * degree + 3
+    return int(q) // 2 + 1
+
+
+def load_vector(V: FunctionSpace, f, geom: torch.Tensor, n_points: int, chunk: int = 1 << 20) -> torch.Tensor:
+    """b_i = int f phi_i dx over the local cells, for a callable ``f(x)``, x: (3, npts).  Element vectors
+    cell by cell, then every dof SUMS its (cell, local index) contributions in the fixed order of the
+    space's dof -> cell adjacency (no atomics: bit-reproducible).  A set-up / diagnostics functional in
+    torch, not part of the time-step path.  A callable marked ``supports_torch`` is evaluated on the
+    device, any other on the host."""
+    mesh = V.mesh
+    d, dev = mesh.gdim, mesh.device
+    bary_np, w_np = _simplex_rule(d, n_points)
+    nv = d + 1
+    if V.degree == 1:
+        phi_np = bary_np
+    else:
+        cols = [bary_np[:, a] * (2 * bary_np[:, a] - 1) for a in range(nv)]
+        cols += [4 * bary_np[:, a] * bary_np[:, b] for a, b in local_edges(d)]
+        phi_np = np.stack(cols, axis=1)
+    bary = torch.from_numpy(bary_np).to(dev)
+    wphi = torch.from_numpy(w_np[:, None] * phi_np).to(dev)  # (NQ, nd)
+    cells = mesh.cells[V.local_cells]
+    nc, nd = int(cells.shape[0]), V.nd
+    adet = geom[:, d * d]
+    bloc = torch.empty((nc, nd), dtype=torch.float64, device=dev)
+    on_dev = getattr(f, "supports_torch", False)
+    for c0 in range(0, nc, chunk):
+        xc = mesh.coords[cells[c0:c0 + chunk]]  # (m, d+1, d)
+        xq = torch.einsum("qa,mak->mqk", bary, xc)  # (m, NQ, d)
+        X = torch.zeros((3, xq.shape[0] * xq.shape[1]), dtype=torch.float64, device=dev)
+        X[:d] = xq.reshape(-1, d).T
+        fq = f(X) if on_dev else torch.from_numpy(np.asarray(f(X.cpu().numpy()), dtype=np.float64)).to(dev)
+        fq = fq.reshape(xq.shape[0], xq.shape[1])
+        bloc[c0:c0 + chunk] = adet[c0:c0 + chunk, None] * (fq @ wphi)
+    # gather: pair (t, lane) of slice s sits at adj_ptr[s] + t*64 + lane
+    adj = V.adj
+    n = V.n_local
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    bflat = bloc.reshape(-1)
+    T_all = ((adj.adj_ptr[1:] - adj.adj_ptr[:-1]) // SLICE)
+    rows_per = max(SLICE, (chunk // max(int(T_all.max().item()), 1)) // SLICE * SLICE)
+    for r0 in range(0, n, rows_per):
+        r = torch.arange(r0, min(r0 + rows_per, n), device=dev)
+        sl, lane = r // SLICE, r % SLICE
+        T = T_all[sl]
+        tmax = int(T.max().item())
+        t = torch.arange(tmax, device=dev)
+        idx = adj.adj_ptr[sl][:, None] + t[None, :] * SLICE + lane[:, None]
+        ok = t[None, :] < T[:, None]
+        idx = torch.where(ok, idx, torch.zeros_like(idx))
+        cell = adj.adj_cell[idx].to(torch.int64)
+        ok = ok & (cell >= 0)
+        val = bflat[torch.where(ok, cell * nd + adj.adj_loc[idx].to(torch.int64), torch.zeros_like(cell))]
+        val = torch.where(ok, val, torch.zeros_like(val))
+        acc = torch.zeros(r.shape[0], dtype=torch.float64, device=dev)
+        for k in range(tmax):  # fixed order of the adjacency: the same sum on every run
+            acc = acc + val[:, k]
+        out[r] = acc
+    return out
 
 
 class LumpedProject:

@@ -177,6 +177,46 @@ def test_projector_of_a_function(hip):
     assert np.abs(proj.x.x.array - u.x.array).max() < 1e-10
 
 
+@pytest.mark.parametrize("dim,deg,on_device", [(2, 1, False), (2, 2, True), (3, 1, True), (3, 2, False)])
+def test_projector_of_an_expression(hip, dim, deg, on_device):
+    """Projector(callable, space): reference test/test_projector.py projects x[0]**degree onto the degree-`degree`
+    Lagrange space and compares with the interpolant (atol 1e-12 there); also a non-polynomial integrand
+    against the numpy oracle's load vector, and the same bits on a second run (ordered sums, no atomics)."""
+    import torch
+
+    from oasisx_amd import Projector, fem
+    from tests.helpers import tg_mesh
+
+    mesh = tg_mesh(dim, 6 if dim == 3 else 12)
+    V = fem.FunctionSpace(mesh, deg, window=128)
+
+    def poly(x):
+        return x[0] ** deg + 2.0 * x[1] - (x[dim - 1] ** deg if deg == 2 else x[dim - 1])
+
+    poly.supports_torch = on_device
+    proj = Projector(poly, V, [], petsc_options={"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-14, "ksp_atol": 1e-30})
+    assert proj.solve() > 0
+    u = fem.Function(V)
+    u.interpolate(lambda x: x[0] ** deg + 2.0 * x[1] - (x[dim - 1] ** deg if deg == 2 else x[dim - 1]))
+    assert np.abs(proj.x.x.array - u.x.array).max() < 1e-10
+    # a smooth non-polynomial integrand: the load vector against a host evaluation with a finer rule
+    from oasisx_amd.function import load_vector
+
+    def g(x):
+        xp = torch if torch.is_tensor(x) else np
+        return xp.sin(2.0 * x[0]) * xp.exp(x[1])
+
+    g.supports_torch = on_device
+    b1 = load_vector(V, g, proj._geom, 6)
+    b2 = load_vector(V, g, proj._geom, 6)
+    assert torch.equal(b1, b2)
+    b_fine = load_vector(V, g, proj._geom, 10)
+    assert float((b1 - b_fine).abs().max()) < 1e-9 * max(float(b_fine.abs().max()), 1e-30) + 1e-13
+    # sum_i b_i = int g dx (partition of unity)
+    ref = float(b_fine.sum())
+    assert abs(float(b1.sum()) - ref) < 1e-10 * max(abs(ref), 1.0)
+
+
 def test_dirichlet_values_evaluated_on_the_device(hip):
     """A callable marked supports_torch gets device coordinates; the imposed values equal the
     numpy path's (reference test/test_bcs.py: apply == set_bc with the interpolated function)."""
