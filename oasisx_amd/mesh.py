@@ -331,6 +331,36 @@ def create_box(comm, points, n, cell_type=CellType.tetrahedron, device=None, **k
     return Mesh(coords, cells.reshape(-1, 4), comm if comm is not None else COMM_WORLD)
 
 
+def create_delaunay_box(comm, points, n, seed: int = 0, jitter: float = 0.35, device=None) -> Mesh:
+    """A genuinely unstructured simplicial mesh of the box ``points = [p0, p1]``: Delaunay triangulation
+    (scipy / Qhull) of a jittered (n+1)^dim lattice whose boundary points slide only inside their face /
+    edge.  Vertex valence ranges from 1 to ~40 cells in 3-D -- nothing of a box mesh's topology is left.
+    Flat cells on the hull are dropped and the total volume is checked.  The test and benchmark mesh for
+    "what an unstructured mesh gets" (no reference counterpart: DOLFINx reads such meshes from files)."""
+    import math
+
+    from scipy.spatial import Delaunay
+
+    p0, p1 = np.asarray(points[0], dtype=np.float64), np.asarray(points[1], dtype=np.float64)
+    dim = p0.shape[0]
+    rng = np.random.default_rng(seed)
+    ax = np.linspace(-1.0, 1.0, n + 1)
+    G = np.stack(np.meshgrid(*([ax] * dim), indexing="ij"), axis=-1).reshape(-1, dim)
+    h = 2.0 / n
+    move = (rng.random(G.shape) - 0.5) * 2.0 * jitter * h
+    move[np.abs(G) > 1.0 - 1e-9] = 0.0  # a boundary point never leaves its face / edge / corner
+    P = G + move
+    T = Delaunay(P).simplices.astype(np.int64)
+    x0 = P[T[:, 0]]
+    J = np.stack([P[T[:, a]] - x0 for a in range(1, dim + 1)], axis=2)
+    det = np.abs(np.linalg.det(J))
+    keep = det > 1e-9 * h ** dim
+    T = T[keep]
+    assert abs(det[keep].sum() / math.factorial(dim) - 2.0 ** dim) < 1e-9
+    X = p0 + (P + 1.0) * 0.5 * (p1 - p0)  # [-1, 1]^dim -> the box
+    return from_arrays(X, T, comm=comm, device=device)
+
+
 def create_unit_cube(comm, nx, ny, nz, cell_type=CellType.tetrahedron, device=None, **kwargs) -> Mesh:
     return create_box(comm, [[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]], [nx, ny, nz], cell_type, device=device)
 

@@ -308,7 +308,8 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     """Time ONE step of the same workload on the host cores with the C/OpenMP port and compare it
     with the GPU's step from the same state.
 
-    The port is set up from the mesh DEFINITION alone (``mesh_def = (p0, p1, n)`` of the box): its
+    The port is set up from the mesh DEFINITION alone (``mesh_def = (p0, p1, n)`` of the box, or the
+    vertex / cell arrays of an unstructured mesh): its
     own vertex numbering and cell list (oracle ``create_box_mesh``), its own dof numbering, CSR
     patterns and M / K / Ap assembly -- nothing is exported from the GPU but the state vectors
     (u, u1, u2, p, dp), which are carried over through the dof COORDINATES.  The relative L2
@@ -319,8 +320,13 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     mesh = S._mesh
     d = mesh.gdim
     t0 = time.perf_counter()
-    p0, p1, nn = mesh_def
-    coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
+    if isinstance(mesh_def, dict):  # an unstructured mesh is DEFINED by its vertex and cell arrays
+        coords = np.ascontiguousarray(mesh_def["coords"], dtype=np.float64)
+        cells = np.ascontiguousarray(mesh_def["cells"], dtype=np.int64)
+        p0, p1 = mesh_def["lo"], mesh_def["hi"]
+    else:
+        p0, p1, nn = mesh_def
+        coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
     cpu, x_v, x_q = from_mesh(coords, cells, Vi.degree, Q.degree, ksp, body_force=S._body_force)
     del coords, cells
     n, nq = Vi.num_dofs, Q.num_dofs

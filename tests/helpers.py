@@ -85,27 +85,9 @@ def run_tg_pair(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, hip_options=Non
 
 
 def delaunay_box_mesh(n, dim=3, seed=0, jitter=0.35):
-    """A genuinely unstructured simplicial mesh of [-1, 1]^dim: Delaunay triangulation (scipy / Qhull)
-    of a jittered (n+1)^dim lattice whose boundary points slide only inside their face / edge.
-    Vertex valence ranges from 1 to ~40 cells in 3-D -- nothing of a box mesh's topology is left.
-    Returns (points (nv, dim), cells (nc, dim+1) int64); flat cells on the hull are dropped and the
-    total volume is checked."""
-    import math
+    """Arrays (points (nv, dim), cells (nc, dim+1) int64) of oasisx_amd.mesh.create_delaunay_box on [-1, 1]^dim:
+    a genuinely unstructured simplicial mesh (Delaunay triangulation of a jittered lattice)."""
+    from oasisx_amd import mesh as M
 
-    from scipy.spatial import Delaunay
-
-    rng = np.random.default_rng(seed)
-    ax = np.linspace(-1.0, 1.0, n + 1)
-    G = np.stack(np.meshgrid(*([ax] * dim), indexing="ij"), axis=-1).reshape(-1, dim)
-    h = 2.0 / n
-    move = (rng.random(G.shape) - 0.5) * 2.0 * jitter * h
-    move[np.abs(G) > 1.0 - 1e-9] = 0.0  # a boundary point never leaves its face / edge / corner
-    P = G + move
-    T = Delaunay(P).simplices.astype(np.int64)
-    x0 = P[T[:, 0]]
-    J = np.stack([P[T[:, a]] - x0 for a in range(1, dim + 1)], axis=2)
-    det = np.abs(np.linalg.det(J))
-    keep = det > 1e-9 * h ** dim
-    T = T[keep]
-    assert abs(det[keep].sum() / math.factorial(dim) - 2.0 ** dim) < 1e-9
-    return P, T
+    m = M.create_delaunay_box(None, [[-1.0] * dim, [1.0] * dim], n, seed=seed, jitter=jitter, device="cpu")
+    return m.coords.cpu().numpy().copy(), m.cells.cpu().numpy().astype(np.int64)
