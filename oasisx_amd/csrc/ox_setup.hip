@@ -630,6 +630,19 @@ int finish_pattern(ox_pattern_store &P, hipStream_t st) {
   }
   P.bin_ptr.push_back(P.n_slices);
   if (P.bin_width.empty()) P.bin_ptr.assign(1, 0);
+  {  // a bin with fewer than max(64, n_slices / 64) slices joins the next wider one (fem.merge_small_bins)
+    const int64_t thresh = std::max<int64_t>(64, P.n_slices / 64);
+    std::vector<int32_t> bw;
+    std::vector<int64_t> bp(1, 0);
+    for (size_t b = 0; b < P.bin_width.size(); ++b) {
+      const bool last = b + 1 == P.bin_width.size();
+      if (P.bin_ptr[b + 1] - bp.back() >= thresh || last) {
+        bw.push_back(P.bin_width[b]);
+        bp.push_back(P.bin_ptr[b + 1]);
+      }
+    }
+    if (!P.bin_width.empty()) P.bin_width.swap(bw), P.bin_ptr.swap(bp);
+  }
   OX_TRY(P.bin_slices.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_slices, 1)));
   if (P.n_slices)
     OX_HIP(hipMemcpyAsync(P.bin_slices.p, order.data(), sizeof(int32_t) * (size_t)P.n_slices, hipMemcpyHostToDevice, st));
