@@ -243,7 +243,7 @@ class FractionalStep_AB_CN:
         if self._options.get("value_dictionary", True):
             # M and Ap never change again: 1-byte value codes where <= 256 distinct values (la.freeze)
             self._M.freeze()
-            self._K.freeze()  # read by the fused assemble_first only
+            self._K.freeze(pairs="never")  # read by the fused assemble_first only: never multiplied
             self._Ap.freeze()
         if not self._low_memory:  # the rectangular operators (:392-404)
             for fam, Mat, R_, C_, adj_, pos_, pw_ in ((0, self._p_vdxi_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
