@@ -322,12 +322,18 @@ def main():
                    **({"sell_window": args.window} if args.window else {}))
     mesh, S = build(N, args.udeg, options, args.zero_guess)
 
+    def at(f, t):  # the analytic fields are array-API callables: evaluated on the device
+        def g(x):
+            return f(x, t)
+        g.supports_torch = True
+        return g
+
     def set_initial_state():
         clock["t"] = 0.0
         if W["analytic"]:
             for i, f in enumerate(fns):
-                S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
-                S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
+                S._u2[i].interpolate(at(f, -dt))
+                S._u1[i].interpolate(at(f, 0.0))
             S._p.interpolate(lambda x: W["p"](x, -dt / 2.0))
 
     set_initial_state()

@@ -957,10 +957,22 @@ class Function:
 
     def interpolate(self, f):
         """Nodal interpolation of ``f(x)``, x of shape (3, npts) (reference bcs.py:125,133)."""
-        X = self.function_space.tabulate_dof_coordinates().T
         if isinstance(f, Function):
             self.x.array[:] = f.x.array
             return
+        V = self.function_space
+        if getattr(f, "supports_torch", False) and self._comp is not None:
+            # a callable marked ``supports_torch`` (as for DirichletBC values, bcs.py) gets the dof
+            # coordinates as a (3, n) DEVICE tensor and returns a device tensor: no host round trip
+            n = V.n_local
+            Xd = torch.zeros((3, n), dtype=torch.float64, device=V.mesh.device)
+            Xd[: V.mesh.gdim] = V.x[:n].T
+            vals_d = f(Xd)
+            if not torch.is_tensor(vals_d):
+                raise TypeError("a supports_torch callable must return a torch tensor")
+            self._storage.dev()[:n, self._comp] = vals_d.reshape(-1).to(torch.float64)
+            return
+        X = V.tabulate_dof_coordinates().T
         vals = np.asarray(f(X), dtype=np.float64)
         if self._comp is None:
             dim = self._storage.nc
@@ -970,8 +982,21 @@ class Function:
 
 
 def locate_dofs_geometrical(V, marker) -> np.ndarray:
+    """Dofs whose coordinates the marker selects (reference bcs.py:98-103).  The same marker object on the
+    same space is evaluated once: the three velocity components of a solver usually share it, and at
+    128^3 a numpy marker over 17 M dof coordinates costs 0.4 s each time."""
+    cache = V.__dict__.setdefault("_marker_cache", {})
+    try:
+        hit = cache.get(marker)
+    except TypeError:  # unhashable callable
+        hit, cache = None, None
+    if hit is not None:
+        return hit.copy()
     X = V.tabulate_dof_coordinates().T
-    return np.nonzero(np.asarray(marker(X), dtype=bool))[0].astype(np.int32)
+    dofs = np.nonzero(np.asarray(marker(X), dtype=bool))[0].astype(np.int32)
+    if cache is not None:
+        cache[marker] = dofs
+    return dofs.copy()
 
 
 def locate_dofs_topological(V, entity_dim: int, entities) -> np.ndarray:
