@@ -55,8 +55,8 @@ def spmv_bytes(nnz, n_rows, n_cols):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)  # the driver's command line: --steps 20 --warmup 5
+    ap.add_argument("--warmup", type=int, default=5)  # (the first steps after the start need more Krylov iterations)
     ap.add_argument("-N", type=int, default=128, help="cubes per direction")
     ap.add_argument("--udeg", type=int, default=2)
     ap.add_argument("--rtol", type=float, default=1e-8)
