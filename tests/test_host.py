@@ -181,3 +181,46 @@ def test_field_storage_and_function_views():
     assert np.allclose(w.x.array[1::2], 7.0) and np.allclose(w.x.array[0::2], V.tabulate_dof_coordinates()[:, 0])
     Vs, idx = W.sub(1).collapse()
     assert Vs is V and (idx == np.arange(V.num_dofs) * 2 + 1).all()
+
+
+def test_lattice_detection_and_curve_order():
+    """fem.mesh_is_lattice: box meshes are lattices (tiled lexicographic order), a Delaunay triangulation of
+    jittered points is not (Z-order curve); the Z-order key keeps near points near in the numbering."""
+    import torch
+
+    from oasisx_amd import fem
+    from oasisx_amd import mesh as M
+
+    box = M.create_box(None, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [6, 7, 5], device="cpu")
+    rect = M.create_rectangle(None, [[0.0, 0.0], [1.0, 2.0]], [9, 12], device="cpu")
+    dl = M.create_delaunay_box(None, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], 6, seed=1, device="cpu")
+    assert fem.mesh_is_lattice(box) and fem.mesh_is_lattice(rect) and not fem.mesh_is_lattice(dl)
+    x = dl.coords
+    lo = x.min(dim=0).values
+    span = x.max(dim=0).values - lo
+    key = fem.locality_key(x, lo, span, 1, 9, curve=True)
+    assert key.unique().numel() == x.shape[0]  # 18 bits per coordinate: every jittered point has its own key
+    order = torch.argsort(key)
+    # consecutive points of the curve are close on average (much closer than random pairs)
+    d_curve = (x[order][1:] - x[order][:-1]).norm(dim=1).mean()
+    perm = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(0))
+    d_rand = (x[perm][1:] - x[perm][:-1]).norm(dim=1).mean()
+    assert float(d_curve) < 0.5 * float(d_rand)
+
+
+def test_small_width_bins_are_merged_forward():
+    """fem.merge_small_bins: ascending widths, every slice kept, a merged bin is at least as wide as every
+    slice in it, and only the last bin may stay below the threshold."""
+    from oasisx_amd import fem
+
+    widths = np.array([10, 14, 16, 18, 20, 22, 24, 26, 28, 32, 34, 36, 120], dtype=np.int32)
+    counts = np.array([1, 25, 590, 29, 1060, 12, 1160, 3, 880, 530, 1, 26, 2])
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    bw, bp = fem.merge_small_bins(widths, ptr)
+    n = int(ptr[-1])
+    thresh = max(64, n // 64)
+    assert bp[0] == 0 and bp[-1] == n and (np.diff(bw) > 0).all() and len(bw) < len(widths)
+    for b in range(len(bw)):
+        inside = widths[(ptr[1:] > bp[b]) & (ptr[:-1] < bp[b + 1])]
+        assert inside.max() == bw[b]  # LDS sized for the widest slice of the merged bin
+        assert bp[b + 1] - bp[b] >= thresh or b == len(bw) - 1
