@@ -326,7 +326,11 @@ class FractionalStep_AB_CN:
         if getattr(self, "_AU1_valid", False):  # one use per assemble_first, and only if u still is u1
             self._AU1_valid = False
             no = self._no_u
-            if torch.equal(self._U.dev()[:no], self._U1.dev()[:no]):
+            same = torch.equal(self._U.dev()[:no], self._U1.dev()[:no])
+            if self._part is not None and getattr(self._comm, "size", 1) > 1:
+                # every rank must take the same branch: the skipped mat-vec carries a halo exchange
+                same = self._comm.allreduce(0.0 if same else 1.0, op="max") == 0.0
+            if same:
                 ax0 = self._B3
         errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U, ax0=ax0), dtype=np.int32)
         # diff = sum_i || u_i^old - u_i ||_2 (:523-524)
