@@ -153,3 +153,51 @@ def test_c5_pattern_beyond_2_to_31_storage_slots(hip):
         del S
         gc.collect()
         torch.cuda.empty_cache()
+
+
+def test_3d_beltrami_convergence_against_the_analytic_solution(hip):
+    """An oracle-free pin of the whole 3-D path: the Ethier-Steinman Beltrami flow (all three velocity
+    components and the pressure non-trivial, exact Dirichlet data) on N = 8, 16, 32 with dt ~ h.  The
+    nodal velocity error against the ANALYTIC field must fall towards second order;
+    nothing in this test comes from the numpy / C restatements."""
+    import math
+
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+
+    import bench  # the workload definitions of bench.py (analytic fields as array-API callables)
+
+    errs = []
+    for N in (8, 16, 32):
+        W = bench.make_workload("beltrami", N, np, torch)
+        nu, fns = W["nu"], W["fns"]
+        p0, p1 = W["box"]
+        T, steps = 0.04, N // 2
+        dt = T / steps
+        clock = {"t": 0.0}
+
+        def on_boundary(x):
+            on = np.zeros(x.shape[1], dtype=bool)
+            for k in range(3):
+                on |= np.isclose(x[k], p0[k]) | np.isclose(x[k], p1[k])
+            return on
+
+        mesh = M.create_box(None, [p0, p1], [N, N, N])
+        bcs_u = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"]), ox.LocatorMethod.GEOMETRICAL, on_boundary)] for f in fns]
+        ksp = {"pc_type": "jacobi", "ksp_rtol": 1e-11, "ksp_atol": 1e-30, "ksp_max_it": 10000}
+        so = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")}
+        S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[], solver_options=so)
+        for i, f in enumerate(fns):
+            S._u2[i].interpolate(lambda x, f=f: f(x, -dt))
+            S._u1[i].interpolate(lambda x, f=f: f(x, 0.0))
+        S._p.interpolate(lambda x: W["p"](x, -dt / 2.0))
+        for _ in range(steps):
+            clock["t"] += dt
+            S.solve(dt, nu, max_iter=1)
+        X = S._Vi[0][0].tabulate_dof_coordinates().T
+        err = max(float(np.abs(S._u1[i].x.array - fns[i](X, clock["t"])).max()) for i in range(3))
+        errs.append(err)
+        del S, mesh
+        gc.collect()
+    rates = [math.log(errs[k] / errs[k + 1], 2.0) for k in range(2)]
+    assert errs[2] < errs[1] < errs[0] and rates[0] > 1.6 and rates[1] > 1.8, (errs, rates)
