@@ -14,7 +14,16 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
  *     stream-ordered and only ox_ksp_solve blocks (it returns host-visible results);
  *   - all floating point data is float64, all indices int32, offsets int64;
- *   - multi-component vectors are interleaved: v[row*ncomp + comp].
+ *   - multi-component vectors are interleaved: v[row*ncomp + comp];
+ *   - process model: ONE process per GPU and ONE call at a time per process.  The library keeps
+ *     per-process scratch (the reduction scratch of ox_dot / ox_remove_mean, the pinned copy of the
+ *     Krylov state and of the fold table of ox_ksp_solve, the SpMV variant switch, the profiler's event
+ *     list): two host threads calling in concurrently, or two solves in flight on different streams, would
+ *     share it.  This is the reference's model too (one PETSc solve at a time per MPI rank);
+ *   - an x handed to ox_spmv / ox_ksp_solve on a matrix with a pair-slot stream (ps_*) must be FINITE in
+ *     every owned and ghost column: a slot multiplies two adjacent columns and its second half may be the
+ *     code of 0.0 (0 * Inf = NaN where the entry streams would not touch that column; -0.0 sums can come
+ *     out as +0.0).  With finite x the results are bit-identical to the entry streams.
  *
  * Matrix layout: SELL-64 ("sliced ELLPACK", one slice = the 64 rows one CDNA
  * wavefront owns, lane = row).  Inside slice s with width w_s (multiple of OX_KV)
@@ -347,6 +356,12 @@ int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const d
 /* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
  * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
  * continue, at most that many times per component (used when a direct solver was asked for). */
+/* Test / tuning hook.  On one GPU every synchronisation point of the Krylov loops is ended by the kernel
+ * that produces its dot products (the block that arrives last sums the per-block partials in a fixed order
+ * and runs the scalar recurrences); on = 0 restores the separate one-block kernel after every producer (what
+ * partitioned operators always use: the all-reduce sits between the sums and the logic).  Same order of every
+ * sum either way: bit-identical iterates.  Environment: OX_KSP_FOLD=0|1 (read at the first solve). */
+int ox_set_ksp_fold(int on);
 
 /* ---- V3 + A10: nullspace.remove and mean shift (fracstep.py:573-574, 579-591) -------- */
 /* m = (sum_{i<n} w[i]*x[i], all ranks) / wsum;  x[i] -= m for i < n_apply (owned + ghost rows);

@@ -8,217 +8,9 @@
 // every-iteration check would give.  Reductions are two-stage and ordered (no float
 // atomics): results are bit-reproducible run to run.
 #include "ox_kernels.h"
+#include "ox_ksp_dev.h"
 #include "ox_p2p.h"
 #include <type_traits>
-
-struct KspState {
-  double rz[OX_MAXC], alpha[OX_MAXC], beta[OX_MAXC], omega[OX_MAXC], rho[OX_MAXC];
-  double bn[OX_MAXC], rn[OX_MAXC];
-  int active[OX_MAXC], reason[OX_MAXC], its[OX_MAXC];
-  int restart[OX_MAXC];   // BiCGStab: next k_bcgs_p re-seeds rhat <- r for this column
-  int nrestart[OX_MAXC];
-  int done;  // all components finished
-  int pad[2];
-};
-
-struct KspParams {
-  double rtol, atol;
-  int max_it;
-  int nc;        // columns of THIS launch (sums are indexed 0..nc-1)
-  int c0;        // state column of launch column 0 (narrowed continuation: the one live column)
-  int nc_total;  // columns of the solve
-  int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
-};
-
-enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT };
-
-__device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P) {
-  if (!(rn == rn) || isinf(rn)) return OX_DIVERGED_NANORINF;
-  if (rn <= P.atol) return OX_CONVERGED_ATOL;
-  if (rn <= P.rtol * bn) return OX_CONVERGED_RTOL;
-  return 0;
-}
-
-// Scalar logic of one synchronisation point, run by thread c for component c.
-// `s` holds the globally reduced sums of that point.
-template <int PH>
-__device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int cl, const KspParams &P) {
-  const int NC = P.nc;
-  const int c = P.c0 + cl;          // state column
-  const double *s = s_all + cl - c;  // so that s[c], s[NC + c], ... address launch column cl
-  if (PH == PH_CG_INIT) {  // s = {r.z, z.z, (Db).(Db)}
-    S->rz[c] = s[c];
-    S->rn[c] = sqrt(s[NC + c]);
-    S->bn[c] = sqrt(s[2 * NC + c]);
-    S->its[c] = 0;
-    S->alpha[c] = 0.0;
-    S->beta[c] = 0.0;
-    const int r = ksp_test(S->rn[c], S->bn[c], P);
-    S->reason[c] = r;
-    S->active[c] = (r == 0);
-  } else if (PH == PH_CG_A) {  // s = {p.q}
-    if (S->active[c]) {
-      const double pq = s[c];
-      if (pq == 0.0 || !(pq == pq)) {
-        S->reason[c] = (pq == pq) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
-        S->active[c] = 0;
-        S->alpha[c] = 0.0;
-      } else {
-        S->alpha[c] = S->rz[c] / pq;
-      }
-    } else {
-      S->alpha[c] = 0.0;
-    }
-  } else if (PH == PH_CG_B) {  // s = {r.z (new), z.z}
-    if (S->active[c]) {
-      S->its[c] += 1;
-      S->rn[c] = sqrt(s[NC + c]);
-      int r = ksp_test(S->rn[c], S->bn[c], P);
-      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
-      if (r) {
-        S->reason[c] = r;
-        S->active[c] = 0;
-        S->beta[c] = 0.0;
-      } else {
-        S->beta[c] = s[c] / S->rz[c];
-        S->rz[c] = s[c];
-      }
-    } else {
-      S->beta[c] = 0.0;
-    }
-  } else if (PH == PH_CGS_INIT) {  // s = {r.u, u.u, (Db).(Db), w.u}   (u = D^-1 r, w = A u)
-    S->rz[c] = s[c];
-    S->rn[c] = sqrt(s[NC + c]);
-    S->bn[c] = sqrt(s[2 * NC + c]);
-    S->its[c] = 0;
-    S->beta[c] = 0.0;
-    int r = ksp_test(S->rn[c], S->bn[c], P);
-    const double wu = s[3 * NC + c];
-    if (r == 0 && (wu == 0.0 || !(wu == wu))) r = (wu == wu) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
-    S->reason[c] = r;
-    S->active[c] = (r == 0);
-    S->alpha[c] = r == 0 ? s[c] / wu : 0.0;
-  } else if (PH == PH_CGS_IT) {  // s = {r.u, u.u (new residual), w.u}: the ONE reduction of the iteration
-    if (S->active[c]) {
-      S->its[c] += 1;
-      S->rn[c] = sqrt(s[NC + c]);
-      int r = ksp_test(S->rn[c], S->bn[c], P);
-      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
-      if (r == 0) {
-        // beta = gamma'/gamma;  alpha = gamma' / (delta - beta gamma'/alpha)   (Chronopoulos & Gear)
-        const double g = s[c], beta = g / S->rz[c];
-        const double den = s[2 * NC + c] - beta * g / S->alpha[c];
-        if (den == 0.0 || !(den == den)) r = (den == den) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
-        else {
-          S->beta[c] = beta;
-          S->alpha[c] = g / den;
-          S->rz[c] = g;
-        }
-      }
-      if (r) {
-        S->reason[c] = r;
-        S->active[c] = 0;
-        S->alpha[c] = 0.0;
-        S->beta[c] = 0.0;
-      }
-    } else {
-      S->alpha[c] = 0.0;
-      S->beta[c] = 0.0;
-    }
-  } else if (PH == PH_BCGS_INIT) {  // s = {r.r, (Db).(Db)}  (r already preconditioned)
-    S->rn[c] = sqrt(s[c]);
-    S->bn[c] = sqrt(s[NC + c]);
-    S->its[c] = 0;
-    S->alpha[c] = 1.0;
-    S->omega[c] = 1.0;
-    S->restart[c] = 0;
-    S->nrestart[c] = 0;
-    const int r = ksp_test(S->rn[c], S->bn[c], P);
-    S->reason[c] = r;
-    S->active[c] = (r == 0);
-    // first iteration: rho_new = rhat.r = r.r, beta = (rho_new/1)*(1/1); p = v = 0
-    S->rho[c] = s[c];
-    S->beta[c] = S->active[c] ? s[c] : 0.0;
-    if (S->active[c] && s[c] == 0.0) {
-      S->reason[c] = OX_DIVERGED_BREAKDOWN;
-      S->active[c] = 0;
-    }
-  } else if (PH == PH_BCGS_1) {  // s = {rhat.v}
-    S->restart[c] = 0;  // consumed by the k_bcgs_p that ran just before
-    if (S->active[c]) {
-      const double rv = s[c];
-      if (rv == 0.0 || !(rv == rv)) {
-        S->reason[c] = (rv == rv) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
-        S->active[c] = 0;
-        S->alpha[c] = 0.0;
-      } else {
-        S->alpha[c] = S->rho[c] / rv;
-      }
-    } else {
-      S->alpha[c] = 0.0;
-    }
-  } else if (PH == PH_BCGS_2) {  // s = {t.t, t.s}
-    if (S->active[c]) {
-      const double tt = s[c];
-      S->omega[c] = (tt != 0.0) ? s[NC + c] / tt : 0.0;
-    } else {
-      S->omega[c] = 0.0;
-    }
-  } else if (PH == PH_BCGS_3) {  // s = {r.r, rhat.r}
-    if (S->active[c]) {
-      S->its[c] += 1;
-      S->rn[c] = sqrt(s[c]);
-      int r = ksp_test(S->rn[c], S->bn[c], P);
-      bool reseed = false;
-      if (r == 0 && (S->omega[c] == 0.0 || s[NC + c] == 0.0)) {
-        // rho = rhat.r = 0 (or omega = 0) with an unconverged residual: PETSc stops here.  With
-        // restarts allowed, re-seed the shadow residual (rhat <- r, p <- r) and carry on.
-        if (S->nrestart[c] < P.max_restarts && s[c] > 0.0) reseed = true;
-        else r = OX_DIVERGED_BREAKDOWN;
-      }
-      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
-      if (r) {
-        S->reason[c] = r;
-        S->active[c] = 0;
-        S->beta[c] = 0.0;
-      } else if (reseed) {
-        S->restart[c] = 1;
-        S->nrestart[c] += 1;
-        S->rho[c] = s[c];  // rhat.r with rhat = r
-        S->beta[c] = 0.0;  // p = r
-        S->alpha[c] = 1.0;
-        S->omega[c] = 1.0;
-      } else {
-        S->beta[c] = (s[NC + c] / S->rho[c]) * (S->alpha[c] / S->omega[c]);
-        S->rho[c] = s[NC + c];
-      }
-    } else {
-      S->beta[c] = 0.0;
-    }
-  }
-}
-
-__device__ __forceinline__ void ksp_finish(KspState *S, int nc) {
-  int any = 0;
-  for (int c = 0; c < nc; ++c) any |= S->active[c];
-  S->done = !any;
-}
-
-// The state block is staged in LDS: one coalesced load, the (dependent, branchy) scalar logic at
-// LDS latency, one coalesced store -- instead of ~10 serialized global round trips per phase.
-static_assert(sizeof(KspState) % 8 == 0, "KspState is copied in 8-byte words");
-constexpr int KSP_STATE_WORDS = sizeof(KspState) / 8;
-
-__device__ __forceinline__ void ksp_state_load(KspState *sh, const KspState *S) {
-  if (threadIdx.x < KSP_STATE_WORDS)
-    reinterpret_cast<unsigned long long *>(sh)[threadIdx.x] =
-        reinterpret_cast<const unsigned long long *>(S)[threadIdx.x];
-}
-__device__ __forceinline__ void ksp_state_store(KspState *S, const KspState *sh) {
-  if (threadIdx.x < KSP_STATE_WORDS)
-    reinterpret_cast<unsigned long long *>(S)[threadIdx.x] =
-        reinterpret_cast<const unsigned long long *>(sh)[threadIdx.x];
-}
 
 // Fused: reduce per-block partials (fixed order) + scalar logic.  One wide block.
 // second partial array of a synchronisation point (the single-reduction CG merges the sums of the
@@ -242,7 +34,6 @@ __device__ __forceinline__ void ksp_gather2(const double *__restrict__ partial, 
   }
 }
 
-constexpr bool ksp_is_init(int ph) { return ph == PH_CG_INIT || ph == PH_BCGS_INIT || ph == PH_CGS_INIT; }
 
 template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
@@ -324,17 +115,18 @@ __global__ __launch_bounds__(64) void k_ksp_logic(KspState *S, const double *__r
 
 // ------------------------------- vector kernels ------------------------------------------
 // thread = row, NC interleaved components per row (24-B contiguous per lane for NC = 3).
-#define OX_ROW_LOOP                                 \
-  const int64_t stride_ = (int64_t)gridDim.x * 256; \
-  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride_)
+// (nwb_: work blocks of the launch -- a folded producer's grid carries OX_FOLD_R reducer blocks more)
+#define OX_ROW_LOOP_N(nwb_)                         \
+  const int64_t stride_ = (int64_t)(nwb_) * 256;    \
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n && (int)blockIdx.x < (nwb_); row += stride_)
+#define OX_ROW_LOOP OX_ROW_LOOP_N(gridDim.x)
 
+// block sum of the kernel's dot products, then the end of the synchronisation point (ox_ksp_dev.h): the
+// partial sums are stored and, when folded, the last block to arrive reduces them and runs the scalar logic
 template <int NV>
-__device__ __forceinline__ void ksp_store_partial(double (&s)[NV], double *red, double *partial) {
-  ox_block_sum_256<NV>(s, red);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
-  }
+__device__ __forceinline__ void ksp_store_partial(double (&s)[NV], KspFoldLds &fl, double *partial, const KspFold &fold) {
+  ox_block_sum_256<NV>(s, fl.red);
+  ksp_arrive<NV>(s, partial, fold, fl);
 }
 
 // Flat traversal of an interleaved (n x NC) block: every thread takes TWO consecutive elements, so
@@ -344,9 +136,11 @@ __device__ __forceinline__ void ksp_store_partial(double (&s)[NV], double *red, 
 // f(e, c0, r0, c1, r1, two): elements e (column c0, row r0) and e+1 (c1, r1); two = false for the
 // odd tail element.
 template <int NC, class F>
-__device__ __forceinline__ void ox_flat_pairs(int64_t n, F &&f) {
+__device__ __forceinline__ void ox_flat_pairs(int64_t n, F &&f, int nwb = 0 /* work blocks; 0: the whole grid */) {
   const int64_t tot = n * NC, n2 = tot >> 1;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (nwb <= 0) nwb = gridDim.x;
+  if ((int)blockIdx.x >= nwb) return;
+  const int64_t stride = (int64_t)nwb * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
     const int64_t e = 2 * i;
     const int64_t r0 = e / NC;
@@ -390,12 +184,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__restrict__ b, double *x,
                                                  const double *q, const double *__restrict__ dinv,
                                                  double *vr, double *vp, int guess,
-                                                 double *partial) {
-  __shared__ double red[4 * 3 * NC];
+                                                 double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   double s[3 * NC];
 #pragma unroll
   for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP {
+  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -412,7 +206,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
       s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
     }
   }
-  ksp_store_partial<3 * NC>(s, red, partial);
+  ksp_store_partial<3 * NC>(s, fl, partial, fold);
 }
 
 // CG, first vector kernel of an iteration: r -= alpha q; z = D^-1 r (not stored); partial = {r.z, z.z}.
@@ -422,8 +216,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *vr,
                                                     const double *__restrict__ vq,
                                                     const double *__restrict__ dinv,
-                                                    double *partial) {
-  __shared__ double red[4 * 2 * NC];
+                                                    double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   if (S->done) return;
   double alpha[NC], s[2 * NC];
 #pragma unroll
@@ -447,8 +241,8 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
       ox_acc<NC>(s, 0, cb, r.y, z.y);
       ox_acc<NC>(s, NC, cb, z.y, z.y);
     }
-  });
-  ksp_store_partial<2 * NC>(s, red, partial);
+  }, fold.args ? fold.nwb : 0);
+  ksp_store_partial<2 * NC>(s, fl, partial, fold);
 }
 
 // CG, second vector kernel: x += alpha p (the iteration's alpha, still in the state); p = D^-1 r + beta p.
@@ -485,12 +279,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cgs_init(int64_t n, const double *__restrict__ b, double *x,
                                                   const double *q, const double *__restrict__ dinv,
                                                   double *vr, double *vu, double *vp, double *vs, int guess,
-                                                  double *partial) {
-  __shared__ double red[4 * 3 * NC];
+                                                  double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   double s[3 * NC];
 #pragma unroll
   for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP {
+  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -509,7 +303,7 @@ __global__ __launch_bounds__(256) void k_cgs_init(int64_t n, const double *__res
       s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
     }
   }
-  ksp_store_partial<3 * NC>(s, red, partial);
+  ksp_store_partial<3 * NC>(s, fl, partial, fold);
 }
 
 // Single-reduction CG, the whole vector update of an iteration in one pass:
@@ -520,8 +314,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S, int c0, double *x, double *vr,
                                                     double *vu, double *vp, double *vs,
                                                     const double *__restrict__ vw,
-                                                    const double *__restrict__ dinv, double *partial) {
-  __shared__ double red[4 * 2 * NC];
+                                                    const double *__restrict__ dinv, double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   if (S->done) return;
   double alpha[NC], beta[NC], s[2 * NC];
 #pragma unroll
@@ -559,8 +353,8 @@ __global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S
       ox_acc<NC>(s, 0, cb, r.y, u.y);
       ox_acc<NC>(s, NC, cb, u.y, u.y);
     }
-  });
-  ksp_store_partial<2 * NC>(s, red, partial);
+  }, fold.args ? fold.nwb : 0);
+  ksp_store_partial<2 * NC>(s, fl, partial, fold);
 }
 
 // BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = v = 0
@@ -570,12 +364,12 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
                                                    double *x, const double *q,
                                                    const double *__restrict__ dinv, double *vr,
                                                    double *vrhat, double *vp, double *vv, int guess,
-                                                   double *partial) {
-  __shared__ double red[4 * 2 * NC];
+                                                   double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   double s[2 * NC];
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP {
+  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -594,7 +388,7 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
       s[NC + c] = fma(db, db, s[NC + c]);
     }
   }
-  ksp_store_partial<2 * NC>(s, red, partial);
+  ksp_store_partial<2 * NC>(s, fl, partial, fold);
 }
 
 // BiCGStab: p = r + beta (p - omega v)   (or, on a restart: rhat <- r, p <- r)
@@ -652,8 +446,8 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
                                                 const double *__restrict__ vrhat,
                                                 const double *__restrict__ vp,
                                                 const double *__restrict__ vs,
-                                                const double *__restrict__ vt, double *partial) {
-  __shared__ double red[4 * 2 * NC];
+                                                const double *__restrict__ vt, double *partial, KspFold fold) {
+  __shared__ KspFoldLds fl;
   if (S->done) return;
   double alpha[NC], omega[NC], s[2 * NC];
 #pragma unroll
@@ -681,34 +475,41 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
       ox_acc<NC>(s, 0, cb, r.y, r.y);
       ox_acc<NC>(s, NC, cb, h.y, r.y);
     }
-  });
-  ksp_store_partial<2 * NC>(s, red, partial);
+  }, fold.args ? fold.nwb : 0);
+  ksp_store_partial<2 * NC>(s, fl, partial, fold);
 }
 
 // ------------------------------- host driver ---------------------------------------------
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// One block reads partials at ~45 GB/s: the 66 312 x 6 partials of a velocity SpMV (3.2 MB) kept the
-// scalar kernel of that synchronisation point busy for 79 us.  From OX_PRERED_MIN doubles on, blocks of
-// OX_PRERED_CHUNK partial rows are summed first (fixed order) and the scalar kernel reads their sums.
+// One block reads partials at ~45 GB/s: the 66 312 x 6 partials of a velocity SpMV (3.2 MB) kept the scalar
+// kernel of that synchronisation point busy for 79 us.  So blocks of rows are summed first (fixed order)
+// and the scalar kernel reads their sums:
+//   * up to OX_FOLD_MAX_ROWS rows: OX_FOLD_R blocks over the row ranges of the folded path's reducer blocks
+//     (ox_ksp_dev.h) -- the unfolded path then adds in exactly the order of the folded one;
+//   * beyond (never folded): chunks of OX_PRERED_CHUNK rows.
 #define OX_PRERED_CHUNK 256
-#define OX_PRERED_MIN 16384
 #define OX_PRERED_OFFSET 64  // doubles of the sums region kept for the sums themselves
-__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ partial, int nparts, int nv,
+__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ partial, int nparts, int nv, int rows_per_block,
                                                    double *__restrict__ out) {
   __shared__ double red[16 * OX_MAX_NV];
-  const int r0 = blockIdx.x * OX_PRERED_CHUNK;
-  const int cnt = min(OX_PRERED_CHUNK, nparts - r0);
+  const int r0 = min(nparts, (int)blockIdx.x * rows_per_block);
+  const int cnt = min(rows_per_block, nparts - r0);
   double v[OX_MAX_NV];
   ox_gather_partials(partial + (size_t)r0 * nv, cnt, nv, v);
   ox_block_sum_wide(v, nv, red);
   if (threadIdx.x == 0)
     for (int i = 0; i < nv; ++i) out[(size_t)blockIdx.x * nv + i] = v[i];
 }
-static inline int ksp_prered_rows(int nparts) { return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK; }
+// blocks of the pre-reduction (0: none -- partitioned operators, which never fold, skip it for small arrays)
+static inline int ksp_prered_rows(int nparts, int nv, bool mirror_fold) {
+  if (nparts <= OX_FOLD_MAX_ROWS) return (mirror_fold || (int64_t)nparts * nv >= 16384) ? OX_FOLD_R : 0;
+  return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK;
+}
+static inline int ksp_prered_rpb(int nparts) { return nparts <= OX_FOLD_MAX_ROWS ? ox_fold_rpg(nparts) : OX_PRERED_CHUNK; }
 
 struct KspLayout {
-  size_t state, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
+  size_t state, sums, partial, partial2, fold_gran, fold_ggran, fold_tab, fold_end, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
 };
 
@@ -722,9 +523,17 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
-  L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (size_t)(ksp_prered_rows(L.nparts_max) + 1) * OX_MAX_NV));
+  const size_t prered_max = (size_t)((L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK > OX_FOLD_R
+                                         ? (L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK : OX_FOLD_R);
+  L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (prered_max + 1) * OX_MAX_NV));
   L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
-  L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * OX_MAXC);
+  // folded synchronisation points (ox_ksp_dev.h): tagged granules of the work blocks' sums, of the group sums,
+  // and the per-phase argument table
+  L.fold_gran = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * OX_MAXC);
+  L.fold_ggran = L.fold_gran + ox_align(16 * (size_t)OX_FOLD_MAX_ROWS * 3 * OX_MAXC);
+  L.fold_tab = L.fold_ggran + ox_align(16 * (size_t)OX_FOLD_R * OX_MAX_NV);
+  L.fold_end = L.fold_tab + ox_align(sizeof(KspFoldArgs) * 2 * PH_COUNT);
+  L.vec0 = L.fold_end;
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
   L.narrow0 = L.vec0 + L.vec_stride * L.nvec;
   L.narrow_stride = ox_align(sizeof(double) * (size_t)n_cols);
@@ -737,6 +546,11 @@ extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, i
 }
 
 static KspState *g_state_host = nullptr;
+static int g_ksp_fold = -1;
+extern "C" int ox_set_ksp_fold(int on) {  // tuning / test hook: 0 = separate scalar kernels everywhere
+  g_ksp_fold = on ? 1 : 0;
+  return 0;
+}
 
 
 template <int PH>
@@ -744,16 +558,14 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
                           const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
   {
     double *scr = sums + OX_PRERED_OFFSET;
-    if ((int64_t)nparts * nv >= OX_PRERED_MIN) {
-      const int g = ksp_prered_rows(nparts);
-      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, scr);
+    if (const int g = ksp_prered_rows(nparts, nv, !dist)) {
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, ksp_prered_rpb(nparts), scr);
       partial = scr;
       nparts = g;
       scr += (size_t)g * nv;
     }
-    if (B.nv > 0 && (int64_t)B.nparts * B.nv >= OX_PRERED_MIN) {
-      const int g = ksp_prered_rows(B.nparts);
-      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, scr);
+    if (const int g = B.nv > 0 ? ksp_prered_rows(B.nparts, B.nv, !dist) : 0) {
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, ksp_prered_rpb(B.nparts), scr);
       B.partial = scr;
       B.nparts = g;
     }
@@ -810,18 +622,57 @@ struct KspCtx {
   const ox_dist *dist;
   hipStream_t st;
   int nb, nbs;
+  bool fold;       // the producer kernels end their synchronisation points themselves (single GPU)
+  ox_u64 *fold_gran, *fold_ggran;
+  KspFoldArgs *fold_tab;  // device [2][PH_COUNT]: [0] the lock-step columns, [1] the narrowed continuation
+  unsigned *epoch;        // folded launches of this solve so far
 };
+
+// can the producer of a synchronisation point with `nparts` partial rows end it itself?
+static inline bool ksp_folds(const KspCtx &C, int nparts) { return C.fold && nparts <= OX_FOLD_MAX_ROWS; }
+
+// what that producer needs (args == nullptr: it only stores its partial sums and ksp_sync_point runs)
+static inline KspFold ksp_fold(const KspCtx &C, const KspParams &P, int phase, int nparts) {
+  KspFold F{};
+  if (ksp_folds(C, nparts)) {
+    F.args = C.fold_tab + (P.nc == P.nc_total ? 0 : PH_COUNT) + phase;
+    F.gran = C.fold_gran;
+    F.ggran = C.fold_ggran;
+    F.epoch = ++*C.epoch;
+    F.nwb = nparts;
+  }
+  return F;
+}
+static KspFoldArgs *g_fold_tab_host = nullptr;  // pinned staging of one table half
+static int ksp_fold_upload(const KspCtx &C, const KspParams &P) {
+  if (!C.fold) return 0;
+  if (!g_fold_tab_host) OX_HIP(hipHostMalloc(&g_fold_tab_host, sizeof(KspFoldArgs) * 2 * PH_COUNT));
+  KspFoldArgs *h = g_fold_tab_host + (P.nc == P.nc_total ? 0 : PH_COUNT);
+  for (int ph = 0; ph < PH_COUNT; ++ph) h[ph] = KspFoldArgs{C.S, P, ph};
+  OX_HIP(hipMemcpyAsync(C.fold_tab + (h - g_fold_tab_host), h, sizeof(KspFoldArgs) * PH_COUNT, hipMemcpyHostToDevice, C.st));
+  return 0;
+}
+// the synchronisation point of phase PH: nothing to launch when the producer was folded
+#define KSP_SYNC(PH, partial, nparts, nv)                                                                    \
+  do {                                                                                                       \
+    if (!ksp_folds(C, nparts) && ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st)) return -1; \
+  } while (0)
+// grid of a producer kernel with nwb work blocks
+#define KSP_GRID(nwb) dim3((nwb) + (ksp_folds(C, (nwb)) ? OX_FOLD_R : 0))
 
 template <int NC>
 static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
-    if (ksp_sync_point<PH_CG_A>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
-    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial);
+    const KspFold fa = ksp_fold(C, P, PH_CG_A, C.nbs);
+    if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st, fa.args ? &fa : nullptr))
+      return -1;
+    KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
+    hipLaunchKernelGGL((k_cg_update1<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial,
+                       ksp_fold(C, P, PH_CG_B, C.nb));
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_CG_B>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
+    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.dinv, V.p, 0);
     OX_LAUNCH_CHECK();
   }
@@ -836,7 +687,7 @@ static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_cgs_update<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.u, V.p, V.s, V.w,
-                       C.dinv, C.partial);
+                       C.dinv, C.partial, KspFold{});
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st,
@@ -853,16 +704,20 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
-    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
-    if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
+    const KspFold f1 = ksp_fold(C, P, PH_BCGS_1, C.nbs);
+    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st, f1.args ? &f1 : nullptr))
+      return -1;
+    KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC);
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
-    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st)) return -1;
-    if (ksp_sync_point<PH_BCGS_2>(C.S, C.partial, C.nbs, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
-    hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                       V.t, C.partial);
+    const KspFold f2 = ksp_fold(C, P, PH_BCGS_2, C.nbs);
+    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st, f2.args ? &f2 : nullptr))
+      return -1;
+    KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC);
+    hipLaunchKernelGGL((k_bcgs_x<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
+                       V.t, C.partial, ksp_fold(C, P, PH_BCGS_3, C.nb));
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_BCGS_3>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st)) return -1;
+    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC);
   }
   return 0;
 }
@@ -932,6 +787,20 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
   C.nbs = ox_spmv_dist_nparts(A, dist);
+  // Folded synchronisation points (ox_ksp_dev.h): on one GPU the producer kernels end them themselves.  A
+  // partitioned operator needs the all-reduce between the sums and the logic, and the single-reduction CG
+  // merges two partial arrays: both keep the separate kernel.  OX_KSP_FOLD=0 restores it everywhere (A/B).
+  if (g_ksp_fold < 0) g_ksp_fold = getenv("OX_KSP_FOLD") ? atoi(getenv("OX_KSP_FOLD")) : 1;
+  C.fold = g_ksp_fold && !dist && ksp_type != OX_KSP_CG_SINGLE;
+  C.fold_gran = reinterpret_cast<ox_u64 *>(work + L.fold_gran);
+  C.fold_ggran = reinterpret_cast<ox_u64 *>(work + L.fold_ggran);
+  C.fold_tab = reinterpret_cast<KspFoldArgs *>(work + L.fold_tab);
+  unsigned epoch = 0;
+  C.epoch = &epoch;
+  if (C.fold) {  // no tag of an earlier solve may look like one of this solve's epochs
+    OX_HIP(hipMemsetAsync(C.fold_gran, 0, L.fold_tab - L.fold_gran, st));
+    if (ksp_fold_upload(C, P)) return -1;
+  }
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
@@ -944,7 +813,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
       if (ox_spmv_dist(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
     hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.w, dinv, V.r, V.u,
-                       V.p, V.s, guess, C.partial);
+                       V.p, V.s, guess, C.partial, KspFold{});
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, dist, st)) return -1;
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
@@ -954,19 +823,19 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
-                       V.p, guess, C.partial);
+    hipLaunchKernelGGL((k_cg_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
+                       V.p, guess, C.partial, ksp_fold(C, P, PH_CG_INIT, C.nb));
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_CG_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st)) return -1;
+    KSP_SYNC(PH_CG_INIT, C.partial, C.nb, 3 * NC);
   } else {
     V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
-                       V.rhat, V.p, V.v, guess, C.partial);
+    hipLaunchKernelGGL((k_bcgs_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
+                       V.rhat, V.p, V.v, guess, C.partial, ksp_fold(C, P, PH_BCGS_INIT, C.nb));
     OX_LAUNCH_CHECK();
-    if (ksp_sync_point<PH_BCGS_INIT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, dist, st)) return -1;
+    KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC);
   }
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;
@@ -1026,6 +895,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
         KspParams P1 = P;
         P1.nc = 1;
         P1.c0 = live;
+        if (ksp_fold_upload(C, P1)) return -1;
         if (run_ahead) {
           const int bsz = batch_of(check_every);
           auto it1 = [&](int count) -> int {
@@ -1057,6 +927,9 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, dinv, V.p, 1);
     OX_LAUNCH_CHECK();
   }
+  for (int c = 0; c < NC; ++c)
+    if (g_state_host->reason[c] == OX_DIVERGED_FOLD_TIMEOUT)
+      OX_FAIL("ox_ksp_solve: a folded synchronisation point timed out waiting for a block's partial sums");
   for (int c = 0; c < NC; ++c) {
     result->reason[c] = g_state_host->reason[c];
     result->its[c] = g_state_host->its[c];

@@ -879,9 +879,16 @@ class FieldStorage:
         self._shared = self._dev.device.type == "cpu"
         self._host = self._dev.numpy()[: self.n] if self._shared else None
         self._out = False
+        # bumped whenever the block may have been written from outside the solver's own kernels (a host
+        # check-out copied back, ``mark_written``): FractionalStep_AB_CN keeps "u still equals u1" on it
+        self.generation = 0
+
+    def mark_written(self):
+        self.generation += 1
 
     def host(self) -> np.ndarray:
         if self._shared:
+            self.generation += 1  # the caller may write through the shared view
             return self._host
         if not self._out:
             if self._host is None:
@@ -894,6 +901,7 @@ class FieldStorage:
         if self._out:
             self._dev[: self.n].copy_(torch.from_numpy(self._host))
             self._out = False
+            self.generation += 1
         return self._dev
 
     def ptr(self):
@@ -971,6 +979,7 @@ class Function:
             if not torch.is_tensor(vals_d):
                 raise TypeError("a supports_torch callable must return a torch tensor")
             self._storage.dev()[:n, self._comp] = vals_d.reshape(-1).to(torch.float64)
+            self._storage.mark_written()
             return
         X = V.tabulate_dof_coordinates().T
         vals = np.asarray(f(X), dtype=np.float64)
@@ -981,21 +990,42 @@ class Function:
             self.x.array[:] = vals.reshape(-1)
 
 
+_marker_scope: dict | None = None  # see shared_marker_evaluations()
+
+
+class shared_marker_evaluations:
+    """Scope inside which ``locate_dofs_geometrical`` evaluates one marker object once per space.
+    ``FractionalStep_AB_CN.__init__`` opens it around the creation of its boundary conditions: the gdim
+    velocity components usually share their marker, and at 128^3 a numpy marker over 17 M dof coordinates
+    costs 0.4 s each time.  Outside such a scope every call evaluates the marker, as DOLFINx does
+    (reference bcs.py:98-103) -- a marker that reads mutable state is never served from a stale cache."""
+
+    def __enter__(self):
+        global _marker_scope
+        self._outer, _marker_scope = _marker_scope, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _marker_scope
+        _marker_scope = self._outer
+        return False
+
+
 def locate_dofs_geometrical(V, marker) -> np.ndarray:
-    """Dofs whose coordinates the marker selects (reference bcs.py:98-103).  The same marker object on the
-    same space is evaluated once: the three velocity components of a solver usually share it, and at
-    128^3 a numpy marker over 17 M dof coordinates costs 0.4 s each time."""
-    cache = V.__dict__.setdefault("_marker_cache", {})
-    try:
-        hit = cache.get(marker)
-    except TypeError:  # unhashable callable
-        hit, cache = None, None
-    if hit is not None:
-        return hit.copy()
+    """Dofs whose coordinates the marker selects (reference bcs.py:98-103)."""
+    cache, key = _marker_scope, None
+    if cache is not None:
+        try:
+            key = (id(V), marker)
+            hit = cache.get(key)
+        except TypeError:  # unhashable callable
+            hit, cache = None, None
+        if hit is not None:
+            return hit.copy()
     X = V.tabulate_dof_coordinates().T
     dofs = np.nonzero(np.asarray(marker(X), dtype=bool))[0].astype(np.int32)
     if cache is not None:
-        cache[marker] = dofs
+        cache[key] = dofs
     return dofs.copy()
 
 

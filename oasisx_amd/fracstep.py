@@ -148,13 +148,16 @@ class FractionalStep_AB_CN:
         self._b2 = Function(Q, "b2", self._B2, 0)
 
         # ---- boundary conditions (reference fracstep.py:196-200,218-227) ---------------------
+        from .fem import shared_marker_evaluations
+
         self._bcs_u = bcs_u
-        for bc_i in self._bcs_u:
-            for bc in bc_i:
-                bc.create_bc(Vi)
         self._bcs_p = bcs_p
-        for bcp in self._bcs_p:  # reference fracstep.py:219-227
-            bcp.create_bcs(Vi, Q)
+        with shared_marker_evaluations():  # the gdim components usually share one marker object
+            for bc_i in self._bcs_u:
+                for bc in bc_i:
+                    bc.create_bc(Vi)
+            for bcp in self._bcs_p:  # reference fracstep.py:219-227
+                bcp.create_bcs(Vi, Q)
         if len(self._bcs_p) > 0:
             self._p_surf = [[bcp.rhs(i) for bcp in self._bcs_p] for i in range(gdim)]
 
@@ -325,13 +328,17 @@ class FractionalStep_AB_CN:
         ax0 = None
         if getattr(self, "_AU1_valid", False):  # one use per assemble_first, and only if u still is u1
             self._AU1_valid = False
-            no = self._no_u
-            same = torch.equal(self._U.dev()[:no], self._U1.dev()[:no])
+            # u was copied into u1 at the end of the last step (solve()); since then neither block has been
+            # written by one of this class's phases (they clear the token) nor from outside (host check-outs
+            # copied back, interpolate, KSPSolver.solve bump FieldStorage.generation): no device compare,
+            # no host synchronisation
+            same = getattr(self, "_u_is_u1", None) == (self._U.generation, self._U1.generation)
             if self._part is not None and getattr(self._comm, "size", 1) > 1:
                 # every rank must take the same branch: the skipped mat-vec carries a halo exchange
                 same = self._comm.allreduce(0.0 if same else 1.0, op="max") == 0.0
             if same:
                 ax0 = self._B3
+        self._u_is_u1 = None  # the solve below writes u
         errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U, ax0=ax0), dtype=np.int32)
         # diff = sum_i || u_i^old - u_i ||_2 (:523-524)
         _lib.check(lib.ox_axpby(n, 1.0, self._WRK.ptr(), -1.0, self._U.ptr(), self._WRK.ptr(), st), "ox_axpby")
@@ -386,6 +393,8 @@ class FractionalStep_AB_CN:
         lib, st = self._lib, _lib.current_stream()
         Vi, Q = self._Vi[0][0], self._Q
         gdim = self._gdim
+        self._AU1_valid = False  # b3 overwrites the block that held A u1 (assemble_first)
+        self._u_is_u1 = None
         # M u* is kept (in the work block of the tentative solve, free here): with a nonzero initial
         # guess it is the solver's first mat-vec A x0, which is then skipped
         MU = self._WRK
@@ -424,6 +433,7 @@ class FractionalStep_AB_CN:
         _lib.check(lib.ox_axpby(n, 1.0, self._U1.ptr(), 0.0, None, self._U2.ptr(), st), "ox_axpby")
         _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._U1.ptr(), st), "ox_axpby")
         _lib.check(lib.ox_axpby(nq, 1.0, self._PS.ptr(), 0.0, None, self._P.ptr(), st), "ox_axpby")
+        self._u_is_u1 = (self._U.generation, self._U1.generation)  # u1 is a bit copy of u from here on
         for d_ in (self._du, self._dq):  # partitioned runs: a peer wait that timed out anywhere in the step fails it
             if d_ is not None:
                 _lib.check(lib.ox_dist_status(d_), "ox_dist_status (halo exchange / all-reduce of this step)")

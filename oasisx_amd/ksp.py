@@ -78,6 +78,7 @@ class KSPSolver:
         tx.dev()[:, 0].copy_(xs.dev()[:, xc])
         reason = self.solve_block(tb, tx)[0]
         xs.dev()[:, xc].copy_(tx.dev()[:, 0])
+        xs.mark_written()
         return int(reason)
 
     # -- block interface used by FractionalStep_AB_CN -------------------------------------

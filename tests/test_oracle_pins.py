@@ -262,8 +262,11 @@ def test_c_port_matches_numpy_oracle():
         assert np.abs(cpu.u1.T - S.u1).max() < 1e-9 and np.abs(cpu.p - S.p).max() < 1e-8
         # OpenMP reductions sum in a run-dependent order: a residual that lands within round-off of
         # the threshold can cost one iteration more or less
+        # (the w = 0 component of the z-extruded 3-D field solves for a round-off right-hand side: its
+        # count wanders by a few iterations with the summation order -- observed 22 vs 24 -- so it gets +-4)
         for k in ("tentative", "update"):
-            assert all(abs(int(a) - int(b)) <= 1 for a, b in zip(cpu.its[k], S.its[k])), (k, cpu.its[k], S.its[k])
+            assert all(abs(int(a) - int(b)) <= (1 if c < 2 else 4)
+                       for c, (a, b) in enumerate(zip(cpu.its[k], S.its[k]))), (k, cpu.its[k], S.its[k])
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))

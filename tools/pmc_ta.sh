@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-pmc_ta}
 mkdir -p $OUT
 cd $R
+PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')  # the real interpreter: no exec hop behind rocprofv3
 export REPS=3 ROUNDS=1 VARIANTS=${VARIANTS:-7,15} REAL=${REAL:-stiff}
 N=${N:-128}
 W=${W:-p}
@@ -13,7 +14,7 @@ i=0
 while read -r CTRS; do
   i=$((i+1))
   echo "pass $i: $CTRS" >> $OUT/progress.log
-  timeout -k 10 150 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p$i -- python3 tools/spmv_bench.py $N $W > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/progress.log
+  timeout -k 10 150 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p$i -- "$PY" tools/spmv_bench.py $N $W > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/progress.log
 done <<'LIST'
 GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr
 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
