@@ -322,6 +322,70 @@ def main():
                    **({"sell_window": args.window} if args.window else {}))
     mesh, S = build(N, args.udeg, options, args.zero_guess)
 
+    def workload_leg(wname, steps=5, warmup=3):
+        """Another workload with the main run's mesh size, options and Krylov settings: its own solver, set up,
+        warmed up and timed here (barrier + synchronize on both sides), then released."""
+        W2 = make_workload(wname, N, np, torch)
+        q0, q1 = W2["box"]
+        clk = {"t": 0.0}
+
+        def on_bnd(x):
+            on = np.zeros(x.shape[1], dtype=bool)
+            for k in range(3):
+                on |= np.isclose(x[k], q0[k]) | np.isclose(x[k], q1[k])
+            return on
+
+        def bcv(f):
+            def g(x):
+                return f(x, clk["t"])
+            g.supports_torch = True
+            return g
+
+        t0 = time.perf_counter()
+        m2 = M.create_box(comm, [q0, q1], [N, N, N])
+        ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
+               "ksp_initial_guess_nonzero": not args.zero_guess}
+        tent = dict(ksp, ksp_type="bcgs")
+        if wname == "cavity":
+            tent["ksp_bcgs_restarts"] = 5  # a start from rest: see build()
+        S2 = ox.FractionalStep_AB_CN(
+            m2, ("Lagrange", args.udeg), ("Lagrange", 1),
+            bcs_u=[[ox.DirichletBC(bcv(f), ox.LocatorMethod.GEOMETRICAL, on_bnd)] for f in W2["fns"]], bcs_p=[],
+            solver_options={"tentative": tent, "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")},
+            options=options)
+        if W2["analytic"]:
+            for i, f in enumerate(W2["fns"]):
+                S2._u2[i].interpolate(at(f, -W2["dt"]))
+                S2._u1[i].interpolate(at(f, 0.0))
+            S2._p.interpolate(lambda x: W2["p"](x, -W2["dt"] / 2.0))
+        torch.cuda.synchronize()
+        t_set = time.perf_counter() - t0
+        its2 = []
+
+        def one():
+            clk["t"] += W2["dt"]
+            S2.solve(W2["dt"], W2["nu"], max_iter=1)
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+            its2.append(S2.iteration_counts())
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+               "workload": f"{W2['desc']}, {N}^3x6 tets P{args.udeg}-P1, nu={W2['nu']}, dt={W2['dt']:g}",
+               "krylov_iterations_per_step": mean_iterations(its2), "setup_s": t_set}
+        if W2["analytic"]:
+            Xd2 = S2._Vi[0][0].x[: S2._n_u].T
+            res["max_nodal_error_u_vs_analytic"] = max(
+                float((S2._U.dev()[: S2._n_u][:, i] - f(Xd2, clk["t"])).abs().max()) for i, f in enumerate(W2["fns"]))
+        del S2, m2
+        torch.cuda.empty_cache()
+        return res
+
     def at(f, t):  # the analytic fields are array-API callables: evaluated on the device
         def g(x):
             return f(x, t)
@@ -632,6 +696,15 @@ def main():
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
             "cpu_baseline": None,  # timed on rank 0 at N = 1 only (below)
         }
+        if variants:  # PETSc's own defaults in one place: zero initial guess, no value dictionaries
+            zg = variants.get("initial_guess_nonzero=False")
+            out["headline_petsc_default"] = {
+                "what": "the same workload as PETSc's defaults leave it: zero initial guess for every Krylov solve "
+                        "(the headline uses -ksp_initial_guess_nonzero), and -- what any mesh without bit-identical "
+                        "cells gets -- f64 value streams instead of the 1-byte value dictionaries",
+                "zero_initial_guess_steps_per_s": zg["value"] if zg else None,
+                "no_value_dictionary_steps_per_s": (variants.get("value_dictionary=False") or {}).get("value"),
+                "headline_steps_per_s": out["value"]}
         if not args.no_cpu and world == 1:
             try:
                 from oracle.cpu_baseline import run_cpu_baseline
@@ -646,6 +719,19 @@ def main():
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
+        # ---- the other BASELINE workloads on the same mesh size, driver-timed beside the headline --------------
+        # (Beltrami: w != 0, no round-off right-hand side; cavity: BASELINE.json configs[3]'s 1-GPU line)
+        if world == 1 and not args.no_extras and args.workload == "tg" and args.mesh == "box":
+            import gc
+
+            del S  # (the phase wrappers hold it in a cycle: collect before the next 49 GiB solver is built)
+            gc.collect()
+            torch.cuda.empty_cache()
+            for wname in ("beltrami", "cavity"):
+                try:
+                    out["variants"]["workload=" + wname] = workload_leg(wname)
+                except Exception as e:
+                    out["variants"]["workload=" + wname] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

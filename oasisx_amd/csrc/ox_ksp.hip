@@ -547,24 +547,25 @@ extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, i
 
 static KspState *g_state_host = nullptr;
 static int g_ksp_fold = -1;
-extern "C" int ox_set_ksp_fold(int on) {  // tuning / test hook: 0 = separate scalar kernels everywhere
-  g_ksp_fold = on ? 1 : 0;
+extern "C" int ox_set_ksp_fold(int on) {  // tuning / test hook: 0 = separate scalar kernels everywhere,
+  g_ksp_fold = on < 0 ? 0 : (on > 2 ? 2 : on);    // 1 = the vector kernels end their points, 2 = the SpMVs too
   return 0;
 }
 
 
 template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
-                          const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
+                          const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0},
+                          bool mirror = false /* add in the order of the folded path (its A/B twin) */) {
   {
     double *scr = sums + OX_PRERED_OFFSET;
-    if (const int g = ksp_prered_rows(nparts, nv, !dist)) {
+    if (const int g = ksp_prered_rows(nparts, nv, mirror)) {
       hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, ksp_prered_rpb(nparts), scr);
       partial = scr;
       nparts = g;
       scr += (size_t)g * nv;
     }
-    if (const int g = B.nv > 0 ? ksp_prered_rows(B.nparts, B.nv, !dist) : 0) {
+    if (const int g = B.nv > 0 ? ksp_prered_rows(B.nparts, B.nv, false) : 0) {
       hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, ksp_prered_rpb(B.nparts), scr);
       B.partial = scr;
       B.nparts = g;
@@ -623,18 +624,25 @@ struct KspCtx {
   hipStream_t st;
   int nb, nbs;
   bool fold;       // the producer kernels end their synchronisation points themselves (single GPU)
+  bool fold_spmv;  // ... the SpMVs too (OX_KSP_FOLD=2: measurement only)
   ox_u64 *fold_gran, *fold_ggran;
   KspFoldArgs *fold_tab;  // device [2][PH_COUNT]: [0] the lock-step columns, [1] the narrowed continuation
   unsigned *epoch;        // folded launches of this solve so far
 };
 
-// can the producer of a synchronisation point with `nparts` partial rows end it itself?
-static inline bool ksp_folds(const KspCtx &C, int nparts) { return C.fold && nparts <= OX_FOLD_MAX_ROWS; }
+// Can the producer of a synchronisation point with `nparts` partial rows end it itself?  Only the VECTOR
+// kernels do (k_cg_init, k_cg_update1, k_bcgs_init, k_bcgs_x: <= 2048 blocks, all resident at once).  The SpMVs
+// keep the separate scalar kernel: their reducer blocks' tail (two hand-off hops, 5.3 us at the 8 392 blocks of
+// the pressure matrix) buys 2.8 us per CG iteration and charges the metric's kernel with a reduction that is
+// not SpMV work (39.6 instead of 34.3 us by HIP events) -- measured, not kept (fold_spmv = false).
+static inline bool ksp_folds(const KspCtx &C, int nparts, bool spmv = false) {
+  return C.fold && nparts <= OX_FOLD_MAX_ROWS && (!spmv || C.fold_spmv);
+}
 
 // what that producer needs (args == nullptr: it only stores its partial sums and ksp_sync_point runs)
-static inline KspFold ksp_fold(const KspCtx &C, const KspParams &P, int phase, int nparts) {
+static inline KspFold ksp_fold(const KspCtx &C, const KspParams &P, int phase, int nparts, bool spmv = false) {
   KspFold F{};
-  if (ksp_folds(C, nparts)) {
+  if (ksp_folds(C, nparts, spmv)) {
     F.args = C.fold_tab + (P.nc == P.nc_total ? 0 : PH_COUNT) + phase;
     F.gran = C.fold_gran;
     F.ggran = C.fold_ggran;
@@ -653,9 +661,13 @@ static int ksp_fold_upload(const KspCtx &C, const KspParams &P) {
   return 0;
 }
 // the synchronisation point of phase PH: nothing to launch when the producer was folded
-#define KSP_SYNC(PH, partial, nparts, nv)                                                                    \
+// (an unfolded vector-kernel point adds in the folded path's order on one GPU: the two are bit-identical twins)
+#define KSP_SYNC(PH, partial, nparts, nv, spmv)                                                              \
   do {                                                                                                       \
-    if (!ksp_folds(C, nparts) && ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st)) return -1; \
+    if (!ksp_folds(C, nparts, spmv) &&                                                                       \
+        ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st, KspPart2{nullptr, 0, 0},      \
+                           !C.dist && !(spmv)))                                                              \
+      return -1;                                                                                             \
   } while (0)
 // grid of a producer kernel with nwb work blocks
 #define KSP_GRID(nwb) dim3((nwb) + (ksp_folds(C, (nwb)) ? OX_FOLD_R : 0))
@@ -665,14 +677,14 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    const KspFold fa = ksp_fold(C, P, PH_CG_A, C.nbs);
+    const KspFold fa = ksp_fold(C, P, PH_CG_A, C.nbs, true);
     if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st, fa.args ? &fa : nullptr))
       return -1;
-    KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
+    KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC, true);
     hipLaunchKernelGGL((k_cg_update1<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial,
                        ksp_fold(C, P, PH_CG_B, C.nb));
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
+    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC, false);
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.dinv, V.p, 0);
     OX_LAUNCH_CHECK();
   }
@@ -704,20 +716,20 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
-    const KspFold f1 = ksp_fold(C, P, PH_BCGS_1, C.nbs);
+    const KspFold f1 = ksp_fold(C, P, PH_BCGS_1, C.nbs, true);
     if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st, f1.args ? &f1 : nullptr))
       return -1;
-    KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC);
+    KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC, true);
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
-    const KspFold f2 = ksp_fold(C, P, PH_BCGS_2, C.nbs);
+    const KspFold f2 = ksp_fold(C, P, PH_BCGS_2, C.nbs, true);
     if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st, f2.args ? &f2 : nullptr))
       return -1;
-    KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC);
+    KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC, true);
     hipLaunchKernelGGL((k_bcgs_x<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
                        V.t, C.partial, ksp_fold(C, P, PH_BCGS_3, C.nb));
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC);
+    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC, false);
   }
   return 0;
 }
@@ -792,6 +804,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   // merges two partial arrays: both keep the separate kernel.  OX_KSP_FOLD=0 restores it everywhere (A/B).
   if (g_ksp_fold < 0) g_ksp_fold = getenv("OX_KSP_FOLD") ? atoi(getenv("OX_KSP_FOLD")) : 1;
   C.fold = g_ksp_fold && !dist && ksp_type != OX_KSP_CG_SINGLE;
+  C.fold_spmv = g_ksp_fold == 2;
   C.fold_gran = reinterpret_cast<ox_u64 *>(work + L.fold_gran);
   C.fold_ggran = reinterpret_cast<ox_u64 *>(work + L.fold_ggran);
   C.fold_tab = reinterpret_cast<KspFoldArgs *>(work + L.fold_tab);
@@ -826,7 +839,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     hipLaunchKernelGGL((k_cg_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
                        V.p, guess, C.partial, ksp_fold(C, P, PH_CG_INIT, C.nb));
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_CG_INIT, C.partial, C.nb, 3 * NC);
+    KSP_SYNC(PH_CG_INIT, C.partial, C.nb, 3 * NC, false);
   } else {
     V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
     if (guess && !ax0) {
@@ -835,7 +848,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     hipLaunchKernelGGL((k_bcgs_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
                        V.rhat, V.p, V.v, guess, C.partial, ksp_fold(C, P, PH_BCGS_INIT, C.nb));
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC);
+    KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC, false);
   }
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;

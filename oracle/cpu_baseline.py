@@ -19,7 +19,36 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def load():
+PORTABLE_FLAGS = ["-O3", "-fopenmp", "-fPIC", "-shared", "-Wall"]
+BUILD = {"flags": " ".join(PORTABLE_FLAGS), "native": False}
+
+
+def _build_native():
+    """``-march=native`` build of ipcs_cpu.c for THIS host, outside the tree (the in-tree .so travels between
+    machines and must stay portable).  Returns the path or None (no compiler, or the flags are refused)."""
+    import hashlib
+    import subprocess
+    import tempfile
+
+    src = os.path.join(_HERE, "ipcs_cpu.c")
+    try:
+        tag = hashlib.sha1(open(src, "rb").read() + cpu_model().encode()).hexdigest()[:12]
+        out = os.path.join(tempfile.gettempdir(), f"libipcs_cpu_native_{tag}_{os.getuid()}.so")
+        if not os.path.exists(out):
+            tmp = out + f".{os.getpid()}"
+            r = subprocess.run(["gcc", *PORTABLE_FLAGS, "-march=native", "-o", tmp, src, "-lm"],
+                               capture_output=True, text=True, timeout=120)
+            if r.returncode != 0:
+                return None
+            os.replace(tmp, out)
+        return out
+    except Exception:
+        return None
+
+
+def load(native: bool = False):
+    """The C port.  ``native=True`` (bench.py's cpu_baseline leg): a -march=native build made on this host, the
+    portable in-tree build if that fails.  The first call decides for the process."""
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libipcs_cpu.so")
@@ -29,7 +58,16 @@ def load():
             subprocess.run(["make", "-s", "-C", _HERE], check=False)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not built: run `make -C oracle`")
-        _LIB = C.CDLL(path)
+        lib = None
+        if native:
+            npath = _build_native()
+            if npath is not None:
+                try:
+                    lib = C.CDLL(npath)
+                    BUILD.update(flags=" ".join(PORTABLE_FLAGS + ["-march=native"]), native=True)
+                except OSError:
+                    lib = None
+        _LIB = lib if lib is not None else C.CDLL(path)
         _LIB.cpu_num_threads.restype = C.c_int
         for name in ("cpu_cg", "cpu_bicgstab"):
             getattr(_LIB, name).restype = C.c_int
@@ -319,6 +357,7 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     Vi, Q = S._Vi[0][0], S._Q
     mesh = S._mesh
     d = mesh.gdim
+    load(native=True)  # built for this host's cores (falls back to the portable in-tree build)
     t0 = time.perf_counter()
     if isinstance(mesh_def, dict):  # an unstructured mesh is DEFINED by its vertex and cell arrays
         coords = np.ascontiguousarray(mesh_def["coords"], dtype=np.float64)
@@ -352,7 +391,7 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
            "sample": f"1 time step of the same workload (same mesh definition, state, Krylov settings) on the host: "
                      f"oracle/ipcs_cpu.c, OpenMP x{cpu.threads}, CSR, per-component solves as the reference; own "
                      f"dof numbering, patterns and M/K/Ap assembly",
-           "seconds": t_step, "setup_seconds": t_setup, "krylov_iterations": cpu.its}
+           "seconds": t_step, "setup_seconds": t_setup, "krylov_iterations": cpu.its, "build_flags": BUILD["flags"]}
     if gpu_step is not None:
         clock["t"] -= dt
         gpu_step()
@@ -371,7 +410,54 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
         t1 = time.perf_counter() - t0
         lib.cpu_set_threads(C.c_int(cpu.threads))
         out["one_core"] = {"value": 1.0 / t1, "seconds": t1}
+    try:
+        out["scipy_single_thread"] = scipy_cross_check(cpu)
+    except Exception as e:  # the cross-check never takes the baseline down
+        out["scipy_single_thread"] = {"error": repr(e)}
     return out
+
+
+def scipy_cross_check(cpu, reps: int = 20, cg_its: int = 40):
+    """BASELINE.md section 3's library-quality single-thread figure beside the port's: scipy.sparse CSR mat-vec
+    and ``scipy.sparse.linalg.cg`` (Jacobi as ``M``) on the pressure-Poisson matrix the port assembled, with the
+    right-hand side of the step just taken; the port's own mat-vec on one core next to it.  CSR bytes as
+    SURVEY.md 8d prices them (12 B per nonzero + row pointers + vectors)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    nq = cpu.nq
+    Ap = sp.csr_matrix((cpu.pv, cpu.pci, cpu.prp.astype(np.int32) if cpu.prp[-1] < 2**31 else cpu.prp), shape=(nq, nq))
+    x = np.sin(np.arange(nq) * 1e-3) + 1.0  # SURVEY.md 8d's SpMV vector
+    y = Ap @ x
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        y = Ap @ x
+    t_spmv = (time.perf_counter() - t0) / reps
+    nbytes = 12 * Ap.nnz + 4 * (nq + 1) + 16 * nq
+    lib = load()
+    lib.cpu_set_threads(C.c_int(1))
+    y2 = np.zeros(nq)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.cpu_spmv(C.c_int64(nq), _p(cpu.prp), _p(cpu.pci), _p(cpu.pv), _p(x), _p(y2))
+    t_port = (time.perf_counter() - t0) / reps
+    lib.cpu_set_threads(C.c_int(cpu.threads))
+    agree = float(np.abs(y - y2).max() / max(np.abs(y).max(), 1e-300))
+    b = cpu.b2 - cpu.b2.mean()
+    dinv = cpu.dinvP
+    its = [0]
+
+    def count(_):
+        its[0] += 1
+
+    t0 = time.perf_counter()
+    spla.cg(Ap, b, x0=np.zeros(nq), rtol=1e-30, atol=0.0, maxiter=cg_its, M=sp.diags(dinv), callback=count)
+    t_cg = time.perf_counter() - t0
+    return {"matrix": f"pressure Poisson, {nq} rows, {Ap.nnz} nonzeros (the port's own assembly)",
+            "scipy_spmv_us": 1e6 * t_spmv, "scipy_spmv_csr_gbs": nbytes / t_spmv / 1e9,
+            "port_spmv_one_core_us": 1e6 * t_port, "port_spmv_one_core_csr_gbs": nbytes / t_port / 1e9,
+            "spmv_max_rel_diff": agree,
+            "scipy_cg_iteration_us": 1e6 * t_cg / max(its[0], 1), "scipy_cg_iterations_timed": its[0]}
 
 
 def cpu_model():

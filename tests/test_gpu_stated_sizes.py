@@ -116,12 +116,15 @@ def test_c2_taylor_green_64cubed_p1p1_against_the_c_port_on_its_own_mesh(hip):
 
 
 def test_c5_pattern_beyond_2_to_31_storage_slots(hip):
+    """BASELINE.json configs[4] at its stated size on one GPU: 256^3 P2-P1, matrix-free (low_memory_version),
+    135 005 697 dofs per velocity component, 3 867 809 793 / 253 036 801 nonzeros (SURVEY.md 8's table), int64
+    entry offsets; exactness identities of M and K and one time step against the analytic field.  ~184 GiB."""
     from oracle import ipcs_oracle as O
     from tests.helpers import make_hip_problem
 
     gc.collect()
     torch.cuda.empty_cache()
-    N, nu = 212, 0.01
+    N, nu = 256, 0.01
     dt = 0.005 * 32 / N
     opts = {k: {"ksp_type": t, "pc_type": "jacobi", "ksp_rtol": 1e-8, "ksp_atol": 1e-14,
                 "ksp_initial_guess_nonzero": True}
@@ -133,8 +136,8 @@ def test_c5_pattern_beyond_2_to_31_storage_slots(hip):
         assert int(P.slice_ptr[-1].item()) == P.size
         assert mesh.num_cells == 6 * N ** 3
         assert S._n_u == (2 * N + 1) ** 3 and S._n_q == (N + 1) ** 3
-        assert P.nnz == 230 * N ** 3 + 138 * N ** 2 + 24 * N + 1
-        assert S._Ap.pattern.nnz == 15 * N ** 3 + 21 * N ** 2 + 9 * N + 1
+        assert P.nnz == 230 * N ** 3 + 138 * N ** 2 + 24 * N + 1 == 3867809793
+        assert S._Ap.pattern.nnz == 15 * N ** 3 + 21 * N ** 2 + 9 * N + 1 == 253036801
         n = S._n_u
         one = torch.ones(n, 1, dtype=torch.float64, device="cuda")
         y = torch.zeros_like(one)
