@@ -681,7 +681,14 @@ def main():
                                      "/".join(sorted(set(comm.active.values()))) or "none")
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
                        if world > 1 else None,
-                       "transport_check": transport_check, "transport_exchange_us": transport_us},
+                       "transport_check": transport_check, "transport_exchange_us": transport_us,
+                       # all-reduces per Krylov iteration on a partitioned operator: single-reduction CG
+                       # (Chronopoulos-Gear) and merged-reduction BiCGStab are the defaults there (oasisx_amd/ksp.py)
+                       "krylov_sync_points_per_iteration": (
+                           None if world == 1 else
+                           {"pressure cg": 1 if S._solver_p._method()[0] == _lib.KSP_CG_SINGLE else 2,
+                            "velocity bcgs": 2 if S._solver_u._method()[0] == _lib.KSP_BCGS_MERGED else 3,
+                            "update cg": 1 if S._solver_c._method()[0] == _lib.KSP_CG_SINGLE else 2})},
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,

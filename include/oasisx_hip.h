@@ -60,6 +60,11 @@ extern "C" {
 #define OX_KSP_BCGS 2    /* PETSc "bcgs" */
 #define OX_KSP_CG_SINGLE 3 /* PETSc "cg" with -ksp_cg_single_reduction: Chronopoulos-Gear recurrences, ONE
                               merged reduction (one all-reduce in partitioned runs) per iteration */
+#define OX_KSP_BCGS_MERGED 4 /* "bcgs" with merged reductions: TWO synchronisation points (all-reduces) per
+                              iteration instead of three -- rhat.v behind the first mat-vec; t.t, t.s, rhat.s,
+                              rhat.t, s.s behind the second give omega, rho and |r| together (|r| by the
+                              recurrence |s - omega t|^2, as PETSc's pipelined / improved BiCGStab variants do).
+                              Same Krylov space and convergence test; iteration counts within +-2 of OX_KSP_BCGS */
 
 /* SELL-64 matrix: pattern + one value array (PETSc Mat on this path). */
 typedef struct {

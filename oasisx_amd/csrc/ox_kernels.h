@@ -7,12 +7,17 @@
 #define OX_EPI_DOT 1     // + partial[c] = sum x_row * y_row            (CG: p.q)
 #define OX_EPI_BCGS_V 2  // y = D^-1 A x, partial[c] = sum aux_row*y_row (BiCGStab: rhat.v)
 #define OX_EPI_BCGS_T 3  // y = D^-1 A x, partial = {y.y, y.x_row}       (BiCGStab: t.t, t.s)
+#define OX_EPI_BCGS_T5 4 // y = D^-1 A x, partial = {y.y, y.x, aux.x, aux.y, x.x}  (merged-reduction BiCGStab:
+                         //   t.t, t.s, rhat.s, rhat.t, s.s -- omega, rho and |r| from ONE reduction)
+__host__ __device__ constexpr int ox_epi_nv(int epi, int nc) {
+  return epi == OX_EPI_NONE ? 0 : (epi == OX_EPI_BCGS_T ? 2 * nc : (epi == OX_EPI_BCGS_T5 ? 5 * nc : nc));
+}
 
 #define OX_VEC_MAX_BLOCKS 2048  // grid cap of the BLAS-1 kernels (256 CUs x 8 blocks)
 
 #define OX_SPMV_MAX_BLOCKS (1 << 22)  // one slice group per block (a cap of 2048 = persistent grid
                                       // measured 10 % slower: r01 notes in DESIGN.md)
-#define OX_MAX_NV 12            // most sums reduced at one synchronisation point (4 * OX_MAXC: single-reduction CG init)
+#define OX_MAX_NV 15            // most sums reduced at one synchronisation point (5 * OX_MAXC: merged-reduction BiCGStab)
 
 static inline int ox_spmv_blocks_n(int n_slices) {
   const int ngroups = (n_slices + 3) / 4;

@@ -446,9 +446,10 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
                                                 const double *__restrict__ vrhat,
                                                 const double *__restrict__ vp,
                                                 const double *__restrict__ vs,
-                                                const double *__restrict__ vt, double *partial, KspFold fold) {
+                                                const double *__restrict__ vt, double *partial, KspFold fold,
+                                                int finish /* merged variant: the x update the `done` flag skipped */) {
   __shared__ KspFoldLds fl;
-  if (S->done) return;
+  if (!finish && S->done) return;
   double alpha[NC], omega[NC], s[2 * NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -519,17 +520,17 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   const int nblk_spmv = (n_slices + 3) / 4;
   const int nb8 = (nblk_spmv + 7) & ~7;
   L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
-  L.nvec = ksp_type == OX_KSP_CG ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);
+  L.nvec = ksp_type == OX_KSP_CG ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);  // (both BiCGStab variants: 6)
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
   const size_t prered_max = (size_t)((L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK > OX_FOLD_R
                                          ? (L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK : OX_FOLD_R);
   L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (prered_max + 1) * OX_MAX_NV));
-  L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
+  L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 5 * OX_MAXC);
   // folded synchronisation points (ox_ksp_dev.h): tagged granules of the work blocks' sums, of the group sums,
   // and the per-phase argument table
-  L.fold_gran = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * OX_MAXC);
+  L.fold_gran = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * 2 * OX_MAXC);
   L.fold_ggran = L.fold_gran + ox_align(16 * (size_t)OX_FOLD_MAX_ROWS * 3 * OX_MAXC);
   L.fold_tab = L.fold_ggran + ox_align(16 * (size_t)OX_FOLD_R * OX_MAX_NV);
   L.fold_end = L.fold_tab + ox_align(sizeof(KspFoldArgs) * 2 * PH_COUNT);
@@ -727,10 +728,42 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
       return -1;
     KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC, true);
     hipLaunchKernelGGL((k_bcgs_x<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                       V.t, C.partial, ksp_fold(C, P, PH_BCGS_3, C.nb));
+                       V.t, C.partial, ksp_fold(C, P, PH_BCGS_3, C.nb), 0);
     OX_LAUNCH_CHECK();
     KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC, false);
   }
+  return 0;
+}
+
+// Merged-reduction BiCGStab (OX_KSP_BCGS_MERGED): TWO synchronisation points per iteration instead of three --
+// rhat.v behind the first mat-vec; {t.t, t.s, rhat.s, rhat.t, s.s} behind the second give omega, rho' and |r|
+// together (PH_BCGSM_B) -- i.e. two all-reduces per iteration on a partitioned operator.
+// The x / r update runs after the second point with that iteration's alpha and omega; the update the `done`
+// flag skips at the end of the solve is applied by bcgsm_finish.
+template <int NC>
+static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+  const int64_t n = C.A->n_rows;
+  const int *done = &C.S->done;
+  for (int k = 0; k < count; ++k) {
+    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
+    OX_LAUNCH_CHECK();
+    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st, nullptr)) return -1;
+    if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
+    OX_LAUNCH_CHECK();
+    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T5, C.dinv, V.rhat, C.partial, done, C.dist, C.st, nullptr)) return -1;
+    if (ksp_sync_point<PH_BCGSM_B>(C.S, C.partial, C.nbs, 5 * NC, C.sums, P, C.dist, C.st)) return -1;
+    hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
+                       V.t, C.partial2, KspFold{}, 0);
+    OX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+template <int NC>
+static int bcgsm_finish(const KspCtx &C, const KspVecs &V, const KspParams &P) {
+  hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, C.A->n_rows, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
+                     V.t, C.partial2, KspFold{}, 1);
+  OX_LAUNCH_CHECK();
   return 0;
 }
 
@@ -803,7 +836,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   // partitioned operator needs the all-reduce between the sums and the logic, and the single-reduction CG
   // merges two partial arrays: both keep the separate kernel.  OX_KSP_FOLD=0 restores it everywhere (A/B).
   if (g_ksp_fold < 0) g_ksp_fold = getenv("OX_KSP_FOLD") ? atoi(getenv("OX_KSP_FOLD")) : 1;
-  C.fold = g_ksp_fold && !dist && ksp_type != OX_KSP_CG_SINGLE;
+  C.fold = g_ksp_fold && !dist && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED;
   C.fold_spmv = g_ksp_fold == 2;
   C.fold_gran = reinterpret_cast<ox_u64 *>(work + L.fold_gran);
   C.fold_ggran = reinterpret_cast<ox_u64 *>(work + L.fold_ggran);
@@ -817,7 +850,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
-  const bool cg = ksp_type == OX_KSP_CG, cgs = ksp_type == OX_KSP_CG_SINGLE;
+  const bool cg = ksp_type == OX_KSP_CG, cgs = ksp_type == OX_KSP_CG_SINGLE, bm = ksp_type == OX_KSP_BCGS_MERGED;
   KspVecs V{};
   V.x = x;
   if (cgs) {
@@ -853,7 +886,8 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;
     return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
-               : (cg ? cg_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every));
+               : (cg ? cg_iterations<N_>(C, W, Q, check_every)
+                     : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every)));
   };
   bool cg_finished = false;
   static int run_ahead = -1;
@@ -866,7 +900,8 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     const int bsz = batch_of(check_every);
     auto it1 = [&](int count) -> int {
       return cgs ? cgs_iterations<1>(C, V, P, count)
-                 : (cg ? cg_iterations<1>(C, V, P, count) : bcgs_iterations<1>(C, V, P, count));
+                 : (cg ? cg_iterations<1>(C, V, P, count)
+                       : (bm ? bcgsm_iterations<1>(C, V, P, count) : bcgs_iterations<1>(C, V, P, count)));
     };
     if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
   }
@@ -913,7 +948,8 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           const int bsz = batch_of(check_every);
           auto it1 = [&](int count) -> int {
             return cgs ? cgs_iterations<1>(C, W, P1, count)
-                       : (cg ? cg_iterations<1>(C, W, P1, count) : bcgs_iterations<1>(C, W, P1, count));
+                       : (cg ? cg_iterations<1>(C, W, P1, count)
+                             : (bm ? bcgsm_iterations<1>(C, W, P1, count) : bcgs_iterations<1>(C, W, P1, count)));
           };
           it += check_every;
           if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
@@ -928,6 +964,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, dinv, W.p, 1);
           OX_LAUNCH_CHECK();
         }
+        if (bm && g_state_host->its[live] > 0 && bcgsm_finish<1>(C, W, P1)) return -1;
         cg_finished = true;
         hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.x, NC, live, x);
         OX_LAUNCH_CHECK();
@@ -936,6 +973,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     }
   }
   if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
+  if (bm && !cg_finished) {  // the x update of the last iteration (skipped by `done`); nothing ran if all converged at once
+    bool any = false;
+    for (int c = 0; c < NC; ++c) any = any || g_state_host->its[c] > 0;
+    if (any && bcgsm_finish<NC>(C, V, P)) return -1;
+  }
   if (cg && !cg_finished) {  // the last x += alpha p (see k_cg_update2)
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, dinv, V.p, 1);
     OX_LAUNCH_CHECK();
@@ -958,7 +1000,7 @@ extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *di
                                 size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
                                 const double *ax0) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
-  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE)
+  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED)
     OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
   if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))

@@ -24,7 +24,7 @@ struct KspParams {
   int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
 };
 
-enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT, PH_COUNT };
+enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT, PH_BCGSM_B, PH_COUNT };
 
 __device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P) {
   if (!(rn == rn) || isinf(rn)) return OX_DIVERGED_NANORINF;
@@ -123,13 +123,14 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
     S->rn[c] = sqrt(s[c]);
     S->bn[c] = sqrt(s[NC + c]);
     S->its[c] = 0;
-    S->alpha[c] = 1.0;
-    S->omega[c] = 1.0;
     S->restart[c] = 0;
     S->nrestart[c] = 0;
     const int r = ksp_test(S->rn[c], S->bn[c], P);
     S->reason[c] = r;
     S->active[c] = (r == 0);
+    // (p = v = 0 in the first k_bcgs_p: any omega serves; 0 for a column that is finished already, so that the
+    // merged variant's deferred x update adds nothing to it)
+    S->alpha[c] = S->omega[c] = (r == 0) ? 1.0 : 0.0;
     // first iteration: rho_new = rhat.r = r.r, beta = (rho_new/1)*(1/1); p = v = 0
     S->rho[c] = s[c];
     S->beta[c] = S->active[c] ? s[c] : 0.0;
@@ -145,11 +146,13 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
         S->reason[c] = (rv == rv) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
         S->active[c] = 0;
         S->alpha[c] = 0.0;
+        S->omega[c] = 0.0;  // (merged variant: its deferred x update must add nothing for this column)
       } else {
         S->alpha[c] = S->rho[c] / rv;
       }
     } else {
       S->alpha[c] = 0.0;
+      S->omega[c] = 0.0;
     }
   } else if (PH == PH_BCGS_2) {  // s = {t.t, t.s}
     if (S->active[c]) {
@@ -158,6 +161,42 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
     } else {
       S->omega[c] = 0.0;
     }
+  } else if (PH == PH_BCGSM_B) {
+    // Merged-reduction BiCGStab, the ONE reduction behind t = D^-1 A s:  s = {t.t, t.s, rhat.s, rhat.t, s.s}
+    //   omega = t.s / t.t;   r = s - omega t  =>  |r|^2 = s.s - 2 omega t.s + omega^2 t.t,   rho' = rhat.s - omega rhat.t
+    // (what PH_BCGS_2 and PH_BCGS_3 take from two reductions; the residual norm by recurrence, as in every
+    // merged / pipelined BiCGStab).  The x update with this iteration's alpha and omega runs AFTER this point.
+    if (S->active[c]) {
+      const double tt = s[c], ts = s[NC + c], hs = s[2 * NC + c], ht = s[3 * NC + c], ss = s[4 * NC + c];
+      const double om = (tt != 0.0) ? ts / tt : 0.0;
+      S->omega[c] = om;
+      S->its[c] += 1;
+      double rr = fma(om, fma(om, tt, -2.0 * ts), ss);
+      if (rr < 0.0) rr = 0.0;  // round-off of the recurrence near convergence
+      S->rn[c] = sqrt(rr);
+      const double rho_new = fma(-om, ht, hs);
+      int r = ksp_test(S->rn[c], S->bn[c], P);
+      bool reseed = false;
+      if (r == 0 && (om == 0.0 || rho_new == 0.0)) {
+        if (S->nrestart[c] < P.max_restarts && rr > 0.0) reseed = true;
+        else r = OX_DIVERGED_BREAKDOWN;
+      }
+      if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
+      if (r) {
+        S->reason[c] = r;
+        S->active[c] = 0;
+        S->beta[c] = 0.0;
+      } else if (reseed) {
+        S->restart[c] = 1;
+        S->nrestart[c] += 1;
+        S->rho[c] = rr;  // rhat.r with rhat = r
+        S->beta[c] = 0.0;
+      } else {
+        S->beta[c] = (rho_new / S->rho[c]) * (S->alpha[c] / om);
+        S->rho[c] = rho_new;
+      }
+    }
+    // (an inactive column keeps alpha = omega = 0 from the first point of the iteration: x is left alone)
   } else if (PH == PH_BCGS_3) {  // s = {r.r, rhat.r}
     if (S->active[c]) {
       S->its[c] += 1;
@@ -267,6 +306,7 @@ __device__ __forceinline__ void ksp_logic_rt(int ph, KspState *S, const double *
     case PH_BCGS_1: ksp_logic<PH_BCGS_1>(S, s, cl, P); break;
     case PH_BCGS_2: ksp_logic<PH_BCGS_2>(S, s, cl, P); break;
     case PH_BCGS_3: ksp_logic<PH_BCGS_3>(S, s, cl, P); break;
+    case PH_BCGSM_B: ksp_logic<PH_BCGSM_B>(S, s, cl, P); break;
     default: break;
   }
 }

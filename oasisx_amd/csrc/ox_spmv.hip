@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
                                               double *__restrict__ partial,
                                               const int *__restrict__ done_flag,
                                               const int32_t *__restrict__ slice_list, int n_list, KspFold fold) {
-  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
+  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   __shared__ KspFoldLds fl;  // block sum of the fused epilogue + tail of a folded synchronisation point
   __shared__ double dict[(VAR & 4) ? 256 : 1];
   if (done_flag && *done_flag) return;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
       }
     }
     if (row < A.n_rows) {
-      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
+      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) {
         const double d = dinv[row];  // one matrix, one diagonal
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] *= d;
@@ -146,6 +146,14 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
         if (EPI == OX_EPI_BCGS_T) {
           s[c] = fma(acc[c], acc[c], s[c]);
           s[NC + c] = fma(acc[c], x[row * NC + c], s[NC + c]);
+        }
+        if (EPI == OX_EPI_BCGS_T5) {
+          const double xs = x[row * NC + c], ah = aux[row * NC + c];
+          s[c] = fma(acc[c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], xs, s[NC + c]);
+          s[2 * NC + c] = fma(ah, xs, s[2 * NC + c]);
+          s[3 * NC + c] = fma(ah, acc[c], s[3 * NC + c]);
+          s[4 * NC + c] = fma(xs, xs, s[4 * NC + c]);
         }
       }
     }
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
                                                  double *__restrict__ partial,
                                                  const int *__restrict__ done_flag /* never null */,
                                                  const int32_t *__restrict__ slice_list, int n_list, KspFold fold) {
-  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : (EPI == OX_EPI_BCGS_T ? 2 * NC : NC);
+  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-B load from an 8-B aligned address
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   __shared__ KspFoldLds fl;
@@ -224,10 +232,10 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
     double xe[NC], ae[NC], de = 1.0;  // epilogue operands: requested now, used after the products
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      xe[c] = (EPI == OX_EPI_DOT || EPI == OX_EPI_BCGS_T) ? x[rowc * NC + c] : 0.0;
-      ae[c] = (EPI == OX_EPI_BCGS_V) ? aux[rowc * NC + c] : 0.0;
+      xe[c] = (EPI == OX_EPI_DOT || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) ? x[rowc * NC + c] : 0.0;
+      ae[c] = (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T5) ? aux[rowc * NC + c] : 0.0;
     }
-    if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) de = dinv[rowc];
+    if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) de = dinv[rowc];
     double acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
       }
     }
     if (row < A.n_rows) {
-      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T) {
+      if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] *= de;
       }
@@ -295,6 +303,13 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
         if (EPI == OX_EPI_BCGS_T) {
           s[c] = fma(acc[c], acc[c], s[c]);
           s[NC + c] = fma(acc[c], xe[c], s[NC + c]);
+        }
+        if (EPI == OX_EPI_BCGS_T5) {
+          s[c] = fma(acc[c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], xe[c], s[NC + c]);
+          s[2 * NC + c] = fma(ae[c], xe[c], s[2 * NC + c]);
+          s[3 * NC + c] = fma(ae[c], acc[c], s[3 * NC + c]);
+          s[4 * NC + c] = fma(xe[c], xe[c], s[4 * NC + c]);
         }
       }
     }
@@ -385,7 +400,8 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   OX_SPMV_CASE(NC, OX_EPI_NONE)      \
   OX_SPMV_CASE(NC, OX_EPI_DOT)       \
   OX_SPMV_CASE(NC, OX_EPI_BCGS_V)    \
-  OX_SPMV_CASE(NC, OX_EPI_BCGS_T)
+  OX_SPMV_CASE(NC, OX_EPI_BCGS_T)    \
+  OX_SPMV_CASE(NC, OX_EPI_BCGS_T5)
   OX_SPMV_NC(1) OX_SPMV_NC(2) OX_SPMV_NC(3)
 #undef OX_SPMV_NC
 #undef OX_SPMV_CASE
@@ -432,7 +448,7 @@ int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, con
   if (ox_prof_on) ox_prof_start(OX_TAG_HALO, st, ncomp);
   if (ox_halo_begin_impl(dist, x, ncomp, st)) return -1;
   if (ox_prof_on) ox_prof_stop(st);
-  const int nv = (epi == OX_EPI_NONE) ? 0 : (epi == OX_EPI_BCGS_T ? 2 * ncomp : ncomp);
+  const int nv = ox_epi_nv(epi, ncomp);
   const int nb_int = ox_spmv_blocks_n(A->n_interior);
   if (spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, A->ib_slices, A->n_interior, nullptr)) return -1;
   if (ox_halo_end_impl(dist, x, ncomp, st)) return -1;

@@ -10,6 +10,10 @@ Option mapping (PETSc string keys, as the reference passes them):
   ksp_cg_single_reduction  PETSc's option name: the Chronopoulos-Gear recurrences with one merged
             reduction (one all-reduce) per iteration; default: true on mesh-partitioned operators,
             false (PETSc's default, faster there) on a single GPU
+  ksp_bcgs_merged_reduction  (extension; also selected by ksp_type ibcgs / pipebcgs / fbcgsr, PETSc's reduced-
+            synchronisation BiCGStab variants): two merged reductions (all-reduces) per iteration instead of
+            three -- omega, rho and the residual norm from one reduction behind the second mat-vec
+            (OX_KSP_BCGS_MERGED); default: true on mesh-partitioned operators, false on a single GPU
   ksp_rtol, ksp_atol, ksp_max_it, ksp_initial_guess_nonzero: as in PETSc (defaults 1e-5,
             1e-50, 10000, false -> the solution vector is zeroed before the solve)
   ksp_bcgs_restarts (extension): BiCGStab restarts allowed after a rho/omega breakdown; default 0
@@ -96,12 +100,17 @@ class KSPSolver:
         dflt = self._A is not None and self._A.pattern.dist is not None
         single = o.get("ksp_cg_single_reduction", dflt) not in (False, 0, "false", "0", "False")
         cg = _lib.KSP_CG_SINGLE if single else _lib.KSP_CG
+        # "bcgs" on a mesh-partitioned operator: the merged-reduction recurrences (2 all-reduces per iteration
+        # instead of 3; same Krylov space, iteration counts within +-2)
+        merged = o.get("ksp_bcgs_merged_reduction", dflt or kt in ("ibcgs", "pipebcgs", "fbcgsr")) \
+            not in (False, 0, "false", "0", "False")
+        bcgs = _lib.KSP_BCGS_MERGED if merged else _lib.KSP_BCGS
         if kt == "cg":
             meth = cg
-        elif kt in ("bcgs", "bicgstab"):
-            meth = _lib.KSP_BCGS
+        elif kt in ("bcgs", "bicgstab", "ibcgs", "pipebcgs", "fbcgsr"):
+            meth = bcgs
         else:
-            meth = cg if (self._A is not None and self._A.symmetric) else _lib.KSP_BCGS
+            meth = cg if (self._A is not None and self._A.symmetric) else bcgs
         if direct:
             return meth, DIRECT_RTOL, 1e-50, 20000, True
         return (meth, float(o.get("ksp_rtol", 1e-5)), float(o.get("ksp_atol", 1e-50)),
@@ -138,7 +147,7 @@ class KSPSolver:
         # so check every iteration unless iterations are shorter than two reads.
         key = (nc, meth)
         if key not in self._every:
-            t_iter = (2 if meth == _lib.KSP_BCGS else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6  # seconds
+            t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6  # seconds
             if nc > 1:
                 ev = 1 if t_iter > 60e-6 else 4
             else:

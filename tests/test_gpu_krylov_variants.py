@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _system(dim, N, deg):
+def _system(dim, N, deg, mass=3.0):
     from oasisx_amd import fem
     from oasisx_amd import mesh as M
     from oasisx_amd.la import SellMatrix
@@ -21,7 +21,7 @@ def _system(dim, N, deg):
     V = fem.FunctionSpace(mesh, deg, window=256)
     F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), deg, 1, vd=V.cell_dofs.cpu().numpy(),
                 qd=V.cells_in_kernel_order(), nv_dofs=V.num_dofs, nq_dofs=mesh.num_vertices)
-    Acsr = (F.stiffness_v() + 3.0 * F.mass_v()).tocsr()
+    Acsr = (F.stiffness_v() + mass * F.mass_v()).tocsr()
     A = SellMatrix(V.pattern, symmetric=True)
     A.vals.copy_(V.pattern.values_from_csr(Acsr))
     A.version += 1
@@ -212,3 +212,48 @@ def test_folded_sync_points_are_bit_identical_to_the_scalar_kernels(hip, ksp_typ
         lib.ox_set_ksp_fold(1)
     assert out[1][1:] == out[0][1:], (out[1][1:], out[0][1:])
     assert torch.equal(out[1][0], out[0][0])
+
+
+@pytest.mark.parametrize("dim,N,deg,nc", [(2, 24, 2, 1), (3, 8, 2, 3), (3, 10, 1, 2), (3, 16, 2, 3)])
+def test_merged_reduction_bicgstab_matches_standard_bicgstab_and_oracle(hip, dim, N, deg, nc):
+    """OX_KSP_BCGS_MERGED (two synchronisation points per iteration: rhat.v, then {t.t, t.s, rhat.s, rhat.t, s.s}
+    with |r| by recurrence) against the standard three-point BiCGStab and the oracle's PETSc-convention BiCGStab
+    (reference ksp.py:76 at fracstep.py:521): same converged reason, iteration counts within +-2, same solution to
+    solver tolerance; lock-step columns of very different scale, the narrowed continuation and a zero
+    right-hand side column (converged at once: its deferred x update must add nothing) included."""
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oracle import ipcs_oracle as O
+
+    # M/dt-dominated, mildly non-symmetric: the tentative-velocity matrix's character (10-30 iterations; on
+    # ill-conditioned systems BiCGStab's count wanders by 10 % with the rounding of any inner product)
+    V, A, Acsr = _system(dim, N, deg, mass=2000.0)
+    A.vals.mul_(1.0 + 0.002 * torch.sin(torch.arange(A.vals.numel(), device="cuda", dtype=torch.float64)))
+    A.version += 1
+    Acsr = A.to_scipy()
+    n = V.num_dofs
+    x = V.x.cpu().numpy()
+    cols = [np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1]), 1e-3 * np.sin(5.0 * x[:, 0] * x[:, -1]), np.zeros(n)][:nc]
+    B = FieldStorage(n, nc, "cuda")
+    B.dev()[:] = torch.from_numpy(np.stack(cols, axis=1)).cuda()
+    out = {}
+    for merged in (True, False):
+        ksp = KSPSolver(None, {"ksp_type": "bcgs", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
+                               "ksp_bcgs_merged_reduction": merged})
+        ksp.setOperators(A)
+        X = FieldStorage(n, nc, "cuda")
+        X.dev().fill_(7.0)  # a zero initial guess is the solver's business
+        reasons = ksp.solve_block(B, X)
+        out[merged] = (X.dev().cpu().numpy().copy(), ksp.iterations[:nc], reasons)
+    for c in range(nc):
+        if not cols[c].any():  # b = 0: converged on the spot (atol), x = 0 from both
+            for merged in (True, False):
+                assert out[merged][2][c] > 0 and out[merged][1][c] == 0 and not out[merged][0][:, c].any()
+            continue
+        sol, reason, its, _ = O.jacobi_bicgstab(Acsr, cols[c], rtol=1e-10, atol=1e-50)
+        for merged in (True, False):
+            xs, it, rs = out[merged]
+            assert rs[c] == reason == 2  # KSP_CONVERGED_RTOL
+            assert abs(it[c] - its) <= (2 if merged else 1), (merged, it, its)
+            assert np.abs(xs[:, c] - sol).max() < 1e-7 * max(np.abs(sol).max(), 1.0)
+    assert np.abs(out[True][0] - out[False][0]).max() < 1e-7 * np.abs(out[False][0]).max()
