@@ -278,6 +278,10 @@ int ox_scatter_add(double *b, const int32_t *rows, const double *y, int64_t n, i
 
 /* ---- S4: Mat.zeroRowsLocal(rows, diag) (fracstep.py:471-472); keeps columns -------- */
 int ox_zero_rows(const ox_sell *A, const int32_t *rows, int64_t n, double diag, void *stream);
+/* The same, and au[row][c] = diag * u1[row][c] for the zeroed rows (au may be NULL): the identity rows of the
+ * product A u1 that ox_assemble_first_au hands to the tentative-velocity solve (fracstep.py:470-472 + :521). */
+int ox_zero_rows_au(const ox_sell *A, const int32_t *rows, int64_t n, double diag, double *au,
+                    const double *u1, int ncomp, void *stream);
 /* DOLFINx assemble_matrix(..., bcs) on the pressure Laplacian (fracstep.py:379):
  * rows AND columns flagged in is_bc[] -> identity. */
 int ox_zero_rows_cols(const ox_sell *A, const uint8_t *is_bc, double diag, void *stream);

@@ -165,6 +165,7 @@ SIGNATURES = {
     "ox_set_bc": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ox_scatter_add": (_I, [_P, _P, _P, _L, _I, _I, _D, _P]),
     "ox_zero_rows": (_I, [C.POINTER(ox_sell), _P, _L, _D, _P]),
+    "ox_zero_rows_au": (_I, [C.POINTER(ox_sell), _P, _L, _D, _P, _P, _I, _P]),
     "ox_zero_rows_cols": (_I, [C.POINTER(ox_sell), _P, _D, _P]),
     "ox_assemble_matrix": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
                                 C.POINTER(ox_sell), _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),

@@ -348,6 +348,9 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
     const double2 *__restrict__ mv = reinterpret_cast<const double2 *>(F.Mv + base) + lane;
     const double2 *__restrict__ kv = reinterpret_cast<const double2 *>(F.Kv + base) + lane;
     const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+    // (the pattern's 16-bit column stream was tried here -- 2 instead of 4 B per entry of ~14 B of streams --
+    // and measured SLOWER: 9.25 vs 8.50 ms per assemble_first on one box, tools/af_bench.py; the decode's scalar
+    // base loads and selects cost the epilogue more than the 1 GB it saves)
     const double idt = F.idt, mhnu = -0.5 * F.nu;
     double bf[GDIM], af[GDIM];
 #pragma unroll

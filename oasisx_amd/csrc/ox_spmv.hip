@@ -850,30 +850,51 @@ __device__ __forceinline__ int64_t ox_entry(const int64_t base, int k, int lane)
   return base + (int64_t)(k / OX_KV) * (64 * OX_KV) + lane * OX_KV + (k % OX_KV);
 }
 
-__global__ void k_zero_rows(ox_sell A, const int32_t *rows, int64_t n, double diag) {
+// One wave per 64 listed rows, each lane its row: the (k, k+1) pairs of a row are 16 B apart-aligned, so a lane
+// stores 16 B at a time.  au (optional): the identity row's product with u1, (A u1)[row] = u1[row], for the
+// mat-vec the fused assembly hands to the tentative-velocity solve (ox_assemble_first_au) -- one launch instead
+// of a zero-rows launch plus two indexed copies per boundary condition.
+__global__ __launch_bounds__(64) void k_zero_rows(ox_sell A, const int32_t *__restrict__ rows, int64_t n, double diag,
+                                                  double *__restrict__ au, const double *__restrict__ u1, int ncomp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int row = rows[i];
   const int slice = row >> 6, lane = row & 63;
   const int64_t base = A.slice_ptr[slice];
-  const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
+  const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
+  const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+  double2 *__restrict__ vp = reinterpret_cast<double2 *>(A.vals + base) + lane;
   bool placed = false;
-  for (int k = 0; k < width; ++k) {
-    const int64_t e = ox_entry(base, k, lane);
-    const bool isd = (A.cols[e] == row) && !placed;  // first match = the real diagonal entry
-    A.vals[e] = isd ? diag : 0.0;
-    placed = placed || isd;
+  for (int k = 0; k < npair; ++k) {
+    const int2 c = cp[(size_t)k * 64];
+    double2 v;
+    const bool d0 = (c.x == row) && !placed;  // first match = the real diagonal entry (padding repeats the row later)
+    placed = placed || d0;
+    const bool d1 = (c.y == row) && !placed;
+    placed = placed || d1;
+    v.x = d0 ? diag : 0.0;
+    v.y = d1 ? diag : 0.0;
+    vp[(size_t)k * 64] = v;
   }
+  if (au) {
+    for (int c = 0; c < ncomp; ++c) au[(size_t)row * ncomp + c] = diag * u1[(size_t)row * ncomp + c];
+  }
+}
+
+extern "C" int ox_zero_rows_au(const ox_sell *A, const int32_t *rows, int64_t n, double diag, double *au,
+                               const double *u1, int ncomp, void *stream) {
+  if (n <= 0) return 0;
+  if (!A || !rows || (au && !u1)) OX_FAIL("ox_zero_rows: null argument");
+  if (au && (ncomp < 1 || ncomp > OX_MAXC)) OX_FAIL("ox_zero_rows_au: ncomp=%d", ncomp);
+  hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ox_stream(stream), *A, rows, n, diag, au, u1,
+                     ncomp);
+  OX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int ox_zero_rows(const ox_sell *A, const int32_t *rows, int64_t n, double diag,
                             void *stream) {
-  if (n <= 0) return 0;
-  if (!A || !rows) OX_FAIL("ox_zero_rows: null argument");
-  hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ox_stream(stream),
-                     *A, rows, n, diag);
-  OX_LAUNCH_CHECK();
-  return 0;
+  return ox_zero_rows_au(A, rows, n, diag, nullptr, nullptr, 1, stream);
 }
 
 __global__ __launch_bounds__(256) void k_zero_rows_cols(ox_sell A, const uint8_t *is_bc,

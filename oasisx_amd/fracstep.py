@@ -297,11 +297,9 @@ class FractionalStep_AB_CN:
             bcp.update_bc()
             bcp.add_surface_terms(self._BFIRST)
         # NOTE (reference :470): rows of the FIRST component's BCs only
-        for bcu in self._bcs_u[0]:
-            self._A.zero_rows(bcu._rows_dev, 1.0)
-            if want_au:  # identity rows: (A @ u1)[row] = u1[row]
-                rows = bcu._rows_dev.to(torch.int64)
-                self._B3.dev()[rows] = self._U1.dev()[rows]
+        for bcu in self._bcs_u[0]:  # identity rows; (A @ u1)[row] = u1[row] there, in the same launch
+            self._A.zero_rows(bcu._rows_dev, 1.0, self._B3.ptr() if want_au else None,
+                              self._U1.ptr() if want_au else None, self._gdim)
         self._AU1_valid = want_au
 
     def velocity_tentative_assemble(self):

@@ -99,11 +99,13 @@ class SellMatrix:
         _lib.check(lib.ox_spmv(self.ref(), _lib.ptr(x), _lib.ptr(y), ncomp, self.pattern.dist,
                                _lib.current_stream()), "ox_spmv")
 
-    def zero_rows(self, rows_dev: torch.Tensor, diag: float = 1.0):
-        """Mat.zeroRowsLocal(rows, diag): keeps the columns (reference fracstep.py:471-472)."""
+    def zero_rows(self, rows_dev: torch.Tensor, diag: float = 1.0, au=None, u1=None, ncomp: int = 1):
+        """Mat.zeroRowsLocal(rows, diag): keeps the columns (reference fracstep.py:471-472).  ``au``/``u1``
+        (device pointers): also set ``au[rows] = diag * u1[rows]``, the identity rows of a product A u1 that was
+        formed before the rows were zeroed (FractionalStep_AB_CN.assemble_first) -- same launch."""
         lib = _lib.load()
-        _lib.check(lib.ox_zero_rows(self.ref(), _lib.ptr(rows_dev), int(rows_dev.shape[0]), float(diag),
-                                    _lib.current_stream()), "ox_zero_rows")
+        _lib.check(lib.ox_zero_rows_au(self.ref(), _lib.ptr(rows_dev), int(rows_dev.shape[0]), float(diag), au, u1,
+                                       int(ncomp), _lib.current_stream()), "ox_zero_rows")
         self.version += 1
 
 
