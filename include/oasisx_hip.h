@@ -197,6 +197,22 @@ int ox_mesh_destroy(ox_mesh *mesh);
 /* scalar Lagrange space of degree 1 or 2 (functionspace(mesh, ("Lagrange", k)), fracstep.py:187-216);
  * window: rows per length-sorting window of the SELL-64 numbering (< 64: the default 4096). */
 int ox_space_create(const ox_mesh *mesh, int degree, int window, ox_space **out);
+/* One rank's piece of a mesh-partitioned space (what DOLFINx's functionspace() returns on a distributed mesh,
+ * reference fracstep.py:186-216): built from that rank's cells only (its own cells + one ghost layer).
+ *   ox_mesh_create_sub   the part as a mesh of its own (vertices renumbered 0..n-1 in ascending global id) whose
+ *                        ordering keys use the WHOLE mesh's frame -- bounding box lo/span, lattice flag, tile bits,
+ *                        cell count -- so every part orders its cells and dofs as the whole mesh would;
+ *   ox_space_create_part owner: device [n_initial] owner rank of every initial dof of the part (its vertices, then
+ *                        its edges by ascending vertex pair for degree 2).  Dofs owned by `rank` come first (tile
+ *                        order, window-sorted by row length: the rows of every pattern of the space), the ghosts
+ *                        behind them ordered by (owner, initial id) -- the order in which the owners send them.
+ *                        pattern.sell.n_rows = owned dofs, n_cols = n_dofs = owned + ghosts.  n_dofs_whole: dofs of
+ *                        the whole space (resolution of the ordering keys). */
+int ox_mesh_create_sub(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                       int on_device, const double *lo, const double *span, int lattice, int tile_bits,
+                       int64_t n_cells_whole, ox_mesh **out);
+int ox_space_create_part(const ox_mesh *mesh, int degree, int window, const int32_t *owner, int64_t n_initial, int rank,
+                         int64_t n_dofs_whole, ox_space **out);
 int ox_space_view(const ox_space *space, ox_space_info *view);
 int ox_space_destroy(ox_space *space);
 /* pattern of a mixed operator, rows = dofs of `rows`, columns = dofs of `cols` (fracstep.py:315,336,352) */

@@ -144,6 +144,8 @@ SIGNATURES = {
     "ox_mesh_view": (_I, [_P, C.POINTER(ox_mesh_info)]),
     "ox_mesh_destroy": (_I, [_P]),
     "ox_space_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "ox_mesh_create_sub": (_I, [_P, _L, _P, _L, _I, _I, C.POINTER(_D), C.POINTER(_D), _I, _I, _L, C.POINTER(_P)]),
+    "ox_space_create_part": (_I, [_P, _I, _I, _P, _L, _I, _L, C.POINTER(_P)]),
     "ox_space_view": (_I, [_P, C.POINTER(ox_space_info)]),
     "ox_space_destroy": (_I, [_P]),
     "ox_rect_create": (_I, [_P, _P, C.POINTER(_P)]),

@@ -552,6 +552,7 @@ struct ox_space {
   const ox_mesh *mesh = nullptr;
   int degree = 0, nd = 0, pw = 0, window = 0;
   int64_t n = 0, n_edges = 0, npairs = 0;  // dofs, edges, padded adjacency pairs
+  int64_t n_rows = 0;   // rows of the space's patterns: n, or the owned dofs of a mesh-partitioned space (they come first)
   DevBuf cell_dofs;     // [nc][nd] int32, final numbering
   DevBuf x;             // [n][gdim]
   DevBuf rank_initial;  // [n] int32: initial dof (vertex id, or nv + edge id) -> final dof
@@ -711,8 +712,15 @@ int group_pairs(const int32_t *cell_dofs, int64_t nc, int nd, int64_t n, DevBuf 
 }  // namespace
 
 // ================================== C ABI ===========================================================
-extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
-                              int on_device, int tile_bits, ox_mesh **out) {
+// frame: the bounding box, lattice flag, tile bits and cell count of the WHOLE mesh when `cells` is one rank's part of
+// it (ox_mesh_create_sub) -- the ordering keys of all parts then live on the same lattice as the whole mesh's
+struct MeshFrame {
+  double lo[3], span[3];
+  int lattice, tile_bits;
+  int64_t n_cells_ref;
+};
+static int mesh_create_impl(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                            int on_device, int tile_bits, const MeshFrame *frame, ox_mesh **out) {
   if (!coords || !cells || !out) OX_FAIL("ox_mesh_create: null argument");
   if (gdim != 2 && gdim != 3) OX_FAIL("ox_mesh_create: gdim=%d (triangles or tetrahedra)", gdim);
   if (n_vertices < gdim + 1 || n_cells < 1) OX_FAIL("ox_mesh_create: empty mesh");
@@ -732,7 +740,9 @@ extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const in
   OX_TRY(cells_in.alloc(sizeof(int32_t) * (size_t)n_cells * nv));
   OX_HIP(hipMemcpy(cells_in.p, cells, cells_in.bytes, kind));
   // bounding box
-  {
+  if (frame) {
+    for (int k = 0; k < 3; ++k) M->lo[k] = frame->lo[k], M->span[k] = k < gdim ? std::max(frame->span[k], 1e-300) : 1.0;
+  } else {
     const int nb = 512;
     DevBuf part;
     OX_TRY(part.alloc(sizeof(double) * 6 * nb));
@@ -753,7 +763,9 @@ extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const in
   // of a wave coalesce); anything else is ordered along a Z-order curve: 64 consecutive rows are then a
   // compact cluster instead of a thin tube through the whole x extent (Delaunay mesh, 2.3 M P2 rows:
   // SpMV 350 -> 262 us).  OX_ORDER=tiles|curve overrides.
-  {
+  if (frame) {
+    M->lattice = frame->lattice;
+  } else {
     int64_t L = 1;
     while (true) {
       __int128 v = 1;
@@ -788,8 +800,9 @@ extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const in
       tile_bits = (int)std::min(6.0, std::max(0.0, std::nearbyint(std::log2(lines / 24.0))));
     }
   }
+  if (frame) tile_bits = frame->tile_bits;
   M->tile_bits = tile_bits;
-  const KeySpec K = key_spec(M, tile_bits, n_cells);
+  const KeySpec K = key_spec(M, tile_bits, frame ? frame->n_cells_ref : n_cells);
   M->key_bits = K.bits;
   // kernel cell order: tiled order of the centroids (stable: ties keep the caller's order)
   {
@@ -819,6 +832,23 @@ extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const in
   return 0;
 }
 
+extern "C" int ox_mesh_create(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                              int on_device, int tile_bits, ox_mesh **out) {
+  return mesh_create_impl(coords, n_vertices, cells, n_cells, gdim, on_device, tile_bits, nullptr, out);
+}
+
+extern "C" int ox_mesh_create_sub(const double *coords, int64_t n_vertices, const int32_t *cells, int64_t n_cells, int gdim,
+                                  int on_device, const double *lo, const double *span, int lattice, int tile_bits,
+                                  int64_t n_cells_whole, ox_mesh **out) {
+  if (!lo || !span) OX_FAIL("ox_mesh_create_sub: null argument");
+  if (tile_bits < 0 || tile_bits > 6) OX_FAIL("ox_mesh_create_sub: tile_bits=%d (the whole mesh's, 0..6)", tile_bits);
+  if (n_cells_whole < n_cells) OX_FAIL("ox_mesh_create_sub: n_cells_whole < n_cells");
+  MeshFrame F{};
+  for (int k = 0; k < 3; ++k) F.lo[k] = k < gdim ? lo[k] : 0.0, F.span[k] = k < gdim ? span[k] : 1.0;
+  F.lattice = lattice ? 1 : 0, F.tile_bits = tile_bits, F.n_cells_ref = n_cells_whole;
+  return mesh_create_impl(coords, n_vertices, cells, n_cells, gdim, on_device, tile_bits, &F, out);
+}
+
 extern "C" int ox_mesh_destroy(ox_mesh *M) {
   delete M;
   return 0;
@@ -839,7 +869,33 @@ extern "C" int ox_mesh_view(const ox_mesh *M, ox_mesh_info *v) {
   return 0;
 }
 
-extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_space **out) {
+// ghosts behind the owned dofs, ordered by (owner rank, initial dof id)
+__global__ __launch_bounds__(256) void k_point_keys_part(const double *__restrict__ x, int64_t n, KeySpec K,
+                                                         const int32_t *__restrict__ owner, int rank,
+                                                         uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int o = owner[i];
+  keys[i] = o == rank ? locality_key(x + i * K.d, K) : ((1ull << 63) | ((uint64_t)(uint32_t)o << 32) | (uint64_t)i);
+  ids[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void k_owned_flag(const int32_t *__restrict__ owner, int64_t n, int rank, int32_t *__restrict__ f) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) f[i] = owner[i] == rank ? 1 : 0;
+}
+// window sort of the owned rows only; the ghosts keep their order behind them
+__global__ __launch_bounds__(256) void k_window_keys_part(const int32_t *__restrict__ len, int64_t n, int64_t n_owned, int window,
+                                                          int lmax, uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t nwin = (uint64_t)((n_owned + window - 1) / window + 1);
+  keys[r] = r < n_owned ? (uint64_t)(r / window) * (uint64_t)(lmax + 1) + (uint64_t)(lmax - len[r])
+                        : nwin * (uint64_t)(lmax + 1) + (uint64_t)(r - n_owned);
+  ids[r] = (int32_t)r;
+}
+
+static int space_create_impl(const ox_mesh *M, int degree, int window, const int32_t *owner, int rank, int64_t n_initial,
+                             int64_t n_dofs_whole, ox_space **out) {
   if (!M || !out) OX_FAIL("ox_space_create: null argument");
   if (degree != 1 && degree != 2) OX_FAIL("ox_space_create: Lagrange degree %d (1 and 2 are built)", degree);
   if (window < SLICE) window = 4096;
@@ -896,6 +952,18 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   const int64_t n = M->nv + V->n_edges;
   if (n >= ((int64_t)1 << 31) - 64) OX_FAIL("ox_space_create: %lld dofs exceed int32", (long long)n);
   V->n = n;
+  if (owner && n != n_initial)
+    OX_FAIL("ox_space_create_part: the mesh part has %lld initial dofs, owners were given for %lld", (long long)n,
+            (long long)n_initial);
+  int64_t n_owned = n;  // mesh-partitioned space: the dofs this rank owns come first, their rows are the rows
+  if (owner) {
+    DevBuf flag;
+    OX_TRY(flag.alloc(sizeof(int32_t) * (size_t)n));
+    hipLaunchKernelGGL(k_owned_flag, dim3(nblk(n)), dim3(256), 0, st, owner, n, rank, flag.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_TRY(reduce_sum_i32(flag.as<int32_t>(), n, &n_owned, st));
+  }
+  V->n_rows = n_owned;
   // ---- 2. dof coordinates, tiled spatial order ------------------------------------------------------
   DevBuf xL, rank1;
   OX_TRY(xL.alloc(sizeof(double) * (size_t)n * d));
@@ -904,16 +972,20 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {
-    const KeySpec K = key_spec(M, M->tile_bits, n);
+    const KeySpec K = key_spec(M, M->tile_bits, owner ? n_dofs_whole : n);
     DevBuf k_in, k_out, v_in, perm1;
     OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)n));
     OX_TRY(perm1.alloc(sizeof(int32_t) * (size_t)n));
-    hipLaunchKernelGGL(k_point_keys, dim3(nblk(n)), dim3(256), 0, st, xL.as<double>(), n, K, k_in.as<uint64_t>(), v_in.as<int32_t>());
+    if (owner)
+      hipLaunchKernelGGL(k_point_keys_part, dim3(nblk(n)), dim3(256), 0, st, xL.as<double>(), n, K, owner, rank,
+                         k_in.as<uint64_t>(), v_in.as<int32_t>());
+    else
+      hipLaunchKernelGGL(k_point_keys, dim3(nblk(n)), dim3(256), 0, st, xL.as<double>(), n, K, k_in.as<uint64_t>(), v_in.as<int32_t>());
     OX_LAUNCH_CHECK();
     OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), perm1.as<int32_t>(), (size_t)n,
-                      key_end_bit(K), st));
+                      owner ? 64 : key_end_bit(K), st));
     hipLaunchKernelGGL(k_invert, dim3(nblk(n)), dim3(256), 0, st, perm1.as<int32_t>(), n, rank1.as<int32_t>());
     OX_LAUNCH_CHECK();
     OX_HIP(hipStreamSynchronize(st));
@@ -924,6 +996,7 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   OX_HIP(hipMemset(err.p, 0, sizeof(int)));
   DevBuf len1;
   OX_TRY(len1.alloc(sizeof(int32_t) * (size_t)n));
+  OX_HIP(hipMemsetAsync(len1.p, 0, len1.bytes, st));  // (ghost rows of a partitioned space: no row, length 0)
   {
     DevBuf cd1, start1, pair1;
     OX_TRY(cd1.alloc(sizeof(int32_t) * (size_t)nc * nd));
@@ -932,13 +1005,13 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
     OX_LAUNCH_CHECK();
     OX_TRY(group_pairs(cd1.as<int32_t>(), nc, nd, n, start1, pair1, st));
     RowArgs A{};
-    A.n_rows = A.n_cols = n;
+    A.n_rows = n_owned, A.n_cols = n;
     A.start = start1.as<int64_t>(), A.pair = pair1.as<uint32_t>();
     A.nd_r = A.nd_c = nd;
     A.col_dofs = cd1.as<int32_t>();
     A.len = len1.as<int32_t>();
     A.err = err.as<int>();
-    hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(n)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(n_owned)), dim3(256), 0, st, A);
     OX_LAUNCH_CHECK();
     OX_HIP(hipStreamSynchronize(st));
     OX_TRY(check_row_error(err.as<int>(), "ox_space_create"));
@@ -954,10 +1027,14 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
     OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)n));
-    hipLaunchKernelGGL(k_window_keys, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), n, window, (int)lmax, k_in.as<uint64_t>(),
-                       v_in.as<int32_t>());
+    if (owner)
+      hipLaunchKernelGGL(k_window_keys_part, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), n, n_owned, window, (int)lmax,
+                         k_in.as<uint64_t>(), v_in.as<int32_t>());
+    else
+      hipLaunchKernelGGL(k_window_keys, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), n, window, (int)lmax, k_in.as<uint64_t>(),
+                         v_in.as<int32_t>());
     OX_LAUNCH_CHECK();
-    const uint64_t kmax = (uint64_t)((n + window - 1) / window + 1) * (uint64_t)(lmax + 1);
+    const uint64_t kmax = (uint64_t)((n + window - 1) / window + 3) * (uint64_t)(lmax + 1) + (uint64_t)(n - n_owned);
     OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), perm2.as<int32_t>(), (size_t)n, bits_for(kmax), st));
     hipLaunchKernelGGL(k_invert, dim3(nblk(n)), dim3(256), 0, st, perm2.as<int32_t>(), n, rank2.as<int32_t>());
     OX_LAUNCH_CHECK();
@@ -975,9 +1052,10 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
                      V->x.as<double>());
   OX_LAUNCH_CHECK();
   ox_pattern_store &P = V->P;
-  P.n_rows = P.n_cols = n;
-  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)n));
-  hipLaunchKernelGGL(k_gather_i32, dim3(nblk(n)), dim3(256), 0, st, len1.as<int32_t>(), perm2.as<int32_t>(), n, P.row_len.as<int32_t>());
+  P.n_rows = n_owned, P.n_cols = n;
+  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(n_owned, 1)));
+  hipLaunchKernelGGL(k_gather_i32, dim3(nblk(std::max<int64_t>(n_owned, 1))), dim3(256), 0, st, len1.as<int32_t>(), perm2.as<int32_t>(),
+                     n_owned, P.row_len.as<int32_t>());
   OX_LAUNCH_CHECK();
   OX_HIP(hipStreamSynchronize(st));
   cd0.release(), xL.release(), rank1.release(), rank2.release(), perm2.release(), len1.release();
@@ -989,7 +1067,7 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   OX_TRY(V->adj_pos.alloc((size_t)std::max<int64_t>(V->npairs, 1) * V->pw));
   {
     RowArgs A{};
-    A.n_rows = A.n_cols = n;
+    A.n_rows = n_owned, A.n_cols = n;
     A.start = V->start.as<int64_t>(), A.pair = V->pair.as<uint32_t>();
     A.nd_r = A.nd_c = nd;
     A.col_dofs = V->cell_dofs.as<int32_t>();
@@ -1007,6 +1085,17 @@ extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_spac
   guard.v = nullptr;
   *out = V;
   return 0;
+}
+
+extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_space **out) {
+  return space_create_impl(M, degree, window, nullptr, 0, 0, 0, out);
+}
+
+extern "C" int ox_space_create_part(const ox_mesh *M, int degree, int window, const int32_t *owner, int64_t n_initial, int rank,
+                                    int64_t n_dofs_whole, ox_space **out) {
+  if (!owner) OX_FAIL("ox_space_create_part: null argument");
+  if (n_dofs_whole < n_initial) OX_FAIL("ox_space_create_part: n_dofs_whole < n_initial");
+  return space_create_impl(M, degree, window, owner, rank, n_initial, n_dofs_whole, out);
 }
 
 extern "C" int ox_space_destroy(ox_space *V) {
@@ -1058,19 +1147,19 @@ extern "C" int ox_rect_create(const ox_space *R, const ox_space *C, ox_rect **ou
   Q->R = R, Q->C = C;
   Q->pw = C->nd <= 4 ? 4 : (C->nd <= 8 ? 8 : 16);
   ox_pattern_store &P = Q->P;
-  P.n_rows = R->n, P.n_cols = C->n;
+  P.n_rows = R->n_rows, P.n_cols = C->n;  // (a mesh-partitioned row space: its owned dofs)
   DevBuf err;
   OX_TRY(err.alloc(sizeof(int)));
   OX_HIP(hipMemset(err.p, 0, sizeof(int)));
-  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)R->n));
+  OX_TRY(P.row_len.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(R->n_rows, 1)));
   RowArgs A{};
-  A.n_rows = R->n, A.n_cols = C->n;
+  A.n_rows = R->n_rows, A.n_cols = C->n;
   A.start = R->start.as<int64_t>(), A.pair = R->pair.as<uint32_t>();
   A.nd_r = R->nd, A.nd_c = C->nd;
   A.col_dofs = C->cell_dofs.as<int32_t>();
   A.len = P.row_len.as<int32_t>();
   A.err = err.as<int>();
-  hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(R->n)), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_rows<0>, dim3(row_grid(R->n_rows)), dim3(256), 0, st, A);
   OX_LAUNCH_CHECK();
   OX_HIP(hipStreamSynchronize(st));
   OX_TRY(check_row_error(err.as<int>(), "ox_rect_create"));

@@ -325,10 +325,12 @@ class FunctionSpace:
         self.part = part
         self.native = None
         dev = mesh.device
-        if part is None and dev.type == "cuda" and _os.environ.get("OX_SETUP", "native") != "torch":
+        if dev.type == "cuda" and _os.environ.get("OX_SETUP", "native") != "torch":
             # the whole set-up runs inside liboasisx_hip.so (csrc/ox_setup.hip, behind the C ABI of
-            # include/oasisx_hip.h); this class only wraps the arrays the library owns
-            self._init_native(window)
+            # include/oasisx_hip.h); this class only wraps the arrays the library owns.  A mesh-partitioned
+            # space hands the library this rank's cells and the owner of each of their dofs
+            # (ox_mesh_create_sub / ox_space_create_part); the halo plan is then read off the partition.
+            self._init_native(window, part)
             return
         d = mesh.gdim
         nverts = mesh.num_vertices
@@ -359,15 +361,15 @@ class FunctionSpace:
                 uniq, inv = torch.unique(key.reshape(-1), return_inverse=True)
                 cell_edges = inv.reshape(nc, -1)
                 del a, b, key, inv
-            else:
+            else:  # the edges of this rank's window (parallel.MeshPartition): ids are positions among ITS keys
                 uniq = part.edge_keys
-                cell_edges = part.cell_edges[self.local_cells]
+                cell_edges = part.cell_edges_of(self.local_cells)
             self._edge_keys = uniq
             cd0g = torch.cat([cells, nverts + cell_edges], dim=1)
             n_glob = nverts + int(uniq.shape[0])
         nd = int(cd0g.shape[1])
         self.nd = nd
-        self.num_dofs_global = n_glob
+        self.num_dofs_global = n_glob if part is None else part.num_dofs_global(degree)
         if part is None:
             gl = None
             cdL = cd0g
@@ -390,7 +392,7 @@ class FunctionSpace:
             xL[~isv] = 0.5 * (mesh.coords[torch.div(ek, nverts, rounding_mode="floor")] + mesh.coords[ek % nverts])
         del isv
         # ---- 2. owned dofs in tiled spatial order, then ghosts by (owner, global id) --------------
-        skey = locality_key(xL, lo, span, tb, default_key_bits(n_glob, mesh.gdim, tb), curve)
+        skey = locality_key(xL, lo, span, tb, default_key_bits(self.num_dofs_global, mesh.gdim, tb), curve)
         if owned is None:
             perm1 = torch.argsort(skey, stable=True)
             n_owned = nL
@@ -481,21 +483,44 @@ class FunctionSpace:
         if part is not None:
             self.halo = self._build_halo(part, ghost_owner, cd0g)
 
-    def _init_native(self, window: int):
+    def _init_native(self, window: int, part=None):
         from . import native as N
 
         mesh, dev = self.mesh, self.mesh.device
-        ns = N.NativeSpace(mesh, self.degree, window)
+        d = mesh.gdim
+        if part is None:
+            ns = N.NativeSpace(mesh, self.degree, window)
+            nc = mesh.num_cells
+        else:
+            # initial dof ids of this rank's part: its vertices (ascending global id), then its edges (ascending key)
+            sub = N.NativeSubMesh.of(mesh, part)
+            nverts = mesh.num_vertices
+            if self.degree == 2:
+                uniq_e = torch.unique(part.cell_edges_of(sub.cells_global).reshape(-1))  # window edge indices, ascending
+                gl = torch.cat([sub.verts, nverts + uniq_e])
+            else:
+                gl = sub.verts
+            owner = part.owner0(self.degree)[gl].to(torch.int32).contiguous()
+            self.num_dofs_global = part.num_dofs_global(self.degree)
+            ns = N.NativeSpace(mesh, self.degree, window, part=part, owner=owner, n_dofs_whole=self.num_dofs_global)
+            nc = int(sub.cells_global.shape[0])
         self.native = ns
         v, own = ns.info, ns.handle
-        nc, d = mesh.num_cells, mesh.gdim
         n = int(v.n_dofs)
         self.nd = int(v.nd)
-        self.local_cells = ns.nmesh.cell_perm.to(torch.int64)
-        self.num_dofs_global = self.n_owned = self.n_local = self.num_dofs = n
-        self._gl = None
-        self._edge_keys = N.dev_tensor(v.edge_keys, (int(v.n_edges),), torch.int64, own, dev) if self.degree == 2 else None
         self._rank_initial = N.dev_tensor(v.rank_initial, (n,), torch.int32, own, dev)
+        if part is None:
+            self.local_cells = ns.nmesh.cell_perm.to(torch.int64)
+            self.num_dofs_global = self.n_owned = self.n_local = self.num_dofs = n
+            self._gl = None
+            self._edge_keys = (N.dev_tensor(v.edge_keys, (int(v.n_edges),), torch.int64, own, dev)
+                               if self.degree == 2 else None)
+        else:
+            self.local_cells = sub.cells_global[ns.nmesh.cell_perm.to(torch.int64)]  # global cell ids, kernel order
+            self.n_owned, self.n_local = int(v.pattern.sell.n_rows), n
+            self.num_dofs = n  # DOLFINx convention: local arrays hold owned dofs, then ghosts
+            self._gl = gl
+            self._edge_keys = part.edge_keys if self.degree == 2 else None
         self.cell_dofs = N.dev_tensor(v.cell_dofs, (nc, self.nd), torch.int32, own, dev)
         self.x = N.dev_tensor(v.x, (n, d), torch.float64, own, dev)
         self._x3 = None
@@ -511,6 +536,10 @@ class FunctionSpace:
         self.adj_count = start[1:] - start[:-1]
         self.halo = None
         self.dist = None
+        if part is not None:
+            owner_f = torch.empty(n, dtype=torch.int64, device=dev)
+            owner_f[self._rank_initial.to(torch.int64)] = owner.to(torch.int64)
+            self.halo = self._build_halo(part, owner_f[self.n_owned:], None)
 
     # ---------------------------------------------------------------------------------
     def global_to_local(self, gids: torch.Tensor) -> torch.Tensor:
@@ -522,22 +551,24 @@ class FunctionSpace:
         return torch.where(ok, self._rank_initial[pos], torch.full_like(pos, -1))
 
     def _build_halo(self, part, ghost_owner, cd0g):
-        """Who sends what: ghosts are ordered by (owner, global id) on the receiver, and the owner
-        lists exactly those dofs in the same order -- computed from the replicated partition data,
-        no communication at set-up."""
+        """Who sends what: ghosts are ordered by (owner, initial id) on the receiver, and the owner lists
+        exactly those dofs in the same order (vertices by id, then edges by key) -- each side computes its list
+        from its own window of the mesh (parallel.MeshPartition), no communication at set-up."""
         dev = self.mesh.device
         nverts = self.mesh.num_vertices
         owner0 = part.owner0(self.degree)
         peers, send_lists, recv_counts = [], [], []
-        for qr in range(part.nparts):
+        cand = set(part.peers()) | set(int(q) for q in torch.unique(ghost_owner).tolist())
+        for qr in sorted(cand):
             if qr == part.rank:
                 continue
             nrecv = int((ghost_owner == qr).sum().item())
-            cm = part.cell_mask(qr)
+            # the cells both ranks keep: qr's ghosts that this rank owns are dofs of exactly these cells
+            cm = part.cells_shared_with(qr)
             cq = self.mesh.cells[cm]
-            ids = cq if self.degree == 1 else torch.cat([cq, nverts + part.cell_edges[cm]], dim=1)
+            ids = cq if self.degree == 1 else torch.cat([cq, nverts + part.cell_edges_of(cm)], dim=1)
             ids = torch.unique(ids.reshape(-1))
-            ids = ids[owner0[ids] == part.rank]  # ascending global id = the receiver's order
+            ids = ids[owner0[ids] == part.rank]  # ascending id (vertices, then edges by key) = the receiver's order
             if nrecv == 0 and ids.shape[0] == 0:
                 continue
             loc = self.global_to_local(ids)
@@ -702,7 +733,10 @@ class FunctionSpace:
             for a, b in itertools.combinations(range(verts.shape[1]), 2):
                 lo = torch.from_numpy(np.minimum(verts[:, a], verts[:, b]).astype(np.int64)).to(dev)
                 hi = torch.from_numpy(np.maximum(verts[:, a], verts[:, b]).astype(np.int64)).to(dev)
-                gids.append(nv + torch.searchsorted(ek, lo * nv + hi))
+                key = lo * nv + hi
+                pos = torch.searchsorted(ek, key).clamp_max(max(int(ek.shape[0]) - 1, 0))
+                hit = ek[pos] == key  # (a partitioned space knows the edges of its window only)
+                gids.append((nv + pos)[hit])
         loc = self.global_to_local(torch.cat(gids))
         loc = loc[loc >= 0]
         return np.unique(loc.cpu().numpy()).astype(np.int32)

@@ -103,7 +103,7 @@ class FractionalStep_AB_CN:
         if comm is not None and getattr(comm, "size", 1) > 1:
             from .parallel import MeshPartition
 
-            part = MeshPartition(mesh, comm.rank, comm.size)
+            part = MeshPartition(mesh, comm.rank, comm.size, comm)
         self._part = part
         Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part)
         if isinstance(p_element, FunctionSpace):

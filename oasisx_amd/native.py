@@ -99,12 +99,60 @@ def pattern_from_info(P, owner, device, SellPattern):
     return pat
 
 
-class NativeSpace:
-    def __init__(self, mesh, degree: int, window: int):
+class NativeSubMesh:
+    """``ox_mesh`` of ONE RANK'S PART of a mesh (``ox_mesh_create_sub``): the rank's local cells with their
+    vertices renumbered in ascending global id, ordered on the whole mesh's key lattice.  Cached on the
+    partition object so that the velocity and the pressure space share cells and geometry."""
+
+    def __init__(self, mesh, part):
+        from .fem import default_tile_bits, mesh_is_lattice
+
         lib = _lib.load()
-        self.nmesh = NativeMesh.of(mesh)
+        dev = mesh.device
+        self.cells_global = part.local_cells  # ascending global cell ids
+        cg = mesh.cells[self.cells_global]
+        self.verts = torch.unique(cg.reshape(-1))  # ascending global vertex ids = the part's vertex numbering
+        cells32 = torch.searchsorted(self.verts, cg.reshape(-1)).reshape(cg.shape).to(torch.int32).contiguous()
+        coords = mesh.coords[self.verts].contiguous()
+        lo = mesh.coords.min(dim=0).values
+        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
+        lo3, sp3 = (C.c_double * 3)(0.0, 0.0, 0.0), (C.c_double * 3)(1.0, 1.0, 1.0)
+        for k in range(mesh.gdim):
+            lo3[k], sp3[k] = float(lo[k]), float(span[k])
         out = C.c_void_p()
-        _lib.check(lib.ox_space_create(self.nmesh.handle.ptr, int(degree), int(window), C.byref(out)), "ox_space_create")
+        nc = int(cells32.shape[0])
+        _lib.check(lib.ox_mesh_create_sub(_lib.ptr(coords), int(self.verts.shape[0]), _lib.ptr(cells32), nc, mesh.gdim, 1,
+                                          lo3, sp3, int(mesh_is_lattice(mesh)), int(default_tile_bits(mesh)),
+                                          mesh.num_cells, C.byref(out)), "ox_mesh_create_sub")
+        self.handle = _Handle(out, lib.ox_mesh_destroy)
+        v = _lib.ox_mesh_info()
+        _lib.check(lib.ox_mesh_view(out, C.byref(v)), "ox_mesh_view")
+        self.info = v
+        gs = 6 if mesh.gdim == 2 else 10
+        self.cell_perm = dev_tensor(v.cell_perm, (nc,), torch.int32, self.handle, dev)
+        self.geom = dev_tensor(v.cells_struct.geom, (nc, gs), torch.float64, self.handle, dev)
+        self.tile_bits = int(v.tile_bits)
+
+    @staticmethod
+    def of(mesh, part):
+        nm = getattr(part, "_native_sub", None)
+        if nm is None:
+            nm = part._native_sub = NativeSubMesh(mesh, part)
+        return nm
+
+
+class NativeSpace:
+    def __init__(self, mesh, degree: int, window: int, part=None, owner=None, n_dofs_whole: int = 0):
+        lib = _lib.load()
+        out = C.c_void_p()
+        if part is not None:  # one rank's piece of a mesh-partitioned space
+            self.nmesh = NativeSubMesh.of(mesh, part)
+            _lib.check(lib.ox_space_create_part(self.nmesh.handle.ptr, int(degree), int(window), _lib.ptr(owner),
+                                                int(owner.shape[0]), int(part.rank), int(n_dofs_whole), C.byref(out)),
+                       "ox_space_create_part")
+        else:
+            self.nmesh = NativeMesh.of(mesh)
+            _lib.check(lib.ox_space_create(self.nmesh.handle.ptr, int(degree), int(window), C.byref(out)), "ox_space_create")
         self.handle = _Handle(out, lib.ox_space_destroy)
         self.handle._mesh = self.nmesh  # the space reads the mesh object: keep it alive
         v = _lib.ox_space_info()

@@ -37,6 +37,8 @@ class Comm:
     """Rank/size plus (on GPUs) the RCCL communicator handle used by liboasisx_hip.so and the
     transport policy (see the module docstring)."""
 
+    collective = True  # allreduce() really spans the job's ranks (stand-in communicators of tests do not say so)
+
     def __init__(self, rank=0, size=1, handle=None, transport=None):
         import os
 
@@ -377,16 +379,31 @@ def recursive_coordinate_bisection(cen: torch.Tensor, nparts: int) -> torch.Tens
 
 
 class MeshPartition:
-    """Replicated partition metadata of a (global) mesh for one rank."""
+    """Partition metadata of a (global) mesh for one rank.
 
-    def __init__(self, mesh: Mesh, rank: int, nparts: int):
+    Global (cheap, one pass over the cells): the cell -> rank map (recursive coordinate bisection: every rank
+    derives the same map by deterministic stable sorts) and the vertex owners (lowest rank among the cells of a
+    vertex).  Everything else is computed on this rank's WINDOW only -- its own cells plus two rings of
+    vertex-neighbours: the edges (P2 dofs), their owners, the rank's local cells (those that touch an owned
+    dof: own cells + one ghost layer) and, for the halo plan, the cells it shares with each peer.  Two rings
+    are what exact owners need: a dof of a local cell lives in cells that share a vertex with that cell, and a
+    local cell shares a vertex with an own cell.  (Rounds 1-2 enumerated the edges of the WHOLE mesh on every
+    rank: 46 GiB and 2.9 s per rank at 256^3 x 8, not shrinking with the number of ranks.)
+
+    Dof ids used between ranks ("global initial ids"): a vertex is its vertex id, an edge is ``num_vertices`` +
+    its position among this window's sorted edge keys (min_vertex * num_vertices + max_vertex).  Positions
+    differ from rank to rank, their ORDER does not -- and the halo plan only needs both sides to list the
+    shared dofs in the same order (vertices by id, then edges by key)."""
+
+    def __init__(self, mesh: Mesh, rank: int, nparts: int, comm=None):
         self.mesh, self.rank, self.nparts = mesh, int(rank), int(nparts)
+        self.comm = comm if comm is not None else getattr(mesh, "comm", None)
         dev = mesh.device
         d = mesh.gdim
         cells = mesh.cells
         nc, nverts = mesh.num_cells, mesh.num_vertices
         # ---- cells -> parts: recursive coordinate bisection of the centroids (OX_PARTITION=slabs: the
-        #      r01 z-slabs) -- replicated and deterministic: every rank computes the same map ------------
+        #      r01 z-slabs) -- deterministic: every rank computes the same map ----------------------------
         import os
 
         cen = mesh.coords[cells].mean(dim=1)
@@ -394,33 +411,97 @@ class MeshPartition:
             cell_rank = slab_partition(cen, mesh.coords, nparts)
         else:
             cell_rank = recursive_coordinate_bisection(cen, nparts)
+        del cen
         self.cell_rank = cell_rank
-        # ---- edges (global ids) -------------------------------------------------------------
-        ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)
-        eb = torch.tensor([e[1] for e in local_edges(d)], device=dev)
-        a, b = cells[:, ea], cells[:, eb]
-        ekey = torch.minimum(a, b) * nverts + torch.maximum(a, b)
-        self.edge_keys, inv = torch.unique(ekey.reshape(-1), return_inverse=True)
-        self.cell_edges = inv.reshape(nc, -1)
-        del a, b, ekey, inv
-        # ---- owners: lowest rank among the cells that contain the entity ------------------------
+        # ---- vertex owners: lowest rank among the cells that contain the vertex (global) -----------------
         big = torch.full((nverts,), nparts, dtype=torch.int64, device=dev)
         self.vown = big.scatter_reduce(0, cells.reshape(-1), cell_rank.repeat_interleave(d + 1), reduce="amin")
-        ne = cells.shape[1] * (cells.shape[1] - 1) // 2
+        del big
+        # ---- this rank's window: own cells + two rings of vertex-neighbours ------------------------------
+        vm = torch.zeros(nverts, dtype=torch.bool, device=dev)
+        vm[cells[cell_rank == self.rank].reshape(-1)] = True
+        ring1 = vm[cells].any(dim=1)
+        vm.zero_()
+        vm[cells[ring1].reshape(-1)] = True
+        self.win_cells = torch.nonzero(vm[cells].any(dim=1)).reshape(-1)  # ascending global cell ids
+        del vm, ring1
+        wc = cells[self.win_cells]
+        wrank = cell_rank[self.win_cells]
+        # ---- edges of the window, their owners ------------------------------------------------------
+        ea = torch.tensor([e[0] for e in local_edges(d)], device=dev)
+        eb = torch.tensor([e[1] for e in local_edges(d)], device=dev)
+        a, b = wc[:, ea], wc[:, eb]
+        ekey = torch.minimum(a, b) * nverts + torch.maximum(a, b)
+        self.edge_keys, inv = torch.unique(ekey.reshape(-1), return_inverse=True)
+        self._win_cell_edges = inv.reshape(wc.shape[0], -1)
+        del a, b, ekey, inv
+        ne = self._win_cell_edges.shape[1]
         bige = torch.full((int(self.edge_keys.shape[0]),), nparts, dtype=torch.int64, device=dev)
-        self.eown = bige.scatter_reduce(0, self.cell_edges.reshape(-1), cell_rank.repeat_interleave(ne),
-                                        reduce="amin")
+        # exact for every edge of a cell within one ring of an own cell (all its cells are in the window);
+        # an edge of the outer ring only can come out too HIGH, never as this rank, and is not a local dof
+        self.eown = bige.scatter_reduce(0, self._win_cell_edges.reshape(-1), wrank.repeat_interleave(ne), reduce="amin")
+        del bige
         self._own2 = None
-        self.local_cells = torch.nonzero(self.cell_mask(self.rank)).reshape(-1)
+        # ---- local cells: those that touch a vertex or an edge this rank owns -----------------------------
+        self._win_local = (self.vown[wc] == self.rank).any(dim=1) | (self.eown[self._win_cell_edges] == self.rank).any(dim=1)
+        self.local_cells = self.win_cells[self._win_local]
+        self._n_edges_global = None
+
+    # -- window look-ups ---------------------------------------------------------------------------------
+    def _win_pos(self, cell_ids: torch.Tensor) -> torch.Tensor:
+        pos = torch.searchsorted(self.win_cells, cell_ids)
+        assert bool((self.win_cells[pos.clamp_max(self.win_cells.shape[0] - 1)] == cell_ids).all()), \
+            "cell outside this rank's window"
+        return pos
+
+    def cell_edges_of(self, cell_ids: torch.Tensor) -> torch.Tensor:
+        """Window edge indices (into ``edge_keys``) of the edges of the given (global) cells of the window."""
+        return self._win_cell_edges[self._win_pos(cell_ids)]
 
     def owner0(self, degree: int) -> torch.Tensor:
-        """Owner rank of every global initial dof (vertices, then edges for degree 2)."""
+        """Owner rank of every initial dof id of this rank's window (vertices, then window edges for degree 2)."""
         if degree == 1:
             return self.vown
         if self._own2 is None:
             self._own2 = torch.cat([self.vown, self.eown])
         return self._own2
 
-    def cell_mask(self, q: int) -> torch.Tensor:
-        """Cells rank ``q`` keeps: those touching a vertex or an edge it owns."""
-        return (self.vown[self.mesh.cells] == q).any(dim=1) | (self.eown[self.cell_edges] == q).any(dim=1)
+    def cells_shared_with(self, q: int) -> torch.Tensor:
+        """This rank's local cells (global ids) that also touch a dof owned by rank ``q``: exactly the cells both
+        ranks keep, i.e. where ``q``'s ghosts owned by this rank live."""
+        wc = self.mesh.cells[self.win_cells]
+        m = self._win_local & ((self.vown[wc] == q).any(dim=1) | (self.eown[self._win_cell_edges] == q).any(dim=1))
+        return self.win_cells[m]
+
+    def peers(self):
+        """Ranks this rank shares a cell with."""
+        wc = self.mesh.cells[self.local_cells]
+        own = torch.cat([self.vown[wc].reshape(-1), self.eown[self.cell_edges_of(self.local_cells)].reshape(-1)])
+        return [int(q) for q in torch.unique(own).tolist() if int(q) != self.rank and int(q) < self.nparts]
+
+    def n_edges_global(self) -> int:
+        """Edges of the whole mesh: every edge has exactly one owner, so the owned counts add up (one scalar
+        all-reduce); without a communicator (single-process tools and tests) they are counted directly."""
+        if self._n_edges_global is None:
+            mine = int((self.eown == self.rank).sum().item())
+            comm = self.comm
+            if comm is not None and getattr(comm, "size", 1) == self.nparts and getattr(comm, "collective", False):
+                self._n_edges_global = int(round(comm.allreduce(float(mine))))
+            else:
+                mesh, d = self.mesh, self.mesh.gdim
+                nverts = mesh.num_vertices
+                ea = torch.tensor([e[0] for e in local_edges(d)], device=mesh.device)
+                eb = torch.tensor([e[1] for e in local_edges(d)], device=mesh.device)
+                total, step = 0, 1 << 24
+                seen = None
+                for c0 in range(0, mesh.num_cells, step):  # chunked: a global unique in one piece is what this class avoids
+                    cc = mesh.cells[c0:c0 + step]
+                    a, b = cc[:, ea], cc[:, eb]
+                    k = torch.unique((torch.minimum(a, b) * nverts + torch.maximum(a, b)).reshape(-1))
+                    seen = k if seen is None else torch.unique(torch.cat([seen, k]))
+                total = 0 if seen is None else int(seen.shape[0])
+                self._n_edges_global = total
+        return self._n_edges_global
+
+    def num_dofs_global(self, degree: int) -> int:
+        return self.mesh.num_vertices + (self.n_edges_global() if degree == 2 else 0)

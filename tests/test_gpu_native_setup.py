@@ -152,3 +152,73 @@ def test_value_dictionary_against_torch_unique(hip):
     _lib.check(lib.ox_value_dictionary(_lib.ptr(many), 5000, 1, _lib.ptr(torch.zeros(5000, dtype=torch.uint8, device="cuda")),
                                        _lib.ptr(torch.zeros(256, dtype=torch.float64, device="cuda")), C.byref(nd), None), "dict")
     assert nd.value == 0  # more than 256 distinct values: declined
+
+
+@pytest.mark.parametrize("kind,N,deg,window,world", [("box", 6, 2, 128, 3), ("box", 7, 1, 64, 2), ("rect", 14, 2, 64, 4),
+                                                      ("jitter", 6, 2, 256, 3)])
+def test_native_partitioned_space_matches_the_torch_twin_element_by_element(hip, kind, N, deg, window, world):
+    """One rank's piece of a mesh-partitioned space (reference fracstep.py:186-216 on a distributed mesh) built
+    inside the library (ox_mesh_create_sub / ox_space_create_part, from the rank's cells and the owner of each of
+    their dofs) against the torch implementation of the same specification: owned dofs first (tile order, window
+    sort), ghosts by (owner, initial id), rows = owned dofs only.  Every array must agree, for every rank --
+    numbering, coordinates, cell order, SELL pattern, adjacency with its position bytes, and the halo plan."""
+    from oasisx_amd import fem
+    from oasisx_amd.parallel import MeshPartition
+
+    mesh = _mesh(kind, N)
+    if mesh.device.type != "cuda":
+        from oasisx_amd import mesh as M
+
+        mesh = M.from_arrays(mesh.coords.numpy(), mesh.cells.numpy())
+    for rank in range(world):
+        part = MeshPartition(mesh, rank, world)
+        os.environ["OX_SETUP"] = "torch"
+        try:
+            Vt = fem.FunctionSpace(mesh, deg, window=window, part=part)
+        finally:
+            os.environ.pop("OX_SETUP")
+        Vn = fem.FunctionSpace(mesh, deg, window=window, part=part)
+        assert Vt.native is None and Vn.native is not None
+        assert (Vn.n_owned, Vn.n_local, Vn.num_dofs_global) == (Vt.n_owned, Vt.n_local, Vt.num_dofs_global)
+        assert 0 < Vn.n_owned < Vn.n_local <= Vn.num_dofs_global
+        assert torch.equal(Vn.local_cells, Vt.local_cells)
+        assert torch.equal(Vn._gl, Vt._gl)
+        hn, ht = Vn.halo, Vt.halo
+        assert (hn["peers"] == ht["peers"]).all() and (hn["send_off"] == ht["send_off"]).all()
+        assert (hn["recv_off"] == ht["recv_off"]).all()
+        no = Vn.n_owned
+        # the ghosts do not depend on the spatial keys: (owner, initial id) order, identical
+        assert torch.equal(Vn.x[no:], Vt.x[no:])
+        Pn, Pt = Vn.pattern, Vt.pattern
+        assert (Pn.n_rows, Pn.n_cols, Pn.nnz) == (Pt.n_rows, Pt.n_cols, Pt.nnz) == (no, Vn.n_local, Pt.nnz)
+        ones_n = Pn.to_csr(torch.ones(Pn.size, dtype=torch.float64, device="cuda"))
+        ones_t = Pt.to_csr(torch.ones(Pt.size, dtype=torch.float64, device="cuda"))
+        if not torch.equal(Vn._rank_initial.to(torch.int64), Vt._rank_initial.to(torch.int64)):
+            # a non-lattice mesh (Z-order keys): the two implementations round a key differently here and there
+            # ((x - lo) / span * c against (x - lo) * (c / span)), so owned dofs may swap places.  Same space
+            # through the dof coordinates: the same operator pattern and the same dofs sent to every peer.
+            assert kind == "jitter"
+
+            def key(xx):
+                return [tuple(np.round(r * 1e9).astype(np.int64)) for r in xx]
+            kt = {k: i for i, k in enumerate(key(Vt.x.cpu().numpy()))}
+            perm = np.array([kt[k] for k in key(Vn.x.cpu().numpy())])  # torch index of native dof i
+            assert (np.sort(perm[:no]) == np.arange(no)).all() and (perm[no:] == np.arange(no, Vn.n_local)).all()
+            assert abs(ones_n - ones_t[perm[:no]][:, perm]).max() == 0
+            sn, st_ = hn["send_idx"].cpu().numpy(), ht["send_idx"].cpu().numpy()
+            assert (perm[sn] == st_).all()
+            continue
+        assert torch.equal(Vn.cell_dofs, Vt.cell_dofs) and torch.equal(Vn.x, Vt.x)
+        assert Pn.size == Pt.size
+        assert torch.equal(Pn.slice_ptr, Pt.slice_ptr) and torch.equal(Pn.row_len.to(torch.int64), Pt.row_len.to(torch.int64))
+        # columns of the real entries (the padding of rows that only pad the last slice is a convention)
+        assert abs(ones_n - ones_t).max() == 0
+        sp = Pn.slice_ptr.cpu().numpy()
+        assert torch.equal(Pn.cols[: sp[no // 64]], Pt.cols[: sp[no // 64]])  # whole slices of owned rows: slot for slot
+        assert torch.equal(Vn.adj.adj_ptr, Vt.adj.adj_ptr)
+        real = Vt.adj.adj_cell >= 0
+        assert torch.equal(Vn.adj.adj_cell >= 0, real)
+        assert torch.equal(Vn.adj.adj_cell[real], Vt.adj.adj_cell[real])
+        assert torch.equal(Vn.adj.adj_loc[real], Vt.adj.adj_loc[real])
+        assert torch.equal(Vn.adj.adj_pos[real][:, : Vn.nd], Vt.adj.adj_pos[real][:, : Vn.nd])
+        assert torch.equal(hn["send_idx"], ht["send_idx"])
