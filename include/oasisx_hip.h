@@ -391,6 +391,16 @@ int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const d
  * Environment: OX_KSP_FOLD=0|1|2 (read at the first solve). */
 int ox_set_ksp_fold(int on);
 
+/* ---- Projector into a discontinuous P1 space (reference function.py:13-143 with the "DG" 1 target of its
+ *      test_projector.py:26-35).  Dof (cell e, vertex a, component c) at (e * (gdim+1) + a) * ncomp + c, cells in
+ *      the order of `cells`.  The mass matrix is block diagonal: its inverse is applied cell by cell in closed
+ *      form (the reference asks PETSc for preonly + LU).
+ *      ox_dg1_grad_rhs: b = assemble_vector(inner(grad(u), v) * dx), u a Lagrange P1 / P2 field (function.py:74-77,
+ *      :110-119), ncomp = gdim;  ox_dg1_mass: out = M^-1 in (inverse != 0: KSP.solve, function.py:132) or M in. */
+int ox_dg1_grad_rhs(int u_degree, const ox_cells *cells, const int32_t *cell_dofs, const double *u, double *b,
+                    void *stream);
+int ox_dg1_mass(int inverse, const ox_cells *cells, int ncomp, const double *in, double *out, void *stream);
+
 /* ---- V3 + A10: nullspace.remove and mean shift (fracstep.py:573-574, 579-591) -------- */
 /* m = (sum_{i<n} w[i]*x[i], all ranks) / wsum;  x[i] -= m for i < n_apply (owned + ghost rows);
  * w == NULL -> plain sum (arithmetic mean when wsum = global n). */

@@ -182,6 +182,8 @@ SIGNATURES = {
                                      _P, _D, _P, _P]),
     "ox_assemble_div_vector": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P, _D,
                                     _P, _P]),
+    "ox_dg1_grad_rhs": (_I, [_I, C.POINTER(ox_cells), _P, _P, _P, _P]),
+    "ox_dg1_mass": (_I, [_I, C.POINTER(ox_cells), _I, _P, _P, _P]),
     "ox_jacobi_setup": (_I, [C.POINTER(ox_sell), _P, _P]),
     "ox_ksp_work_bytes": (C.c_size_t, [_L, _L, _I, _I]),
     "ox_ksp_solve": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,

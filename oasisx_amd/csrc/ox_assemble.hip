@@ -593,6 +593,115 @@ extern "C" int ox_assemble_weights(int degree, const ox_cells *cells, const ox_a
   OX_FAIL("ox_assemble_weights: unsupported gdim=%d degree=%d", g, degree);
 }
 
+// ---------------------------------------------------------------------------------------
+// Projection into the discontinuous P1 space (reference function.py:13-143 with a "DG" 1 target, as its
+// test_projector.py builds: basix.ufl.element("DG", cell, 1, shape=(gdim,))).  Dof (cell e, vertex a,
+// component c) at (e * (gdim+1) + a) * ncomp + c.  No coupling between cells: the mass matrix is block
+// diagonal with the blocks |K| (I + 11^T) / ((d+1)(d+2)), whose inverse is closed form -- the "LU" the
+// reference asks PETSc for.  One thread per cell.
+//   k_dg1_grad_rhs   b[(e,a)][c] = int_e d_c(u) lambda_a   (the form inner(grad(u), v) * dx; u Lagrange P1 / P2)
+//   k_dg1_mass       x = M^-1 b   (INV)   or   b = M x
+// ---------------------------------------------------------------------------------------
+template <int GDIM, int DEG>
+__global__ __launch_bounds__(256) void k_dg1_grad_rhs(ox_cells cells, const int32_t *__restrict__ cell_dofs,
+                                                      const double *__restrict__ u, double *__restrict__ b) {
+  using E = Elem<GDIM, DEG>;
+  using E1 = Elem<GDIM, 1>;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cells.n_cells) return;
+  double G[GDIM + 1][GDIM], adet;
+  load_geom<GDIM>(cells.geom + (size_t)e * E::GS, G, adet);
+  double uc[E::ND];
+#pragma unroll
+  for (int k = 0; k < E::ND; ++k) uc[k] = u[cell_dofs[(size_t)e * E::ND + k]];
+  double acc[GDIM + 1][GDIM];
+#pragma unroll
+  for (int a = 0; a <= GDIM; ++a)
+#pragma unroll
+    for (int d = 0; d < GDIM; ++d) acc[a][d] = 0.0;
+#pragma unroll
+  for (int q = 0; q < E::NQ; ++q) {
+    double gl[GDIM + 1];  // du/d(lambda_b) at the point
+#pragma unroll
+    for (int bb = 0; bb <= GDIM; ++bb) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < E::ND; ++k) v = fma(E::dphi(q, k, bb), uc[k], v);
+      gl[bb] = v;
+    }
+#pragma unroll
+    for (int d = 0; d < GDIM; ++d) {
+      double g = 0.0;
+#pragma unroll
+      for (int bb = 0; bb <= GDIM; ++bb) g = fma(gl[bb], G[bb][d], g);
+#pragma unroll
+      for (int a = 0; a <= GDIM; ++a) acc[a][d] = fma(E::w(q) * E1::phi(q, a), g, acc[a][d]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a <= GDIM; ++a)
+#pragma unroll
+    for (int d = 0; d < GDIM; ++d) b[((size_t)e * (GDIM + 1) + a) * GDIM + d] = adet * acc[a][d];
+}
+
+template <int GDIM, bool INV>
+__global__ __launch_bounds__(256) void k_dg1_mass(ox_cells cells, int ncomp, const double *__restrict__ in,
+                                                  double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cells.n_cells) return;
+  constexpr int GS = GDIM == 2 ? 6 : 10, NV = GDIM + 1;
+  constexpr double fact = GDIM == 2 ? 2.0 : 6.0;
+  const double alpha = cells.geom[(size_t)e * GS + GDIM * GDIM] / fact / (double)((GDIM + 1) * (GDIM + 2));  // |K| / ((d+1)(d+2))
+  for (int c = 0; c < ncomp; ++c) {
+    double v[NV], s = 0.0;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      v[a] = in[((size_t)e * NV + a) * ncomp + c];
+      s += v[a];
+    }
+#pragma unroll
+    for (int a = 0; a < NV; ++a)
+      out[((size_t)e * NV + a) * ncomp + c] = INV ? (v[a] - s / (double)(GDIM + 2)) / alpha : alpha * (v[a] + s);
+  }
+}
+
+extern "C" int ox_dg1_grad_rhs(int u_degree, const ox_cells *cells, const int32_t *cell_dofs, const double *u, double *b,
+                               void *stream) {
+  if (!cells || !cell_dofs || !u || !b) OX_FAIL("ox_dg1_grad_rhs: null argument");
+  if (cells->n_cells <= 0) return 0;
+  const dim3 grid((unsigned)((cells->n_cells + 255) / 256));
+  hipStream_t st = ox_stream(stream);
+  const int g = cells->gdim;
+#define OX_DG_CASE(GD, DG)                                                                           \
+  if (g == GD && u_degree == DG) {                                                                   \
+    hipLaunchKernelGGL((k_dg1_grad_rhs<GD, DG>), grid, dim3(256), 0, st, *cells, cell_dofs, u, b);    \
+    OX_LAUNCH_CHECK();                                                                               \
+    return 0;                                                                                        \
+  }
+  OX_DG_CASE(2, 1) OX_DG_CASE(2, 2) OX_DG_CASE(3, 1) OX_DG_CASE(3, 2)
+#undef OX_DG_CASE
+  OX_FAIL("ox_dg1_grad_rhs: unsupported gdim=%d degree=%d", g, u_degree);
+}
+
+extern "C" int ox_dg1_mass(int inverse, const ox_cells *cells, int ncomp, const double *in, double *out, void *stream) {
+  if (!cells || !in || !out) OX_FAIL("ox_dg1_mass: null argument");
+  if (ncomp < 1) OX_FAIL("ox_dg1_mass: ncomp=%d", ncomp);
+  if (cells->n_cells <= 0) return 0;
+  const dim3 grid((unsigned)((cells->n_cells + 255) / 256));
+  hipStream_t st = ox_stream(stream);
+  if (cells->gdim == 2) {
+    if (inverse) hipLaunchKernelGGL((k_dg1_mass<2, true>), grid, dim3(256), 0, st, *cells, ncomp, in, out);
+    else hipLaunchKernelGGL((k_dg1_mass<2, false>), grid, dim3(256), 0, st, *cells, ncomp, in, out);
+  } else if (cells->gdim == 3) {
+    if (inverse) hipLaunchKernelGGL((k_dg1_mass<3, true>), grid, dim3(256), 0, st, *cells, ncomp, in, out);
+    else hipLaunchKernelGGL((k_dg1_mass<3, false>), grid, dim3(256), 0, st, *cells, ncomp, in, out);
+  } else {
+    OX_FAIL("ox_dg1_mass: gdim=%d", cells->gdim);
+  }
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+
 // kind 0: out[r][d] = base[r][d] + scale * int p * d_d(phi_r)       (A6, fracstep.py:487-497)
 // kind 1: out[r][d] = base[r][d] + scale * int d_d(p) * phi_r       (A8, fracstep.py:618)
 template <int GDIM, int RDEG, int PDEG, int KIND>

@@ -869,6 +869,46 @@ def functionspace(mesh: Mesh, element, **kwargs):
     return V
 
 
+class DGSpace:
+    """Discontinuous Lagrange space of degree 1, scalar or vector valued -- what
+    ``basix.ufl.element("DG", cell, 1, shape=(k,))`` gives the reference's ``test_projector.py:26-27``.
+    Dof (cell e, vertex a) at index e * (gdim+1) + a, ``dim`` components interleaved; cells in the kernel cell
+    order of the mesh (the order every continuous space on it uses: ``local_cells``)."""
+
+    is_dg = True
+
+    def __init__(self, mesh: Mesh, degree: int = 1, shape=None):
+        if degree != 1:
+            raise NotImplementedError("DGSpace: degree 1")
+        self.mesh, self.degree = mesh, 1
+        self.dim = int(shape[0]) if shape else 1
+        self.num_sub_spaces = self.dim if shape else 0
+        dev = mesh.device
+        if dev.type == "cuda" and _os.environ.get("OX_SETUP", "native") != "torch":
+            from . import native as N
+
+            nm = N.NativeMesh.of(mesh)
+            self.local_cells, self.geom, self._owner = nm.cell_perm.to(torch.int64), nm.geom, nm
+        else:
+            lo = mesh.coords.min(dim=0).values
+            span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
+            tb = default_tile_bits(mesh)
+            ckey = locality_key(mesh.coords[mesh.cells].mean(dim=1), lo, span, tb,
+                                default_key_bits(mesh.num_cells, mesh.gdim, tb), not mesh_is_lattice(mesh))
+            self.local_cells = torch.argsort(ckey, stable=True)
+            self.geom = cell_geometry(mesh, self.local_cells)
+        self.nd = mesh.gdim + 1
+        self.num_dofs = self.n_local = self.n_owned = int(self.local_cells.shape[0]) * self.nd
+        self.element = type("Element", (), {"degree": 1, "family": "DG"})()
+
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        """(num_dofs, 3): the vertices of every cell, cell by cell."""
+        x = self.mesh.coords[self.mesh.cells[self.local_cells]].reshape(-1, self.mesh.gdim).cpu().numpy()
+        out = np.zeros((x.shape[0], 3))
+        out[:, : self.mesh.gdim] = x
+        return out
+
+
 class VectorFunctionSpace:
     """Blocked space (bs = dim) over a scalar space: dof (i, c) at index i*dim + c."""
 
@@ -990,7 +1030,7 @@ class Function:
         self.function_space = V
         self.name = name
         if storage is None:
-            if isinstance(V, VectorFunctionSpace):
+            if isinstance(V, VectorFunctionSpace) or (getattr(V, "is_dg", False) and V.dim > 1):
                 storage, comp = FieldStorage(V.num_dofs, V.dim, V.mesh.device), None
             else:
                 storage, comp = FieldStorage(V.num_dofs, 1, V.mesh.device), 0

@@ -20,15 +20,29 @@ from . import _lib
 import numpy as np
 import torch
 
-from .fem import SLICE, FieldStorage, Function, FunctionSpace, _simplex_rule, cell_geometry, local_edges
+from .fem import SLICE, DGSpace, FieldStorage, Function, FunctionSpace, _simplex_rule, cell_geometry, local_edges
 from .ksp import KSPSolver
 from .la import SellMatrix
 
-__all__ = ["Projector", "LumpedProject"]
+__all__ = ["Projector", "LumpedProject", "grad"]
+
+
+class Grad:
+    """``ufl.grad(u)`` of a Lagrange field: the one expression of a field the reference's own projector test
+    projects (test_projector.py:33)."""
+
+    def __init__(self, u: Function):
+        if not isinstance(u, Function) or not isinstance(u.function_space, FunctionSpace):
+            raise TypeError("grad: a Function on a Lagrange space")
+        self.u = u
+
+
+def grad(u: Function) -> Grad:
+    return Grad(u)
 
 
 class Projector:
-    def __init__(self, function, space: FunctionSpace, bcs=None, petsc_options=None, jit_options=None,
+    def __init__(self, function, space, bcs=None, petsc_options=None, jit_options=None,
                  form_compiler_options=None, metadata=None):
         if bcs:
             raise NotImplementedError("Projector: Dirichlet conditions on the projection are not supported")
@@ -37,6 +51,28 @@ class Projector:
         self._space = space
         self._metadata = metadata or {}
         mesh = space.mesh
+        self._dg = isinstance(space, DGSpace)
+        if self._dg:
+            # Discontinuous P1 target (test_projector.py:26-35): the mass matrix is block diagonal, one
+            # (gdim+1) x (gdim+1) block per cell and component; its inverse is applied cell by cell in closed
+            # form by ox_dg1_mass -- the direct solve the reference asks PETSc for (preonly + lu), whatever
+            # Krylov options are passed.
+            self._geom = space.geom
+            self._cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
+            self._A = None
+            dev = mesh.device
+            self._B = FieldStorage(space.num_dofs, space.dim, dev)
+            self._X = FieldStorage(space.num_dofs, space.dim, dev)
+            self._b = Function(space, "b", self._B, None if space.dim > 1 else 0)
+            self._x = Function(space, "x", self._X, None if space.dim > 1 else 0)
+            self._ksp = KSPSolver(mesh.comm, petsc_options, prefix="oasis_projector")
+            if isinstance(function, Grad):
+                Vu = function.u.function_space
+                if Vu.mesh is not mesh or space.dim != mesh.gdim:
+                    raise ValueError("Projector(grad(u), W): W must be the gdim-vector DG1 space on u's mesh")
+                if not torch.equal(Vu.local_cells, space.local_cells):
+                    raise ValueError("Projector(grad(u), W): the two spaces do not share the kernel cell order")
+            return
         self._geom = cell_geometry(mesh, space.local_cells)
         cells = _lib.ox_cells(mesh.gdim, 0, int(self._geom.shape[0]), self._geom.data_ptr())
         # the mass matrix, assembled once (function.py:62-71)
@@ -58,6 +94,21 @@ class Projector:
     def assemble_rhs(self):
         """Update the RHS by re-assembling (function.py:110-119)."""
         f = self._function
+        if self._dg:
+            lib, st = _lib.load(), _lib.current_stream()
+            if isinstance(f, Grad):  # assemble_vector(inner(grad(u), v) * dx)
+                Vu = f.u.function_space
+                _lib.check(lib.ox_dg1_grad_rhs(Vu.degree, C.byref(self._cells), _lib.ptr(Vu.cell_dofs),
+                                               C.c_void_p(f.u._storage.dev().data_ptr() if f.u._storage.nc == 1 else
+                                                          f.u._storage.dev()[:, f.u._comp].contiguous().data_ptr()),
+                                               self._B.ptr(), st), "ox_dg1_grad_rhs")
+            elif isinstance(f, Function) and f.function_space is self._space:  # b = M f
+                _lib.check(lib.ox_dg1_mass(0, C.byref(self._cells), self._space.dim, f._storage.ptr(), self._B.ptr(), st),
+                           "ox_dg1_mass")
+            else:
+                raise TypeError("Projector into a DG space: `function` must be grad(u) of a Lagrange field or a "
+                                "Function on the space")
+            return
         if isinstance(f, Function):
             self._A.mult(f._storage.dev(), self._B.dev(), 1)
         elif hasattr(f, "assemble_rhs_into"):
@@ -73,6 +124,11 @@ class Projector:
         """Compute the projection; returns the KSP converged reason (function.py:121-135)."""
         if assemble_rhs:
             self.assemble_rhs()
+        if self._dg:  # block-diagonal mass matrix: the cell-wise inverse IS the solve
+            _lib.check(_lib.load().ox_dg1_mass(1, C.byref(self._cells), self._space.dim, self._B.ptr(), self._X.ptr(),
+                                               _lib.current_stream()), "ox_dg1_mass")
+            direct = str(self._ksp._options.get("ksp_type", "")).lower() == "preonly"
+            return _lib.CONVERGED_ITS if direct else _lib.CONVERGED_RTOL
         return self._ksp.solve_block(self._B, self._X)[0]
 
     @property
