@@ -724,6 +724,8 @@ class FunctionSpace:
         """Local dofs on the closure of mesh entities (vertices + edges for P2)."""
         mesh = self.mesh
         dev = mesh.device
+        if len(entities) == 0:  # (test_bcs.py's dim = 2 case: no cell lies in the marked line)
+            return np.zeros(0, dtype=np.int32)
         ev, _ = mesh._entities(dim)
         verts = ev[np.asarray(entities, dtype=np.int64)].reshape(len(entities), -1)
         gids = [torch.from_numpy(verts.ravel().astype(np.int64)).to(dev)]
@@ -861,8 +863,14 @@ def functionspace(mesh: Mesh, element, **kwargs):
     if isinstance(element, FunctionSpace):
         return element
     family, degree = element[0], int(element[1])
+    if str(family).lower() in ("dg", "discontinuous lagrange", "dp"):
+        return DGSpace(mesh, degree, shape=element[2] if len(element) > 2 else None)
     if str(family).lower() not in ("lagrange", "p", "cg"):
         raise ValueError(f"unsupported element family {family!r}")
+    if degree > 2:  # boundary conditions and interpolation only: no operators are assembled on these
+        if len(element) > 2 and element[2]:
+            raise NotImplementedError("vector-valued Lagrange spaces of degree > 2")
+        return HighOrderLagrangeSpace(mesh, degree)
     V = FunctionSpace(mesh, degree, **kwargs)
     if len(element) > 2 and element[2]:
         return VectorFunctionSpace(V, int(element[2][0]))
@@ -907,6 +915,77 @@ class DGSpace:
         out = np.zeros((x.shape[0], 3))
         out[:, : self.mesh.gdim] = x
         return out
+
+
+class HighOrderLagrangeSpace:
+    """Scalar Lagrange space of degree >= 3 on a simplicial mesh, for what the reference's ``DirichletBC`` needs of
+    it (test/test_bcs.py:19-160 runs P1-P4): a dof numbering, dof coordinates, the dofs on the closure of mesh
+    entities, nodal interpolation and vectors.  No operator of the time step is assembled on it (the solver's
+    spaces are P1 / P2; ``FractionalStep_AB_CN`` says so).
+
+    Dofs are numbered entity by entity -- vertices, then the interior points of the edges, of the triangles and of
+    the tetrahedra -- with the points of an entity ordered by their barycentric multi-index relative to the entity's
+    vertices in ascending global id (orientation-independent).  Points are EQUISPACED; the reference asks Basix for
+    the ``gll_warped`` variant (fracstep.py:170,181), which moves the interior points from degree 3 on -- values
+    imposed by a ``DirichletBC`` are the boundary function at the space's own points either way."""
+
+    def __init__(self, mesh: Mesh, degree: int):
+        if degree < 3:
+            raise ValueError("HighOrderLagrangeSpace: degree >= 3 (use FunctionSpace for 1 and 2)")
+        self.mesh, self.degree = mesh, int(degree)
+        self.num_sub_spaces = 0
+        self.element = _Element(degree, mesh.gdim)
+        p, d = self.degree, mesh.gdim
+        xv = mesh.coords.cpu().numpy()
+        coords, self._first, self._multi = [], {}, {}
+        n = 0
+        for k in range(d + 1):
+            ev, _ = mesh._entities(k)  # (ne, k+1) sorted vertex ids
+            mi = [m for m in itertools.product(range(1, p), repeat=k + 1) if sum(m) == p] if k > 0 else [(p,)]
+            self._first[k], self._multi[k] = n, len(mi)
+            if not mi:
+                continue
+            w = np.asarray(mi, dtype=np.float64) / p  # (npts, k+1) barycentric weights
+            pts = np.einsum("pa,eak->epk", w, xv[ev])  # (ne, npts, d)
+            coords.append(pts.reshape(-1, d))
+            n += ev.shape[0] * len(mi)
+        self.num_dofs = self.n_local = self.n_owned = self.num_dofs_global = n
+        x = np.concatenate(coords, axis=0)
+        self.x = torch.from_numpy(x).to(mesh.device)
+        self._x3 = np.zeros((n, 3))
+        self._x3[:, :d] = x
+        self.dofmap = None
+
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        return self._x3
+
+    def entity_dofs(self, dim: int, entities) -> np.ndarray:
+        """Dofs on the closure of mesh entities: the entity's own interior points and those of all its
+        sub-entities (what ``locate_dofs_topological`` returns)."""
+        mesh = self.mesh
+        if len(entities) == 0:
+            return np.zeros(0, dtype=np.int32)
+        ev, _ = mesh._entities(dim)
+        verts = ev[np.asarray(entities, dtype=np.int64)].reshape(len(entities), -1)
+        out = []
+        nv = mesh.num_vertices
+        for k in range(dim + 1):
+            if self._multi[k] == 0:
+                continue
+            evk, _ = mesh._entities(k)
+            key_all = np.zeros(evk.shape[0], dtype=np.int64)
+            for c in range(k + 1):
+                key_all = key_all * np.int64(nv) + evk[:, c]
+            order = np.argsort(key_all)
+            for combo in itertools.combinations(range(verts.shape[1]), k + 1):
+                sub = np.sort(verts[:, list(combo)], axis=1)
+                key = np.zeros(sub.shape[0], dtype=np.int64)
+                for c in range(k + 1):
+                    key = key * np.int64(nv) + sub[:, c]
+                idx = order[np.searchsorted(key_all[order], key)]
+                base = self._first[k] + idx * self._multi[k]
+                out.append((base[:, None] + np.arange(self._multi[k])[None, :]).ravel())
+        return np.unique(np.concatenate(out)).astype(np.int32) if out else np.zeros(0, dtype=np.int32)
 
 
 class VectorFunctionSpace:

@@ -140,9 +140,11 @@ def test_dirichlet_bc_host_side():
     from oasisx_amd import DirichletBC, LocatorMethod
 
     m = M.create_unit_square(None, 5, 5, device="cpu")
-    for P in (1, 2):
-        V = fem.FunctionSpace(m, P, window=64)
+    for P in (1, 2, 3, 4):  # test_bcs.py:19 parametrises P = 1..4
+        V = fem.functionspace(m, ("Lagrange", P))
+        assert V.num_dofs == (5 * P + 1) ** 2
         X = V.tabulate_dof_coordinates()
+        assert len(np.unique(np.round(X[:, :2] * 1e9).astype(np.int64), axis=0)) == V.num_dofs
         clock = {"t": 0.1}
         f = lambda x: x[0] + 2 * x[1] ** 2 + clock["t"]  # noqa: E731
         bc = DirichletBC(f, LocatorMethod.GEOMETRICAL, lambda x: np.isclose(x[0], 0))
