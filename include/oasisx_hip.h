@@ -381,15 +381,6 @@ int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const d
 /* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
  * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
  * continue, at most that many times per component (used when a direct solver was asked for). */
-/* Test / tuning hook.  On one GPU the synchronisation points whose dot products come from a VECTOR kernel
- * (CG: r.z, z.z; BiCGStab: r.r, rhat.r; the init kernels) are ended by that kernel itself: its blocks publish
- * their sums as tagged write-through granules and OX_FOLD_R reducer blocks of the same launch sum them in a
- * fixed order and run the scalar recurrences (csrc/ox_ksp_dev.h) -- no one-block kernel in between.
- * on = 0 restores the separate kernels everywhere (what partitioned operators always use: the all-reduce sits
- * between the sums and the logic); same order of every sum: bit-identical iterates.  on = 2 folds the points
- * behind the SpMVs as well (measurement only: it lengthens the SpMV kernel by its reduction tail).
- * Environment: OX_KSP_FOLD=0|1|2 (read at the first solve). */
-int ox_set_ksp_fold(int on);
 
 /* ---- Projector into a discontinuous P1 space (reference function.py:13-143 with the "DG" 1 target of its
  *      test_projector.py:26-35).  Dof (cell e, vertex a, component c) at (e * (gdim+1) + a) * ncomp + c, cells in

@@ -192,7 +192,6 @@ SIGNATURES = {
                               C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
-    "ox_set_ksp_fold": (_I, [_I]),
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),

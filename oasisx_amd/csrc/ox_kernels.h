@@ -92,14 +92,13 @@ __device__ __forceinline__ void ox_block_sum_wide(double (&v)[OX_MAX_NV], int nv
   }
 }
 
-struct KspFold;  // ox_ksp_dev.h: the fused epilogue ends the synchronisation point itself (single GPU)
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
-                   hipStream_t st, const KspFold *fold = nullptr);
+                   hipStream_t st);
 // distributed mat-vec (halo exchange overlapped with the interior slices where the operator carries the
 // interior / boundary split) and the number of per-block partials its fused epilogue writes
 int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
-                 double *partial, const int *done, const ox_dist *dist, hipStream_t st, const KspFold *fold = nullptr);
+                 double *partial, const int *done, const ox_dist *dist, hipStream_t st);
 int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist);
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st);
 

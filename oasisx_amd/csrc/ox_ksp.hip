@@ -35,22 +35,85 @@ __device__ __forceinline__ void ksp_gather2(const double *__restrict__ partial, 
 }
 
 
+// (register arrays sized by the phase: ksp_ph_nv -- OX_MAX_NV-wide ones spill in this 1024-thread block)
+template <int NVT>
+__device__ __forceinline__ void ksp_gather_t(const double *__restrict__ partial, int nparts, int nv, double (&v)[NVT]) {
+  const int T = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) v[i] = 0.0;
+  int p = threadIdx.x;
+  for (; p + 3 * T < nparts; p += 4 * T) {
+    double t[4][NVT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NVT; ++i) t[u][i] = (i < nv) ? partial[(size_t)(p + u * T) * nv + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NVT; ++i) v[i] += t[u][i];
+  }
+  for (; p < nparts; p += T) {
+#pragma unroll
+    for (int i = 0; i < NVT; ++i)
+      if (i < nv) v[i] += partial[(size_t)p * nv + i];
+  }
+}
+template <int NVT>
+__device__ __forceinline__ void ksp_block_sum_t(double (&v)[NVT], int nv, double *lds /* [16 * NVT] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    if (i < nv) {
+      const double s = ox_wave_sum(v[i]);
+      if (lane == 0) lds[i * 16 + wave] = s;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+      if (i < nv) {
+        double s = lane < nw ? lds[i * 16 + lane] : 0.0;
+        s += __shfl_down(s, 8, 64);
+        s += __shfl_down(s, 4, 64);
+        s += __shfl_down(s, 2, 64);
+        s += __shfl_down(s, 1, 64);
+        v[i] = s;
+      }
+    }
+  }
+}
+
 template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
                                                                const double *__restrict__ partial,
                                                                int nparts, int nv, KspParams P, KspPart2 B) {
-  __shared__ double red[16 * OX_MAX_NV];
+  constexpr int NVT = ksp_ph_nv(PH) * OX_MAXC;
+  __shared__ double red[16 * NVT];
+  __shared__ double sums[NVT];
   __shared__ KspState sh;
   // state and partials are loaded in ONE memory round trip; the done flag is looked at afterwards
   // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
   ksp_state_load(&sh, S);
-  double v[OX_MAX_NV];
-  ksp_gather2(partial, nparts, nv, B, v);
+  double v[NVT];
+  ksp_gather_t<NVT>(partial, nparts, nv, v);
+  if (B.nv > 0) {  // second partial array of the point (single-reduction CG): its sums follow the first's
+    double w[NVT];
+    ksp_gather_t<NVT>(B.partial, B.nparts, B.nv, w);
+#pragma unroll
+    for (int i = 0; i < NVT; ++i)
+#pragma unroll
+      for (int j = 0; j < NVT; ++j)
+        if (j == i - nv && j < B.nv) v[i] = w[j];
+  }
   nv += B.nv;
-  ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
+  ksp_block_sum_t<NVT>(v, nv, red);  // contains a __syncthreads(): sh is complete after it
   if (!ksp_is_init(PH) && sh.done) return;  // uniform: nothing is stored
   if (threadIdx.x == 0) {
-    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) sums[i] = v[i];  // (the logic indexes the sums at run time: from LDS, not scratch)
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, sums, c, P);
     ksp_finish(&sh, P.nc_total);
   }
   __syncthreads();
@@ -115,18 +178,17 @@ __global__ __launch_bounds__(64) void k_ksp_logic(KspState *S, const double *__r
 
 // ------------------------------- vector kernels ------------------------------------------
 // thread = row, NC interleaved components per row (24-B contiguous per lane for NC = 3).
-// (nwb_: work blocks of the launch -- a folded producer's grid carries OX_FOLD_R reducer blocks more)
-#define OX_ROW_LOOP_N(nwb_)                         \
-  const int64_t stride_ = (int64_t)(nwb_) * 256;    \
-  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n && (int)blockIdx.x < (nwb_); row += stride_)
-#define OX_ROW_LOOP OX_ROW_LOOP_N(gridDim.x)
+#define OX_ROW_LOOP                                 \
+  const int64_t stride_ = (int64_t)gridDim.x * 256; \
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride_)
 
-// block sum of the kernel's dot products, then the end of the synchronisation point (ox_ksp_dev.h): the
-// partial sums are stored and, when folded, the last block to arrive reduces them and runs the scalar logic
 template <int NV>
-__device__ __forceinline__ void ksp_store_partial(double (&s)[NV], KspFoldLds &fl, double *partial, const KspFold &fold) {
-  ox_block_sum_256<NV>(s, fl.red);
-  ksp_arrive<NV>(s, partial, fold, fl);
+__device__ __forceinline__ void ksp_store_partial(double (&s)[NV], double *red, double *partial) {
+  ox_block_sum_256<NV>(s, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+  }
 }
 
 // Flat traversal of an interleaved (n x NC) block: every thread takes TWO consecutive elements, so
@@ -136,11 +198,9 @@ __device__ __forceinline__ void ksp_store_partial(double (&s)[NV], KspFoldLds &f
 // f(e, c0, r0, c1, r1, two): elements e (column c0, row r0) and e+1 (c1, r1); two = false for the
 // odd tail element.
 template <int NC, class F>
-__device__ __forceinline__ void ox_flat_pairs(int64_t n, F &&f, int nwb = 0 /* work blocks; 0: the whole grid */) {
+__device__ __forceinline__ void ox_flat_pairs(int64_t n, F &&f) {
   const int64_t tot = n * NC, n2 = tot >> 1;
-  if (nwb <= 0) nwb = gridDim.x;
-  if ((int)blockIdx.x >= nwb) return;
-  const int64_t stride = (int64_t)nwb * 256;
+  const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
     const int64_t e = 2 * i;
     const int64_t r0 = e / NC;
@@ -184,12 +244,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__restrict__ b, double *x,
                                                  const double *q, const double *__restrict__ dinv,
                                                  double *vr, double *vp, int guess,
-                                                 double *partial, KspFold fold) {
-  __shared__ KspFoldLds fl;
+                                                 double *partial) {
+  __shared__ double red[4 * 3 * NC];
   double s[3 * NC];
 #pragma unroll
   for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
+  OX_ROW_LOOP {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -206,7 +266,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
       s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
     }
   }
-  ksp_store_partial<3 * NC>(s, fl, partial, fold);
+  ksp_store_partial<3 * NC>(s, red, partial);
 }
 
 // CG, first vector kernel of an iteration: r -= alpha q; z = D^-1 r (not stored); partial = {r.z, z.z}.
@@ -216,8 +276,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *vr,
                                                     const double *__restrict__ vq,
                                                     const double *__restrict__ dinv,
-                                                    double *partial, KspFold fold) {
-  __shared__ KspFoldLds fl;
+                                                    double *partial) {
+  __shared__ double red[4 * 2 * NC];
   if (S->done) return;
   double alpha[NC], s[2 * NC];
 #pragma unroll
@@ -241,8 +301,8 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
       ox_acc<NC>(s, 0, cb, r.y, z.y);
       ox_acc<NC>(s, NC, cb, z.y, z.y);
     }
-  }, fold.args ? fold.nwb : 0);
-  ksp_store_partial<2 * NC>(s, fl, partial, fold);
+  });
+  ksp_store_partial<2 * NC>(s, red, partial);
 }
 
 // CG, second vector kernel: x += alpha p (the iteration's alpha, still in the state); p = D^-1 r + beta p.
@@ -279,12 +339,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cgs_init(int64_t n, const double *__restrict__ b, double *x,
                                                   const double *q, const double *__restrict__ dinv,
                                                   double *vr, double *vu, double *vp, double *vs, int guess,
-                                                  double *partial, KspFold fold) {
-  __shared__ KspFoldLds fl;
+                                                  double *partial) {
+  __shared__ double red[4 * 3 * NC];
   double s[3 * NC];
 #pragma unroll
   for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
+  OX_ROW_LOOP {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -303,7 +363,7 @@ __global__ __launch_bounds__(256) void k_cgs_init(int64_t n, const double *__res
       s[2 * NC + c] = fma(db, db, s[2 * NC + c]);
     }
   }
-  ksp_store_partial<3 * NC>(s, fl, partial, fold);
+  ksp_store_partial<3 * NC>(s, red, partial);
 }
 
 // Single-reduction CG, the whole vector update of an iteration in one pass:
@@ -314,8 +374,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S, int c0, double *x, double *vr,
                                                     double *vu, double *vp, double *vs,
                                                     const double *__restrict__ vw,
-                                                    const double *__restrict__ dinv, double *partial, KspFold fold) {
-  __shared__ KspFoldLds fl;
+                                                    const double *__restrict__ dinv, double *partial) {
+  __shared__ double red[4 * 2 * NC];
   if (S->done) return;
   double alpha[NC], beta[NC], s[2 * NC];
 #pragma unroll
@@ -353,8 +413,8 @@ __global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S
       ox_acc<NC>(s, 0, cb, r.y, u.y);
       ox_acc<NC>(s, NC, cb, u.y, u.y);
     }
-  }, fold.args ? fold.nwb : 0);
-  ksp_store_partial<2 * NC>(s, fl, partial, fold);
+  });
+  ksp_store_partial<2 * NC>(s, red, partial);
 }
 
 // BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = v = 0
@@ -364,12 +424,12 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
                                                    double *x, const double *q,
                                                    const double *__restrict__ dinv, double *vr,
                                                    double *vrhat, double *vp, double *vv, int guess,
-                                                   double *partial, KspFold fold) {
-  __shared__ KspFoldLds fl;
+                                                   double *partial) {
+  __shared__ double red[4 * 2 * NC];
   double s[2 * NC];
 #pragma unroll
   for (int i = 0; i < 2 * NC; ++i) s[i] = 0.0;
-  OX_ROW_LOOP_N(fold.args ? fold.nwb : (int)gridDim.x) {
+  OX_ROW_LOOP {
     const double d = dinv[row];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -388,7 +448,7 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
       s[NC + c] = fma(db, db, s[NC + c]);
     }
   }
-  ksp_store_partial<2 * NC>(s, fl, partial, fold);
+  ksp_store_partial<2 * NC>(s, red, partial);
 }
 
 // BiCGStab: p = r + beta (p - omega v)   (or, on a restart: rhat <- r, p <- r)
@@ -446,9 +506,9 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
                                                 const double *__restrict__ vrhat,
                                                 const double *__restrict__ vp,
                                                 const double *__restrict__ vs,
-                                                const double *__restrict__ vt, double *partial, KspFold fold,
+                                                const double *__restrict__ vt, double *partial,
                                                 int finish /* merged variant: the x update the `done` flag skipped */) {
-  __shared__ KspFoldLds fl;
+  __shared__ double red[4 * 2 * NC];
   if (!finish && S->done) return;
   double alpha[NC], omega[NC], s[2 * NC];
 #pragma unroll
@@ -476,41 +536,34 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
       ox_acc<NC>(s, 0, cb, r.y, r.y);
       ox_acc<NC>(s, NC, cb, h.y, r.y);
     }
-  }, fold.args ? fold.nwb : 0);
-  ksp_store_partial<2 * NC>(s, fl, partial, fold);
+  });
+  ksp_store_partial<2 * NC>(s, red, partial);
 }
 
 // ------------------------------- host driver ---------------------------------------------
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// One block reads partials at ~45 GB/s: the 66 312 x 6 partials of a velocity SpMV (3.2 MB) kept the scalar
-// kernel of that synchronisation point busy for 79 us.  So blocks of rows are summed first (fixed order)
-// and the scalar kernel reads their sums:
-//   * up to OX_FOLD_MAX_ROWS rows: OX_FOLD_R blocks over the row ranges of the folded path's reducer blocks
-//     (ox_ksp_dev.h) -- the unfolded path then adds in exactly the order of the folded one;
-//   * beyond (never folded): chunks of OX_PRERED_CHUNK rows.
+// One block reads partials at ~45 GB/s: the 66 312 x 6 partials of a velocity SpMV (3.2 MB) kept the
+// scalar kernel of that synchronisation point busy for 79 us.  From OX_PRERED_MIN doubles on, blocks of
+// OX_PRERED_CHUNK partial rows are summed first (fixed order) and the scalar kernel reads their sums.
 #define OX_PRERED_CHUNK 256
+#define OX_PRERED_MIN 16384
 #define OX_PRERED_OFFSET 64  // doubles of the sums region kept for the sums themselves
-__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ partial, int nparts, int nv, int rows_per_block,
+__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ partial, int nparts, int nv,
                                                    double *__restrict__ out) {
   __shared__ double red[16 * OX_MAX_NV];
-  const int r0 = min(nparts, (int)blockIdx.x * rows_per_block);
-  const int cnt = min(rows_per_block, nparts - r0);
+  const int r0 = blockIdx.x * OX_PRERED_CHUNK;
+  const int cnt = min(OX_PRERED_CHUNK, nparts - r0);
   double v[OX_MAX_NV];
   ox_gather_partials(partial + (size_t)r0 * nv, cnt, nv, v);
   ox_block_sum_wide(v, nv, red);
   if (threadIdx.x == 0)
     for (int i = 0; i < nv; ++i) out[(size_t)blockIdx.x * nv + i] = v[i];
 }
-// blocks of the pre-reduction (0: none -- partitioned operators, which never fold, skip it for small arrays)
-static inline int ksp_prered_rows(int nparts, int nv, bool mirror_fold) {
-  if (nparts <= OX_FOLD_MAX_ROWS) return (mirror_fold || (int64_t)nparts * nv >= 16384) ? OX_FOLD_R : 0;
-  return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK;
-}
-static inline int ksp_prered_rpb(int nparts) { return nparts <= OX_FOLD_MAX_ROWS ? ox_fold_rpg(nparts) : OX_PRERED_CHUNK; }
+static inline int ksp_prered_rows(int nparts) { return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK; }
 
 struct KspLayout {
-  size_t state, sums, partial, partial2, fold_gran, fold_ggran, fold_tab, fold_end, vec0, vec_stride, narrow0, narrow_stride, total;
+  size_t state, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
 };
 
@@ -524,17 +577,9 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
-  const size_t prered_max = (size_t)((L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK > OX_FOLD_R
-                                         ? (L.nparts_max + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK : OX_FOLD_R);
-  L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (prered_max + 1) * OX_MAX_NV));
+  L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (size_t)(ksp_prered_rows(L.nparts_max) + 1) * OX_MAX_NV));
   L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 5 * OX_MAXC);
-  // folded synchronisation points (ox_ksp_dev.h): tagged granules of the work blocks' sums, of the group sums,
-  // and the per-phase argument table
-  L.fold_gran = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * 2 * OX_MAXC);
-  L.fold_ggran = L.fold_gran + ox_align(16 * (size_t)OX_FOLD_MAX_ROWS * 3 * OX_MAXC);
-  L.fold_tab = L.fold_ggran + ox_align(16 * (size_t)OX_FOLD_R * OX_MAX_NV);
-  L.fold_end = L.fold_tab + ox_align(sizeof(KspFoldArgs) * 2 * PH_COUNT);
-  L.vec0 = L.fold_end;
+  L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * 2 * OX_MAXC);
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
   L.narrow0 = L.vec0 + L.vec_stride * L.nvec;
   L.narrow_stride = ox_align(sizeof(double) * (size_t)n_cols);
@@ -547,27 +592,22 @@ extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, i
 }
 
 static KspState *g_state_host = nullptr;
-static int g_ksp_fold = -1;
-extern "C" int ox_set_ksp_fold(int on) {  // tuning / test hook: 0 = separate scalar kernels everywhere,
-  g_ksp_fold = on < 0 ? 0 : (on > 2 ? 2 : on);    // 1 = the vector kernels end their points, 2 = the SpMVs too
-  return 0;
-}
-
 
 template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
-                          const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0},
-                          bool mirror = false /* add in the order of the folded path (its A/B twin) */) {
+                          const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
   {
     double *scr = sums + OX_PRERED_OFFSET;
-    if (const int g = ksp_prered_rows(nparts, nv, mirror)) {
-      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, ksp_prered_rpb(nparts), scr);
+    if ((int64_t)nparts * nv >= OX_PRERED_MIN) {
+      const int g = ksp_prered_rows(nparts);
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, scr);
       partial = scr;
       nparts = g;
       scr += (size_t)g * nv;
     }
-    if (const int g = B.nv > 0 ? ksp_prered_rows(B.nparts, B.nv, false) : 0) {
-      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, ksp_prered_rpb(B.nparts), scr);
+    if (B.nv > 0 && (int64_t)B.nparts * B.nv >= OX_PRERED_MIN) {
+      const int g = ksp_prered_rows(B.nparts);
+      hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, B.partial, B.nparts, B.nv, scr);
       B.partial = scr;
       B.nparts = g;
     }
@@ -624,68 +664,23 @@ struct KspCtx {
   const ox_dist *dist;
   hipStream_t st;
   int nb, nbs;
-  bool fold;       // the producer kernels end their synchronisation points themselves (single GPU)
-  bool fold_spmv;  // ... the SpMVs too (OX_KSP_FOLD=2: measurement only)
-  ox_u64 *fold_gran, *fold_ggran;
-  KspFoldArgs *fold_tab;  // device [2][PH_COUNT]: [0] the lock-step columns, [1] the narrowed continuation
-  unsigned *epoch;        // folded launches of this solve so far
 };
 
-// Can the producer of a synchronisation point with `nparts` partial rows end it itself?  Only the VECTOR
-// kernels do (k_cg_init, k_cg_update1, k_bcgs_init, k_bcgs_x: <= 2048 blocks, all resident at once).  The SpMVs
-// keep the separate scalar kernel: their reducer blocks' tail (two hand-off hops, 5.3 us at the 8 392 blocks of
-// the pressure matrix) buys 2.8 us per CG iteration and charges the metric's kernel with a reduction that is
-// not SpMV work (39.6 instead of 34.3 us by HIP events) -- measured, not kept (fold_spmv = false).
-static inline bool ksp_folds(const KspCtx &C, int nparts, bool spmv = false) {
-  return C.fold && nparts <= OX_FOLD_MAX_ROWS && (!spmv || C.fold_spmv);
-}
-
-// what that producer needs (args == nullptr: it only stores its partial sums and ksp_sync_point runs)
-static inline KspFold ksp_fold(const KspCtx &C, const KspParams &P, int phase, int nparts, bool spmv = false) {
-  KspFold F{};
-  if (ksp_folds(C, nparts, spmv)) {
-    F.args = C.fold_tab + (P.nc == P.nc_total ? 0 : PH_COUNT) + phase;
-    F.gran = C.fold_gran;
-    F.ggran = C.fold_ggran;
-    F.epoch = ++*C.epoch;
-    F.nwb = nparts;
-  }
-  return F;
-}
-static KspFoldArgs *g_fold_tab_host = nullptr;  // pinned staging of one table half
-static int ksp_fold_upload(const KspCtx &C, const KspParams &P) {
-  if (!C.fold) return 0;
-  if (!g_fold_tab_host) OX_HIP(hipHostMalloc(&g_fold_tab_host, sizeof(KspFoldArgs) * 2 * PH_COUNT));
-  KspFoldArgs *h = g_fold_tab_host + (P.nc == P.nc_total ? 0 : PH_COUNT);
-  for (int ph = 0; ph < PH_COUNT; ++ph) h[ph] = KspFoldArgs{C.S, P, ph};
-  OX_HIP(hipMemcpyAsync(C.fold_tab + (h - g_fold_tab_host), h, sizeof(KspFoldArgs) * PH_COUNT, hipMemcpyHostToDevice, C.st));
-  return 0;
-}
-// the synchronisation point of phase PH: nothing to launch when the producer was folded
-// (an unfolded vector-kernel point adds in the folded path's order on one GPU: the two are bit-identical twins)
-#define KSP_SYNC(PH, partial, nparts, nv, spmv)                                                              \
-  do {                                                                                                       \
-    if (!ksp_folds(C, nparts, spmv) &&                                                                       \
-        ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st, KspPart2{nullptr, 0, 0},      \
-                           !C.dist && !(spmv)))                                                              \
-      return -1;                                                                                             \
+#define KSP_SYNC(PH, partial, nparts, nv)                                                       \
+  do {                                                                                          \
+    if (ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st)) return -1;       \
   } while (0)
-// grid of a producer kernel with nwb work blocks
-#define KSP_GRID(nwb) dim3((nwb) + (ksp_folds(C, (nwb)) ? OX_FOLD_R : 0))
 
 template <int NC>
 static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    const KspFold fa = ksp_fold(C, P, PH_CG_A, C.nbs, true);
-    if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st, fa.args ? &fa : nullptr))
-      return -1;
-    KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC, true);
-    hipLaunchKernelGGL((k_cg_update1<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial,
-                       ksp_fold(C, P, PH_CG_B, C.nb));
+    if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
+    KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
+    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC, false);
+    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.dinv, V.p, 0);
     OX_LAUNCH_CHECK();
   }
@@ -700,7 +695,7 @@ static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_cgs_update<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.u, V.p, V.s, V.w,
-                       C.dinv, C.partial, KspFold{});
+                       C.dinv, C.partial);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st,
@@ -717,20 +712,16 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
-    const KspFold f1 = ksp_fold(C, P, PH_BCGS_1, C.nbs, true);
-    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st, f1.args ? &f1 : nullptr))
-      return -1;
-    KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC, true);
+    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
+    KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC);
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
-    const KspFold f2 = ksp_fold(C, P, PH_BCGS_2, C.nbs, true);
-    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st, f2.args ? &f2 : nullptr))
-      return -1;
-    KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC, true);
-    hipLaunchKernelGGL((k_bcgs_x<NC>), KSP_GRID(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                       V.t, C.partial, ksp_fold(C, P, PH_BCGS_3, C.nb), 0);
+    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T, C.dinv, nullptr, C.partial, done, C.dist, C.st)) return -1;
+    KSP_SYNC(PH_BCGS_2, C.partial, C.nbs, 2 * NC);
+    hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
+                       V.t, C.partial, 0);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC, false);
+    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC);
   }
   return 0;
 }
@@ -747,14 +738,14 @@ static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &
   for (int k = 0; k < count; ++k) {
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
-    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st, nullptr)) return -1;
+    if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
-    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T5, C.dinv, V.rhat, C.partial, done, C.dist, C.st, nullptr)) return -1;
+    if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T5, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGSM_B>(C.S, C.partial, C.nbs, 5 * NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                       V.t, C.partial2, KspFold{}, 0);
+                       V.t, C.partial2, 0);
     OX_LAUNCH_CHECK();
   }
   return 0;
@@ -762,7 +753,7 @@ static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &
 template <int NC>
 static int bcgsm_finish(const KspCtx &C, const KspVecs &V, const KspParams &P) {
   hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, C.A->n_rows, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                     V.t, C.partial2, KspFold{}, 1);
+                     V.t, C.partial2, 1);
   OX_LAUNCH_CHECK();
   return 0;
 }
@@ -832,21 +823,6 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
   C.nbs = ox_spmv_dist_nparts(A, dist);
-  // Folded synchronisation points (ox_ksp_dev.h): on one GPU the producer kernels end them themselves.  A
-  // partitioned operator needs the all-reduce between the sums and the logic, and the single-reduction CG
-  // merges two partial arrays: both keep the separate kernel.  OX_KSP_FOLD=0 restores it everywhere (A/B).
-  if (g_ksp_fold < 0) g_ksp_fold = getenv("OX_KSP_FOLD") ? atoi(getenv("OX_KSP_FOLD")) : 1;
-  C.fold = g_ksp_fold && !dist && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED;
-  C.fold_spmv = g_ksp_fold == 2;
-  C.fold_gran = reinterpret_cast<ox_u64 *>(work + L.fold_gran);
-  C.fold_ggran = reinterpret_cast<ox_u64 *>(work + L.fold_ggran);
-  C.fold_tab = reinterpret_cast<KspFoldArgs *>(work + L.fold_tab);
-  unsigned epoch = 0;
-  C.epoch = &epoch;
-  if (C.fold) {  // no tag of an earlier solve may look like one of this solve's epochs
-    OX_HIP(hipMemsetAsync(C.fold_gran, 0, L.fold_tab - L.fold_gran, st));
-    if (ksp_fold_upload(C, P)) return -1;
-  }
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
@@ -859,7 +835,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
       if (ox_spmv_dist(A, x, V.w, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
     hipLaunchKernelGGL((k_cgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.w, dinv, V.r, V.u,
-                       V.p, V.s, guess, C.partial, KspFold{});
+                       V.p, V.s, guess, C.partial);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, dist, st)) return -1;
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
@@ -869,19 +845,19 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_cg_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
-                       V.p, guess, C.partial, ksp_fold(C, P, PH_CG_INIT, C.nb));
+    hipLaunchKernelGGL((k_cg_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.q, dinv, V.r,
+                       V.p, guess, C.partial);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_CG_INIT, C.partial, C.nb, 3 * NC, false);
+    KSP_SYNC(PH_CG_INIT, C.partial, C.nb, 3 * NC);
   } else {
     V.r = vec[0], V.rhat = vec[1], V.p = vec[2], V.v = vec[3], V.s = vec[4], V.t = vec[5];
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.t, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
     }
-    hipLaunchKernelGGL((k_bcgs_init<NC>), KSP_GRID(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
-                       V.rhat, V.p, V.v, guess, C.partial, ksp_fold(C, P, PH_BCGS_INIT, C.nb));
+    hipLaunchKernelGGL((k_bcgs_init<NC>), dim3(C.nb), dim3(256), 0, st, n, b, x, (guess && ax0) ? ax0 : V.t, dinv, V.r,
+                       V.rhat, V.p, V.v, guess, C.partial);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC, false);
+    KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC);
   }
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;
@@ -943,7 +919,6 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
         KspParams P1 = P;
         P1.nc = 1;
         P1.c0 = live;
-        if (ksp_fold_upload(C, P1)) return -1;
         if (run_ahead) {
           const int bsz = batch_of(check_every);
           auto it1 = [&](int count) -> int {
@@ -982,9 +957,6 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, dinv, V.p, 1);
     OX_LAUNCH_CHECK();
   }
-  for (int c = 0; c < NC; ++c)
-    if (g_state_host->reason[c] == OX_DIVERGED_FOLD_TIMEOUT)
-      OX_FAIL("ox_ksp_solve: a folded synchronisation point timed out waiting for a block's partial sums");
   for (int c = 0; c < NC; ++c) {
     result->reason[c] = g_state_host->reason[c];
     result->its[c] = g_state_host->its[c];

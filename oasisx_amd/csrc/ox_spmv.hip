@@ -3,7 +3,6 @@
 // slice mapping.  No MFMA: the path is sparse and HBM-bound.
 #include "ox_common.h"
 #include "ox_kernels.h"
-#include "ox_ksp_dev.h"
 #include <stdlib.h>
 
 thread_local char ox_err_buf[512] = "";
@@ -37,9 +36,9 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
                                               const double *__restrict__ aux,
                                               double *__restrict__ partial,
                                               const int *__restrict__ done_flag,
-                                              const int32_t *__restrict__ slice_list, int n_list, KspFold fold) {
+                                              const int32_t *__restrict__ slice_list, int n_list) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
-  __shared__ KspFoldLds fl;  // block sum of the fused epilogue + tail of a folded synchronisation point
+  __shared__ double red[4 * NV];
   __shared__ double dict[(VAR & 4) ? 256 : 1];
   if (done_flag && *done_flag) return;
   if (VAR & 4) {  // value dictionary (<= 256 distinct values in the whole matrix): 1 B per entry
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   // slice_list (interior / boundary split of a partitioned operator): the launch covers that list
   const int n_sl = slice_list ? n_list : A.n_slices;
   const int ngroups = (n_sl + 3) >> 2;
-  const int per = (fold.args ? fold.nwb : (int)gridDim.x) >> 3;  // (a folded launch has OX_FOLD_R reducer blocks more)
+  const int per = gridDim.x >> 3;
   const int chunk = (ngroups + 7) >> 3;
   const int xcd = blockIdx.x & 7;
   const int g_begin = xcd * chunk;
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
   double s[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) s[i] = 0.0;
-  for (int g = g_begin + (blockIdx.x >> 3); g < g_end && (int)blockIdx.x < per * 8; g += per) {
+  for (int g = g_begin + (blockIdx.x >> 3); g < g_end; g += per) {
     const int li = g * 4 + wave;
     if (li >= n_sl) continue;
     const int slice = __builtin_amdgcn_readfirstlane(slice_list ? slice_list[li] : li);  // wave-uniform: scalar loads below
@@ -159,8 +158,11 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
     }
   }
   if (EPI != OX_EPI_NONE) {
-    ox_block_sum_256<NV>(s, fl.red);
-    ksp_arrive<NV>(s, partial, fold, fl);
+    ox_block_sum_256<NV>(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+    }
   }
 }
 
@@ -185,20 +187,20 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
                                                  const double *__restrict__ aux,
                                                  double *__restrict__ partial,
                                                  const int *__restrict__ done_flag /* never null */,
-                                                 const int32_t *__restrict__ slice_list, int n_list, KspFold fold) {
+                                                 const int32_t *__restrict__ slice_list, int n_list) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-B load from an 8-B aligned address
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  __shared__ KspFoldLds fl;
+  __shared__ double red[4 * NV];
   __shared__ double dict[4 * 256];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n_sl = slice_list ? n_list : A.n_slices;
   const int ngroups_l = (n_sl + 3) >> 2;
-  const int per = (fold.args ? fold.nwb : (int)gridDim.x) >> 3;  // (a folded launch has OX_FOLD_R reducer blocks more)
+  const int per = gridDim.x >> 3;
   const int chunk = (ngroups_l + 7) >> 3;
   const int g_begin = (blockIdx.x & 7) * chunk;
-  const int g_end = (int)blockIdx.x < per * 8 ? min(ngroups_l, g_begin + chunk) : 0;  // reducer blocks: no slices
+  const int g_end = min(ngroups_l, g_begin + chunk);
   int g = g_begin + (blockIdx.x >> 3);
   // ---- round A
   const int dn = *done_flag;
@@ -323,8 +325,11 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
     }
   }
   if (EPI != OX_EPI_NONE) {
-    ox_block_sum_256<NV>(s, fl.red);
-    ksp_arrive<NV>(s, partial, fold, fl);
+    ox_block_sum_256<NV>(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+    }
   }
 }
 
@@ -359,15 +364,9 @@ extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench
 
 static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                             const double *dinv, const double *aux, double *partial, const int *done,
-                            hipStream_t st, const int32_t *list, int n_list, const KspFold *fold_in) {
+                            hipStream_t st, const int32_t *list, int n_list) {
   const int nblk = list ? ox_spmv_blocks_n(n_list) : ox_spmv_blocks(A);
   if (nblk == 0) return 0;
-  KspFold fold{};  // args == nullptr: the blocks only store their partial sums
-  if (fold_in) {
-    fold = *fold_in;
-    fold.nwb = nblk;
-  }
-  const int ngrid = nblk + (fold_in ? OX_FOLD_R : 0);
   if (g_spmv_variant < 0) {
     const char *e = getenv("OX_SPMV_VARIANT");
     g_spmv_variant = e ? atoi(e) & 15 : OX_SPMV_DEFAULT_VARIANT;
@@ -379,14 +378,14 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
-  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(ngrid), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list, fold)
+  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
     if (var == 7 && pairs) {                                                                    \
       const int *dz = done ? done : ox_zero_flag(st);                                             \
       if (!dz) OX_FAIL("ox_spmv: no device flag");                                              \
-      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(ngrid), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list, fold); \
+      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list); \
     } else if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                              \
     else if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                \
     else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \
@@ -410,8 +409,8 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
 
 int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                    const double *dinv, const double *aux, double *partial, const int *done,
-                   hipStream_t st, const KspFold *fold) {
-  return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, nullptr, 0, fold);
+                   hipStream_t st) {
+  return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, nullptr, 0);
 }
 
 // OX_HALO_OVERLAP: 1 = start the halo exchange, multiply the interior slices while it is in flight, the boundary
@@ -439,21 +438,20 @@ int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist) {
 // y = A x with the ghost block of x refreshed: halo exchange started, interior slices multiplied
 // while it is in flight, boundary slices after it has landed (or exchange-then-multiply without the split)
 int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
-                 double *partial, const int *done, const ox_dist *dist, hipStream_t st, const KspFold *fold) {
-  if (fold && dist) OX_FAIL("ox_spmv_dist: a folded synchronisation point needs a single-GPU operator");
+                 double *partial, const int *done, const ox_dist *dist, hipStream_t st) {
   if (!ox_overlap_on(A, dist)) {
     if (dist && ox_halo_forward_impl(dist, x, ncomp, st)) return -1;
-    return ox_spmv_launch(A, x, y, ncomp, epi, dinv, aux, partial, done, st, fold);
+    return ox_spmv_launch(A, x, y, ncomp, epi, dinv, aux, partial, done, st);
   }
   if (ox_prof_on) ox_prof_start(OX_TAG_HALO, st, ncomp);
   if (ox_halo_begin_impl(dist, x, ncomp, st)) return -1;
   if (ox_prof_on) ox_prof_stop(st);
   const int nv = ox_epi_nv(epi, ncomp);
   const int nb_int = ox_spmv_blocks_n(A->n_interior);
-  if (spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, A->ib_slices, A->n_interior, nullptr)) return -1;
+  if (spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, A->ib_slices, A->n_interior)) return -1;
   if (ox_halo_end_impl(dist, x, ncomp, st)) return -1;
   return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial ? partial + (size_t)nb_int * nv : nullptr, done, st,
-                          A->ib_slices + A->n_interior, A->n_slices - A->n_interior, nullptr);
+                          A->ib_slices + A->n_interior, A->n_slices - A->n_interior);
 }
 
 extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
@@ -461,7 +459,7 @@ extern "C" int ox_spmv(const ox_sell *A, const double *x, double *y, int ncomp,
   if (!A || !x || !y) OX_FAIL("ox_spmv: null argument");
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_spmv: ncomp=%d out of range", ncomp);
   hipStream_t st = ox_stream(stream);
-  return ox_spmv_dist(A, const_cast<double *>(x), y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st, nullptr);
+  return ox_spmv_dist(A, const_cast<double *>(x), y, ncomp, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -154,66 +154,6 @@ def test_fused_assembly_returns_the_first_matvec_of_the_tentative_solve(hip):
     assert its_with == list(S._solver_u.iterations) and torch.equal(u_with, S._U.dev())
 
 
-@pytest.mark.parametrize("ksp_type", ["cg", "bcgs"])
-@pytest.mark.parametrize("dim,N,deg,nc", [(2, 24, 2, 1), (3, 8, 2, 3), (3, 28, 1, 1), (3, 20, 2, 3), (3, 40, 2, 1)])
-def test_folded_sync_points_are_bit_identical_to_the_scalar_kernels(hip, ksp_type, dim, N, deg, nc):
-    """The producer kernels end the synchronisation points themselves on one GPU (the block that arrives last
-    reduces the partial sums and runs the scalar recurrences, ox_ksp_dev.h).  Same order of every sum as the
-    separate k_prereduce / k_ksp_scalar kernels: the iterates, the iteration counts and the residual norms
-    must agree bit for bit -- a stale or torn hand-off between workgroups would show here.  Sizes from one
-    group of 256 partial rows (N = 8) to several hundred groups (40^3 P2: 531 441 rows, 2 076 blocks), repeated
-    so that the counters are reused many times."""
-    from oasisx_amd import _lib
-    from oasisx_amd.fem import FieldStorage
-    from oasisx_amd.ksp import KSPSolver
-
-    V, A, Acsr = _system(dim, N, deg)
-    if ksp_type == "bcgs":  # make it non-symmetric: BiCGStab's own ground
-        A.vals.mul_(1.0 + 0.002 * torch.sin(torch.arange(A.vals.numel(), device="cuda", dtype=torch.float64)))
-        A.version += 1
-    n = V.num_dofs
-    x = V.x.cpu().numpy()
-    cols = [np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1]), 1e-3 * np.sin(5.0 * x[:, 0] * x[:, -1]), np.exp(x[:, 1])][:nc]
-    B = FieldStorage(n, nc, "cuda")
-    B.dev()[:] = torch.from_numpy(np.stack(cols, axis=1)).cuda()
-    lib = _lib.load()
-    out = {}
-    try:
-        for fold in (1, 0, 1):
-            lib.ox_set_ksp_fold(fold)
-            ksp = KSPSolver(None, {"ksp_type": ksp_type, "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
-                                   "ksp_cg_single_reduction": False})
-            ksp.setOperators(A)
-            for rep in range(3):
-                X = FieldStorage(n, nc, "cuda")
-                reasons = ksp.solve_block(B, X)
-                res = (X.dev().clone(), list(ksp.iterations[:nc]), list(reasons),
-                       [float(ksp.last_result.rnorm[c]) for c in range(nc)])
-                assert all(r > 0 for r in reasons), reasons
-                if fold in out:
-                    assert out[fold][1:] == res[1:] and torch.equal(out[fold][0], res[0]), (fold, rep)
-                out[fold] = res
-        # the SpMV-side points folded as well (measurement mode): another order of the sums behind the SpMVs,
-        # so agreement to rounding only -- what it checks is the hand-off (a stale granule would be far off)
-        lib.ox_set_ksp_fold(2)
-        ksp = KSPSolver(None, {"ksp_type": ksp_type, "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
-                               "ksp_cg_single_reduction": False})
-        ksp.setOperators(A)
-        for rep in range(2):
-            X = FieldStorage(n, nc, "cuda")
-            reasons = ksp.solve_block(B, X)
-            assert all(r > 0 for r in reasons), reasons
-            # (BiCGStab's iteration count moves by a few with the rounding of its inner products)
-            slack = 2 if ksp_type == "cg" else max(4, out[1][1][0] // 10)
-            assert all(abs(a - b) <= slack for a, b in zip(ksp.iterations[:nc], out[1][1])), (ksp.iterations, out[1][1])
-            ref = out[1][0]
-            assert float((X.dev() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
-    finally:
-        lib.ox_set_ksp_fold(1)
-    assert out[1][1:] == out[0][1:], (out[1][1:], out[0][1:])
-    assert torch.equal(out[1][0], out[0][0])
-
-
 @pytest.mark.parametrize("dim,N,deg,nc", [(2, 24, 2, 1), (3, 8, 2, 3), (3, 10, 1, 2), (3, 16, 2, 3)])
 def test_merged_reduction_bicgstab_matches_standard_bicgstab_and_oracle(hip, dim, N, deg, nc):
     """OX_KSP_BCGS_MERGED (two synchronisation points per iteration: rhat.v, then {t.t, t.s, rhat.s, rhat.t, s.s}
