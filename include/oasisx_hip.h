@@ -378,6 +378,14 @@ int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const d
                      int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
                      int check_every, int max_restarts, void *work, size_t work_bytes,
                      ox_ksp_result *result, const ox_dist *dist, void *stream, const double *ax0);
+/* The same with a value dictionary of dinv (dinv_code: device [n_rows] bytes, dinv[i] == dinv_dict[dinv_code[i]] bit
+ * for bit; ox_value_dictionary builds it where dinv takes <= 256 distinct values, as the diagonals of M and Ap do on
+ * meshes of congruent cells): the CG update kernels then read one byte per row instead of eight.  Same iterates. */
+int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
+                    int ncomp, double rtol, double atol, int max_it, int nonzero_guess,
+                    int check_every, int max_restarts, void *work, size_t work_bytes,
+                    ox_ksp_result *result, const ox_dist *dist, void *stream, const double *ax0,
+                    const uint8_t *dinv_code, const double *dinv_dict, int n_dinv_dict);
 /* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
  * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
  * continue, at most that many times per component (used when a direct solver was asked for). */

@@ -190,6 +190,8 @@ SIGNATURES = {
                           C.c_size_t, C.POINTER(ox_ksp_result), _P, _P]),
     "ox_ksp_solve_ax0": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
                               C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P]),
+    "ox_ksp_solve_dc": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
+                             C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P, _P, _P, _I]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
     "ox_profile_begin": (_I, [_I, _I]),

@@ -269,16 +269,35 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double *__rest
   ksp_store_partial<3 * NC>(s, red, partial);
 }
 
+// The Jacobi diagonal of the CG vector kernels.  A matrix assembled on congruent cells has few distinct diagonal
+// values (Ap on the box meshes: 4, M: 8): with a dictionary of <= 256 values the two update kernels read ONE
+// byte per row instead of eight -- 2 of the 10 vector passes of a pressure-CG iteration (the kernels run at
+// ~6 TB/s: bandwidth is their bound).  Same values, same operations: bit-identical iterates.
+struct KspDinv {
+  const double *v;      // [n_rows]
+  const uint8_t *code;  // [n_rows] or nullptr
+  const double *dict;   // [n]
+  int n;
+};
+__device__ __forceinline__ void ksp_dinv_stage(const KspDinv &D, double *dd /* LDS [256] */) {
+  if (D.code) {  // uniform
+    for (int i = threadIdx.x; i < D.n; i += blockDim.x) dd[i] = D.dict[i];
+    __syncthreads();
+  }
+}
+#define KSP_DINV(row) (D.code ? dd[D.code[row]] : D.v[row])
+
 // CG, first vector kernel of an iteration: r -= alpha q; z = D^-1 r (not stored); partial = {r.z, z.z}.
 // x waits for the second kernel, which reads p anyway: 10 vector passes per iteration instead of 11,
 // no z vector; every element sees the same operations as in the textbook order.
 template <int NC>
 __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S, int c0, double *vr,
-                                                    const double *__restrict__ vq,
-                                                    const double *__restrict__ dinv,
+                                                    const double *__restrict__ vq, KspDinv D,
                                                     double *partial) {
   __shared__ double red[4 * 2 * NC];
+  __shared__ double dd[256];
   if (S->done) return;
+  ksp_dinv_stage(D, dd);
   double alpha[NC], s[2 * NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) alpha[c] = S->alpha[c0 + c];
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
     const double2 qq = ox_ld2(vq, e, two);
     double2 r = ox_ld2(vr, e, two);
     const double a0 = ox_sel<NC>(alpha, ca), a1 = ox_sel<NC>(alpha, cb);
-    const double d0 = dinv[ra], d1 = two ? dinv[rb] : 0.0;
+    const double d0 = KSP_DINV(ra), d1 = two ? KSP_DINV(rb) : 0.0;
     r.x = fma(-a0, qq.x, r.x);
     r.y = fma(-a1, qq.y, r.y);
     double2 z;
@@ -310,9 +329,10 @@ __global__ __launch_bounds__(256) void k_cg_update1(int64_t n, const KspState *S
 // the host then runs it once with `finish` set so that x receives its last update.
 template <int NC>
 __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S, int c0, double *x,
-                                                    const double *__restrict__ vr,
-                                                    const double *__restrict__ dinv, double *vp, int finish) {
+                                                    const double *__restrict__ vr, KspDinv D, double *vp, int finish) {
+  __shared__ double dd[256];
   if (!finish && S->done) return;
+  ksp_dinv_stage(D, dd);
   double alpha[NC], beta[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S
   ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t ra, int cb, int64_t rb, bool two) {
     const double2 r = ox_ld2(vr, e, two);
     double2 p = ox_ld2(vp, e, two), xx = ox_ld2(x, e, two);
-    const double d0 = dinv[ra], d1 = two ? dinv[rb] : 0.0;
+    const double d0 = KSP_DINV(ra), d1 = two ? KSP_DINV(rb) : 0.0;
     xx.x = fma(ox_sel<NC>(alpha, ca), p.x, xx.x);
     xx.y = fma(ox_sel<NC>(alpha, cb), p.y, xx.y);
     const double z0 = d0 * r.x, z1 = d1 * r.y;
@@ -659,6 +679,7 @@ struct KspVecs {
 struct KspCtx {
   const ox_sell *A;
   const double *dinv;
+  KspDinv D;  // dinv again, with its value dictionary where the caller has one (CG update kernels)
   KspState *S;
   double *sums, *partial, *partial2;
   const ox_dist *dist;
@@ -678,10 +699,10 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
   for (int k = 0; k < count; ++k) {
     if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
     KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
-    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.dinv, C.partial);
+    hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.D, C.partial);
     OX_LAUNCH_CHECK();
     KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
-    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.dinv, V.p, 0);
+    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 0);
     OX_LAUNCH_CHECK();
   }
   return 0;
@@ -809,12 +830,13 @@ static int ksp_run_ahead(const KspCtx &C, Iterate &&iterate, int batch, int &it,
 template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
-                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0) {
+                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0, const KspDinv &Dc) {
   const int64_t n = A->n_rows;
   const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type);
   KspCtx C;
   C.A = A;
   C.dinv = dinv;
+  C.D = Dc;
   C.S = reinterpret_cast<KspState *>(work + L.state);
   C.sums = reinterpret_cast<double *>(work + L.sums);
   C.partial = reinterpret_cast<double *>(work + L.partial);
@@ -936,7 +958,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           }
         }
         if (cg) {  // the last x += alpha p (see k_cg_update2)
-          hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, dinv, W.p, 1);
+          hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, C.D, W.p, 1);
           OX_LAUNCH_CHECK();
         }
         if (bm && g_state_host->its[live] > 0 && bcgsm_finish<1>(C, W, P1)) return -1;
@@ -954,7 +976,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     if (any && bcgsm_finish<NC>(C, V, P)) return -1;
   }
   if (cg && !cg_finished) {  // the last x += alpha p (see k_cg_update2)
-    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, dinv, V.p, 1);
+    hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 1);
     OX_LAUNCH_CHECK();
   }
   for (int c = 0; c < NC; ++c) {
@@ -966,11 +988,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   return 0;
 }
 
-extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
-                                double *x, int ncomp, double rtol, double atol, int max_it,
-                                int nonzero_guess, int check_every, int max_restarts, void *work,
-                                size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
-                                const double *ax0) {
+extern "C" int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
+                               double *x, int ncomp, double rtol, double atol, int max_it,
+                               int nonzero_guess, int check_every, int max_restarts, void *work,
+                               size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
+                               const double *ax0, const uint8_t *dinv_code, const double *dinv_dict, int n_dinv_dict) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
   if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED)
     OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
@@ -978,23 +1000,34 @@ extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *di
   if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))
     OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes,
             ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type));
+  if (dinv_code && (!dinv_dict || n_dinv_dict < 1 || n_dinv_dict > 256)) OX_FAIL("ox_ksp_solve: dinv dictionary of %d entries", n_dinv_dict);
   if (max_it < 1) max_it = 1;
   if (check_every < 1) check_every = 1;
   memset(result, 0, sizeof(*result));
   KspParams P{rtol, atol, max_it, ncomp, 0, ncomp, max_restarts < 0 ? 0 : max_restarts};
   hipStream_t st = ox_stream(stream);
   char *w = static_cast<char *>(work);
+  const KspDinv D{dinv, dinv_code, dinv_dict, dinv_code ? n_dinv_dict : 0};
   switch (ncomp) {
-    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
-    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
-    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0);
+    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
+    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
+    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
   }
+}
+
+extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
+                                double *x, int ncomp, double rtol, double atol, int max_it,
+                                int nonzero_guess, int check_every, int max_restarts, void *work,
+                                size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
+                                const double *ax0) {
+  return ox_ksp_solve_dc(ksp_type, A, dinv, b, x, ncomp, rtol, atol, max_it, nonzero_guess, check_every, max_restarts,
+                         work, work_bytes, result, dist, stream, ax0, nullptr, nullptr, 0);
 }
 
 extern "C" int ox_ksp_solve(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
                             double *x, int ncomp, double rtol, double atol, int max_it,
                             int nonzero_guess, int check_every, int max_restarts, void *work,
                             size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream) {
-  return ox_ksp_solve_ax0(ksp_type, A, dinv, b, x, ncomp, rtol, atol, max_it, nonzero_guess, check_every, max_restarts,
-                          work, work_bytes, result, dist, stream, nullptr);
+  return ox_ksp_solve_dc(ksp_type, A, dinv, b, x, ncomp, rtol, atol, max_it, nonzero_guess, check_every, max_restarts,
+                         work, work_bytes, result, dist, stream, nullptr, nullptr, nullptr, 0);
 }

@@ -136,6 +136,17 @@ class KSPSolver:
         if self._dinv_version != A.version:
             _lib.check(lib.ox_jacobi_setup(A.ref(), _lib.ptr(self._dinv), st), "ox_jacobi_setup")
             self._dinv_version = A.version
+            # a matrix that carries a value dictionary (la.SellMatrix.freeze: it will not change any more) has
+            # few distinct diagonal values too: the CG update kernels then read one byte of dinv per row
+            self._dcode = self._ddict = None
+            if A.vcode is not None and dev.type == "cuda":
+                code = torch.empty(A.pattern.n_rows, dtype=torch.uint8, device=dev)
+                vdict = torch.zeros(256, dtype=torch.float64, device=dev)
+                nd = C.c_int(0)
+                _lib.check(lib.ox_value_dictionary(_lib.ptr(self._dinv), A.pattern.n_rows, 1, _lib.ptr(code), _lib.ptr(vdict),
+                                                   C.byref(nd), st), "ox_value_dictionary")
+                if nd.value > 0:
+                    self._dcode, self._ddict = code, vdict[: nd.value]
         need = lib.ox_ksp_work_bytes(A.pattern.n_rows, A.pattern.n_cols, nc, meth)
         if self._work is None or self._work.shape[0] < need:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
@@ -160,10 +171,13 @@ class KSPSolver:
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
-        _lib.check(lib.ox_ksp_solve_ax0(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
-                                        max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
-                                        int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
-                                        ax0.ptr() if (ax0 is not None and guess) else None),
+        dcode = getattr(self, "_dcode", None)
+        _lib.check(lib.ox_ksp_solve_dc(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
+                                       max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
+                                       int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
+                                       ax0.ptr() if (ax0 is not None and guess) else None,
+                                       _lib.ptr(dcode), _lib.ptr(self._ddict) if dcode is not None else None,
+                                       int(self._ddict.shape[0]) if dcode is not None else 0),
                    "ox_ksp_solve")
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
             _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")
