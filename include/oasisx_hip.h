@@ -98,7 +98,9 @@ typedef struct {
    * Slots keep the stored order of the row's entries (an entry whose successor is the next column
    * shares its slot; any other entry gets b = the code of 0.0), so sums are bit-identical. */
   const int64_t *ps_ptr;     /* device [n_slices+1], offsets into ps_code, multiples of 256;
-                                bit 0 set by _fill: that slice is read from cols / vcode      */
+                                bit 0 set by _fill: that slice is read from cols / vcode;
+                                bits 1-3 set by _fill: slots of the slice's last group of 4 that
+                                any row uses (the others are padding: no gather is issued)    */
   const uint32_t *ps_code;   /* device [ps_ptr[n_slices]]; slot j of lane l of slice s at
                                 ps_ptr[s] + (j/4)*256 + l*4 + j%4: bits 0-14 column offset, bit 15
                                 which base, bits 16-23 code a, bits 24-31 code b                */

@@ -13,7 +13,22 @@ __host__ __device__ constexpr int ox_epi_nv(int epi, int nc) {
   return epi == OX_EPI_NONE ? 0 : (epi == OX_EPI_BCGS_T ? 2 * nc : (epi == OX_EPI_BCGS_T5 ? 5 * nc : nc));
 }
 
-#define OX_VEC_MAX_BLOCKS 2048  // grid cap of the BLAS-1 kernels (256 CUs x 8 blocks)
+#define OX_VEC_MAX_BLOCKS 4096  // upper bound of the grid cap of the BLAS-1 kernels (sizes the partial arrays)
+// The cap itself depends on the vector: measured on one box with the bench workload (OX_VEC_BLOCKS = 512 / 768 /
+// 1024 / 1536 / 2048): the BiCGStab solve on the 3 x 17 M-row vectors takes 44.0 / 42.1 / 40.8 / 41.2 / 44.3 ms per
+// step (fewer, longer blocks keep fewer DRAM streams open), the pressure-CG iteration on 2.1 M rows 69.8 / 68.3 /
+// 68.1 / 67.1 / 67.0 us (8 short blocks per CU hide the launch ramp).  OX_VEC_BLOCKS overrides (tuning).
+#include <stdlib.h>
+static inline int ox_vec_cap(int64_t n) {
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("OX_VEC_BLOCKS");
+    env = e ? atoi(e) : 0;
+    if (env > OX_VEC_MAX_BLOCKS) env = OX_VEC_MAX_BLOCKS;
+  }
+  if (env >= 8) return env;
+  return n >= ((int64_t)1 << 24) ? 1024 : 2048;
+}
 
 #define OX_SPMV_MAX_BLOCKS (1 << 22)  // one slice group per block (a cap of 2048 = persistent grid
                                       // measured 10 % slower: r01 notes in DESIGN.md)
@@ -30,7 +45,7 @@ static inline int ox_spmv_blocks(const ox_sell *A) { return ox_spmv_blocks_n(A->
 static inline int ox_vec_blocks(int64_t n) {
   int64_t b = (n / 2 + 255) / 256;
   if (b < 1) b = 1;
-  return (int)(b > OX_VEC_MAX_BLOCKS ? OX_VEC_MAX_BLOCKS : b);
+  return (int)(b > ox_vec_cap(n) ? ox_vec_cap(n) : b);
 }
 
 #define OX_RED_THREADS 1024  // widest final-reduction block (many partials: velocity SpMV)

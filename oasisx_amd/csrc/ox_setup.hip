@@ -1342,13 +1342,14 @@ __global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *_
     const int64_t n_own = min(A.n_rows, A.n_cols);
     const int pad_col = (int)min(max(row, (int64_t)0), n_own - 2);  // x[pad_col], x[pad_col+1]: owned
     bool ok = true;
-    int k = 0;
+    int k = 0, used = 0;  // used: slots of this row that hold an entry
     for (int g = 0; g < ngroups; ++g) {
       int c[4];
       unsigned vv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (k < len) {
+          ++used;
           int cc = A.cols[ps_slot(base, k, lane)];
           unsigned a = A.vcode[ps_slot(base, k, lane)], b = (unsigned)zero_code;
           if (k + 1 < len && A.cols[ps_slot(base, k + 1, lane)] == cc + 1) {
@@ -1396,9 +1397,13 @@ __global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *_
         ps_base[((pb >> 8) + g) * 2 + 1] = lo2 == BIG ? lo : lo2;
       }
     }
-    if (lane == 0 && ngroups > 0 && !ok) {  // the kernel learns it with the offset: one round trip less
-      ps_ptr[slice] = pb | 1;
-      atomicAdd(n_wide, 1ull);
+    // slots of the LAST group that any row of the slice uses (1..4), in bits 1-3 of the offset: the SpMV issues
+    // gathers for those only (a slice of interior P1 rows needs 9 slots and stores 12)
+    const int m = ps_wave_max(used);
+    const int last = ngroups > 0 ? min(4, max(1, m - 4 * (ngroups - 1))) : 0;
+    if (lane == 0 && ngroups > 0) {  // (with the offset: the kernel learns both without another round trip)
+      ps_ptr[slice] = pb | (ok ? 0 : 1) | ((int64_t)last << 1);
+      if (!ok) atomicAdd(n_wide, 1ull);
     }
   }
 }

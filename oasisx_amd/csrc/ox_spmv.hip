@@ -4,6 +4,7 @@
 #include "ox_common.h"
 #include "ox_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 thread_local char ox_err_buf[512] = "";
 
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
   if (dn) valid = false;
   while (valid) {
     const bool wide = (base & 1) != 0;
+    const int last = (int)((base >> 1) & 7);  // slots of the last group that any row uses (0: a stream without the hint)
     base &= ~(int64_t)255;
     const int ng = (int)(((next & ~(int64_t)255) - base) >> 8);  // groups of 4 slots x 64 lanes
     const int64_t row = (int64_t)slice * 64 + lane;
@@ -246,9 +248,12 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
     // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B (NC = 1)
     // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B per component; the fused
     // multiply-adds in the stored order of the entries
-    auto group = [&](const u4 code, const int2 b) {
+    // NS: slots of the group in use (the rest is padding in every row of the slice: zero coefficients, no gather
+    // needed); a compile-time count keeps the group's gathers one straight-line batch
+    auto group = [&](auto ns_tag, const u4 code, const int2 b) {
+      constexpr int NS = decltype(ns_tag)::value;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NS; ++j) {
         const unsigned cj = code[j];
         const int col = ((cj & 0x8000u) ? b.y : b.x) + (int)(cj & 0x7fffu);
         const double va = md[(cj >> 16) & 0xffu], vb = md[cj >> 24];
@@ -272,8 +277,19 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
           const u4 ca = __builtin_nontemporal_load(cp + (size_t)q * 64);
           const u4 cb2 = __builtin_nontemporal_load(cp + (size_t)q1 * 64);
           const int2 ba = bp[q], bb = bp[q1];
-          group(ca, ba);
-          if (q + 1 < ng) group(cb2, bb);
+          auto tail = [&](const u4 cc, const int2 bq) {  // the slice's last group
+            if (last == 1) group(std::integral_constant<int, 1>{}, cc, bq);
+            else if (last == 2) group(std::integral_constant<int, 2>{}, cc, bq);
+            else if (last == 3) group(std::integral_constant<int, 3>{}, cc, bq);
+            else group(std::integral_constant<int, 4>{}, cc, bq);
+          };
+          if (q + 1 < ng) {
+            group(std::integral_constant<int, 4>{}, ca, ba);
+            if (q + 2 < ng) group(std::integral_constant<int, 4>{}, cb2, bb);
+            else tail(cb2, bb);
+          } else {
+            tail(ca, ba);
+          }
         }
       } else {  // this slice's pair columns did not fit two 15-bit windows (rare): entry stream
         const int64_t eb = A.slice_ptr[slice];
