@@ -873,7 +873,10 @@ __global__ __launch_bounds__(256) void k_assemble_rect(ox_cells cells, ox_adj ad
   using ER = Elem<GDIM, RDEG>;
   using EC = Elem<GDIM, CDEG>;
   const auto &R = rt<GDIM, RDEG>();
-  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // blocks that share an XCD take one contiguous eighth of the slices (as k_assemble_rows): neighbouring rows,
+  // which share their cells, then meet in ONE L2 (r02 PMC: 31-52 GB moved to write 3.3 GB with blocks dealt
+  // round-robin over the XCDs)
+  const int slice = ox_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (slice >= adj.n_slices) return;
   const int64_t base = A.slice_ptr[slice];
   const int64_t abase = adj.adj_ptr[slice];
