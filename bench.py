@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the variant legs (zero guess, dictionaries off) and the 256^3 past-cache SpMV")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cg-single-reduction", default=None, choices=["true", "false"],
+                    help="force -ksp_cg_single_reduction for the CG solves (default: true on partitioned operators only)")
+    ap.add_argument("--bcgs-merged", default=None, choices=["true", "false"],
+                    help="force the merged-reduction BiCGStab (default: true on partitioned operators only)")
     ap.add_argument("--matrix-free", action="store_true",
                     help="low_memory_version=True: matrix-free vector kernels for the p*, div(u) and grad(phi) "
                          "terms instead of the pre-assembled rectangular operators (reference "
@@ -314,6 +318,11 @@ def main():
             # extension re-seeds the shadow residual instead (oasisx_amd/ksp.py)
             tent["ksp_bcgs_restarts"] = 5
         so = {"tentative": tent, "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")}
+        if args.cg_single_reduction is not None:
+            for k in ("pressure", "scalar"):
+                so[k]["ksp_cg_single_reduction"] = args.cg_single_reduction == "true"
+        if args.bcgs_merged is not None:
+            so["tentative"]["ksp_bcgs_merged_reduction"] = args.bcgs_merged == "true"
         S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                      solver_options=so, options=opts)
         return mesh, S_
