@@ -270,19 +270,40 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
     };
     if (ng > 0) {
       if (!wide) {
-        // ---- rounds B, C: two groups per turn (measured: eight gathers in flight per wave at 100
-        // registers, or slices padded to whole turns, are 25 % slower than this)
-        for (int q = 0; q < ng; q += 2) {
+        // ---- rounds B, C.  The code loads come from the Infinity Cache / HBM (the stream does not fit the L2s):
+        // ~2000 cycles a round, the longest link of the wave's chain.  The codes of the first THREE groups are
+        // therefore requested together (a P1 slice has 2 or 3): a 3-group slice saves a whole round.  Gathers
+        // stay two groups per turn (eight in flight per wave at 100 registers measured 25 % slower).
+        auto tail = [&](const u4 cc, const int2 bq) {  // the slice's last group
+          if (last == 1) group(std::integral_constant<int, 1>{}, cc, bq);
+          else if (last == 2) group(std::integral_constant<int, 2>{}, cc, bq);
+          else if (last == 3) group(std::integral_constant<int, 3>{}, cc, bq);
+          else group(std::integral_constant<int, 4>{}, cc, bq);
+        };
+        int q0 = 0;
+        if (ng <= 3) {
+          const u4 c0 = __builtin_nontemporal_load(cp);
+          const u4 c1 = __builtin_nontemporal_load(cp + (size_t)min(1, ng - 1) * 64);
+          const u4 c2 = __builtin_nontemporal_load(cp + (size_t)(ng - 1) * 64);
+          const int2 b0 = bp[0], b1 = bp[min(1, ng - 1)], b2 = bp[ng - 1];
+          if (ng == 1) {
+            tail(c0, b0);
+          } else {
+            group(std::integral_constant<int, 4>{}, c0, b0);
+            if (ng == 2) {
+              tail(c1, b1);
+            } else {
+              group(std::integral_constant<int, 4>{}, c1, b1);
+              tail(c2, b2);
+            }
+          }
+          q0 = ng;
+        }
+        for (int q = q0; q < ng; q += 2) {
           const int q1 = min(q + 1, ng - 1);
           const u4 ca = __builtin_nontemporal_load(cp + (size_t)q * 64);
           const u4 cb2 = __builtin_nontemporal_load(cp + (size_t)q1 * 64);
           const int2 ba = bp[q], bb = bp[q1];
-          auto tail = [&](const u4 cc, const int2 bq) {  // the slice's last group
-            if (last == 1) group(std::integral_constant<int, 1>{}, cc, bq);
-            else if (last == 2) group(std::integral_constant<int, 2>{}, cc, bq);
-            else if (last == 3) group(std::integral_constant<int, 3>{}, cc, bq);
-            else group(std::integral_constant<int, 4>{}, cc, bq);
-          };
           if (q + 1 < ng) {
             group(std::integral_constant<int, 4>{}, ca, ba);
             if (q + 2 < ng) group(std::integral_constant<int, 4>{}, cb2, bb);
