@@ -560,6 +560,51 @@ __global__ __launch_bounds__(256) void k_bcgs_x(int64_t n, const KspState *S, in
   ksp_store_partial<2 * NC>(s, red, partial);
 }
 
+// Merged-reduction BiCGStab: behind its second synchronisation point alpha, omega AND the next beta are known, so
+// the x / r update of iteration k and the p update of iteration k+1 are one kernel:
+//   x += alpha p + omega s;   r = s - omega t;   p = r + beta (p - omega v)      (re-seeded column: rhat = p = r)
+// reads s, p, t, x, v, writes x, r, p: 8 vector passes where k_bcgs_x + k_bcgs_p make 11 (rhat is not read: the
+// residual norm and rho come from the recurrence).  The same order of operations per element as the two kernels.
+template <int NC>
+__global__ __launch_bounds__(256) void k_bcgs_xp(int64_t n, const KspState *S, int c0, double *x, double *vr, double *vrhat,
+                                                 double *vp, const double *__restrict__ vs, const double *__restrict__ vt,
+                                                 const double *__restrict__ vv,
+                                                 int finish /* the x update the `done` flag skipped */) {
+  if (!finish && S->done) return;
+  double alpha[NC], omega[NC], beta[NC], reseed[NC];
+  bool any = false;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    alpha[c] = S->alpha[c0 + c];
+    omega[c] = S->omega[c0 + c];
+    beta[c] = S->beta[c0 + c];
+    reseed[c] = S->restart[c0 + c] ? 1.0 : 0.0;
+    any = any || S->restart[c0 + c];
+  }
+  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t, int cb, int64_t, bool two) {
+    const double2 si = ox_ld2(vs, e, two), t = ox_ld2(vt, e, two), v = ox_ld2(vv, e, two);
+    double2 p = ox_ld2(vp, e, two), xx = ox_ld2(x, e, two), r;
+    const double a0 = ox_sel<NC>(alpha, ca), a1 = ox_sel<NC>(alpha, cb);
+    const double w0 = ox_sel<NC>(omega, ca), w1 = ox_sel<NC>(omega, cb);
+    xx.x = fma(w0, si.x, fma(a0, p.x, xx.x));
+    xx.y = fma(w1, si.y, fma(a1, p.y, xx.y));
+    r.x = fma(-w0, t.x, si.x);
+    r.y = fma(-w1, t.y, si.y);
+    const bool ra = ox_sel<NC>(reseed, ca) != 0.0, rb = ox_sel<NC>(reseed, cb) != 0.0;
+    p.x = ra ? r.x : fma(ox_sel<NC>(beta, ca), fma(-w0, v.x, p.x), r.x);
+    p.y = rb ? r.y : fma(ox_sel<NC>(beta, cb), fma(-w1, v.y, p.y), r.y);
+    ox_st2(x, e, xx, two);
+    ox_st2(vr, e, r, two);
+    ox_st2(vp, e, p, two);
+    if (any) {
+      double2 h = ox_ld2(vrhat, e, two);
+      h.x = ra ? r.x : h.x;
+      h.y = rb ? r.y : h.y;
+      ox_st2(vrhat, e, h, two);
+    }
+  });
+}
+
 // ------------------------------- host driver ---------------------------------------------
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -750,31 +795,32 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
 // Merged-reduction BiCGStab (OX_KSP_BCGS_MERGED): TWO synchronisation points per iteration instead of three --
 // rhat.v behind the first mat-vec; {t.t, t.s, rhat.s, rhat.t, s.s} behind the second give omega, rho' and |r|
 // together (PH_BCGSM_B) -- i.e. two all-reduces per iteration on a partitioned operator.
-// The x / r update runs after the second point with that iteration's alpha and omega; the update the `done`
-// flag skips at the end of the solve is applied by bcgsm_finish.
+// The x / r update runs after the second point with that iteration's alpha and omega, fused with the next p
+// update (k_bcgs_xp); the update the `done` flag skips at the end of the solve is applied by bcgsm_finish.
 template <int NC>
-static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
-  for (int k = 0; k < count; ++k) {
+  if (first) {  // p of the first iteration (p = r: v = p = 0); every later p comes out of k_bcgs_xp
     hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
     OX_LAUNCH_CHECK();
+  }
+  for (int k = 0; k < count; ++k) {
     if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T5, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGSM_B>(C.S, C.partial, C.nbs, 5 * NC, C.sums, P, C.dist, C.st)) return -1;
-    hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                       V.t, C.partial2, 0);
+    hipLaunchKernelGGL((k_bcgs_xp<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s, V.t, V.v, 0);
     OX_LAUNCH_CHECK();
   }
   return 0;
 }
 template <int NC>
 static int bcgsm_finish(const KspCtx &C, const KspVecs &V, const KspParams &P) {
-  hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, C.A->n_rows, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
-                     V.t, C.partial2, 1);
+  hipLaunchKernelGGL((k_bcgs_xp<NC>), dim3(C.nb), dim3(256), 0, C.st, C.A->n_rows, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s, V.t,
+                     V.v, 1);
   OX_LAUNCH_CHECK();
   return 0;
 }
@@ -881,11 +927,14 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     OX_LAUNCH_CHECK();
     KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC);
   }
+  bool bm_first = true;  // merged BiCGStab: the first batch starts with the p update, later ones carry it inside
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;
+    const bool first = bm_first;
+    bm_first = false;
     return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
                : (cg ? cg_iterations<N_>(C, W, Q, check_every)
-                     : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every) : bcgs_iterations<N_>(C, W, Q, check_every)));
+                     : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every, first) : bcgs_iterations<N_>(C, W, Q, check_every)));
   };
   bool cg_finished = false;
   static int run_ahead = -1;
@@ -897,9 +946,11 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     int it = 0;
     const int bsz = batch_of(check_every);
     auto it1 = [&](int count) -> int {
+      const bool first = bm_first;
+      bm_first = false;
       return cgs ? cgs_iterations<1>(C, V, P, count)
                  : (cg ? cg_iterations<1>(C, V, P, count)
-                       : (bm ? bcgsm_iterations<1>(C, V, P, count) : bcgs_iterations<1>(C, V, P, count)));
+                       : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count)));
     };
     if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
   }
@@ -946,7 +997,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           auto it1 = [&](int count) -> int {
             return cgs ? cgs_iterations<1>(C, W, P1, count)
                        : (cg ? cg_iterations<1>(C, W, P1, count)
-                             : (bm ? bcgsm_iterations<1>(C, W, P1, count) : bcgs_iterations<1>(C, W, P1, count)));
+                             : (bm ? bcgsm_iterations<1>(C, W, P1, count, false) : bcgs_iterations<1>(C, W, P1, count)));
           };
           it += check_every;
           if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
