@@ -155,6 +155,9 @@ typedef struct {
   const int32_t *cells;      /* device [n_cells][gdim+1], KERNEL order (tiled by centroid)  */
   const int32_t *cell_perm;  /* device [n_cells]: kernel cell index -> caller's cell index  */
   ox_cells cells_struct;     /* geometry of the cells in kernel order, as the kernels take it */
+  int32_t lattice;           /* 1: vertices on a tensor grid (tiled lexicographic order), 0: Z-order curve;
+                                with lo / span / tile_bits / n_cells: the frame ox_mesh_create_sub takes  */
+  int32_t reserved;
 } ox_mesh_info;
 
 typedef struct {

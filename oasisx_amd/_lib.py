@@ -74,6 +74,8 @@ class ox_mesh_info(C.Structure):
         ("cells", C.c_void_p),
         ("cell_perm", C.c_void_p),
         ("cells_struct", ox_cells),
+        ("lattice", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

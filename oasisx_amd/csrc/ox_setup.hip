@@ -866,6 +866,7 @@ extern "C" int ox_mesh_view(const ox_mesh *M, ox_mesh_info *v) {
   v->cells_struct.gdim = M->gdim;
   v->cells_struct.n_cells = M->nc;
   v->cells_struct.geom = M->geom.as<double>();
+  v->lattice = M->lattice;
   return 0;
 }
 
