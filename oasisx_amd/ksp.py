@@ -24,6 +24,7 @@ Option mapping (PETSc string keys, as the reference passes them):
 from __future__ import annotations
 
 import ctypes as C
+import time
 import typing
 
 import torch
@@ -49,6 +50,7 @@ class KSPSolver:
         self.last_result = None
         self.check_every = None  # override of the automatic check interval (see solve_block)
         self._every = {}
+        self._every_measured = set()
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -65,6 +67,7 @@ class KSPSolver:
         self._A = A
         self._dinv_version = -1
         self._every = {}
+        self._every_measured = set()
 
     def solve(self, b, x: Function) -> int:
         """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
@@ -158,20 +161,16 @@ class KSPSolver:
         # so check every iteration unless iterations are shorter than two reads.
         key = (nc, meth)
         if key not in self._every:
-            t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6  # seconds
-            if nc > 1:
-                ev = 1 if t_iter > 60e-6 else 4
-            else:
-                ev = max(1, min(16, int(1.5e-3 / t_iter)))
-            if A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
-                # every rank must enqueue the same number of iterations (each carries exchanges)
-                ev = int(self._comm.allreduce(ev, op="max"))
-            self._every[key] = ev
+            # first solve of this shape: an estimate from the matrix size (bytes per iteration at ~4 TB/s + launch
+            # latencies); replaced after the solve by what an iteration really took (below)
+            t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6
+            self._every[key] = self._check_interval(nc, t_iter)
         every = self.check_every or self._every[key]
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
         dcode = getattr(self, "_dcode", None)
+        t_start = time.perf_counter()
         _lib.check(lib.ox_ksp_solve_dc(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
                                        max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
                                        int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
@@ -182,10 +181,27 @@ class KSPSolver:
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
             _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")
         self.last_result = res
+        if key not in self._every_measured:  # the call blocks until the state is back on the host: wall time = solve time
+            its = max(int(res.its[c]) for c in range(nc))
+            if its >= 4:
+                self._every_measured.add(key)
+                self._every[key] = self._check_interval(nc, (time.perf_counter() - t_start) / its)
         reasons = [int(res.reason[c]) for c in range(nc)]
         if direct:
             reasons = [_lib.CONVERGED_ITS if r > 0 else r for r in reasons]
         return reasons
+
+    def _check_interval(self, nc: int, t_iter: float) -> int:
+        """Iterations enqueued between two host reads of the device state, from the time of one iteration."""
+        if nc > 1:
+            ev = 1 if t_iter > 60e-6 else 4
+        else:
+            ev = max(1, min(16, int(1.5e-3 / t_iter)))
+        A = self._A
+        if A is not None and A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
+            # every rank must enqueue the same number of iterations (each carries exchanges)
+            ev = int(self._comm.allreduce(ev, op="max"))
+        return ev
 
     @property
     def iterations(self):
