@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256) void k_cgs_update(int64_t n, const KspState *S
   ksp_store_partial<2 * NC>(s, red, partial);
 }
 
-// BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = v = 0
+// BiCGStab init: r = D^-1 (b - q) or D^-1 b (x = 0); rhat = r; p = r.
+// (The textbook starts from p = v = 0 and forms p = r + beta (p - omega v) = r in its first iteration -- exactly r,
+// bit for bit -- so the first k_bcgs_p is skipped and v, which the first mat-vec writes before anyone reads it, is
+// not initialised: 5 vector passes less per solve.)
 // partial = {r.r, (D^-1 b).(D^-1 b)}
 template <int NC>
 __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__restrict__ b,
@@ -462,8 +465,7 @@ __global__ __launch_bounds__(256) void k_bcgs_init(int64_t n, const double *__re
       const double db = d * bi;
       vr[i] = ri;
       vrhat[i] = ri;
-      vp[i] = 0.0;
-      vv[i] = 0.0;
+      vp[i] = ri;
       s[c] = fma(ri, ri, s[c]);
       s[NC + c] = fma(db, db, s[NC + c]);
     }
@@ -772,12 +774,14 @@ static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
 }
 
 template <int NC>
-static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
+static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
   for (int k = 0; k < count; ++k) {
-    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
-    OX_LAUNCH_CHECK();
+    if (!(first && k == 0)) {  // the first iteration's p = r was written by k_bcgs_init
+      hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
+      OX_LAUNCH_CHECK();
+    }
     if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     KSP_SYNC(PH_BCGS_1, C.partial, C.nbs, NC);
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
@@ -801,10 +805,7 @@ template <int NC>
 static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
-  if (first) {  // p of the first iteration (p = r: v = p = 0); every later p comes out of k_bcgs_xp
-    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
-    OX_LAUNCH_CHECK();
-  }
+  (void)first;  // the first iteration's p = r was written by k_bcgs_init; every later p comes out of k_bcgs_xp
   for (int k = 0; k < count; ++k) {
     if (ox_spmv_dist(C.A, V.p, V.v, NC, OX_EPI_BCGS_V, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
     if (ksp_sync_point<PH_BCGS_1>(C.S, C.partial, C.nbs, NC, C.sums, P, C.dist, C.st)) return -1;
@@ -927,14 +928,14 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     OX_LAUNCH_CHECK();
     KSP_SYNC(PH_BCGS_INIT, C.partial, C.nb, 2 * NC);
   }
-  bool bm_first = true;  // merged BiCGStab: the first batch starts with the p update, later ones carry it inside
+  bool bm_first = true;  // BiCGStab: the first iteration of the solve finds p = r in place (k_bcgs_init)
   auto iterate = [&](auto nc_tag, const KspVecs &W, const KspParams &Q) -> int {
     constexpr int N_ = decltype(nc_tag)::value;
     const bool first = bm_first;
     bm_first = false;
     return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
                : (cg ? cg_iterations<N_>(C, W, Q, check_every)
-                     : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every, first) : bcgs_iterations<N_>(C, W, Q, check_every)));
+                     : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every, first) : bcgs_iterations<N_>(C, W, Q, check_every, first)));
   };
   bool cg_finished = false;
   static int run_ahead = -1;
@@ -950,7 +951,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
       bm_first = false;
       return cgs ? cgs_iterations<1>(C, V, P, count)
                  : (cg ? cg_iterations<1>(C, V, P, count)
-                       : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count)));
+                       : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count, first)));
     };
     if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
   }
@@ -997,7 +998,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
           auto it1 = [&](int count) -> int {
             return cgs ? cgs_iterations<1>(C, W, P1, count)
                        : (cg ? cg_iterations<1>(C, W, P1, count)
-                             : (bm ? bcgsm_iterations<1>(C, W, P1, count, false) : bcgs_iterations<1>(C, W, P1, count)));
+                             : (bm ? bcgsm_iterations<1>(C, W, P1, count, false) : bcgs_iterations<1>(C, W, P1, count, false)));
           };
           it += check_every;
           if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
