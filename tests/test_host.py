@@ -226,3 +226,31 @@ def test_small_width_bins_are_merged_forward():
         inside = widths[(ptr[1:] > bp[b]) & (ptr[:-1] < bp[b + 1])]
         assert inside.max() == bw[b]  # LDS sized for the widest slice of the merged bin
         assert bp[b + 1] - bp[b] >= thresh or b == len(bw) - 1
+
+
+def test_high_order_lagrange_space_3d():
+    """fem.HighOrderLagrangeSpace on tetrahedra: P3 / P4 dof counts (vertices + (p-1) per edge + (p-1)(p-2)/2 per face
+    + (p-1)(p-2)(p-3)/6 per cell), distinct dof coordinates, and the dofs a DirichletBC finds on a face of the cube --
+    geometrically and through the face's facets -- are the (p N + 1)^2 lattice points of that face."""
+    from oasisx_amd import DirichletBC, LocatorMethod
+
+    N = 2
+    m = M.create_unit_cube(None, N, N, N, device="cpu")
+    nv = m.num_vertices
+    ne, nf, nc = (m._entities(k)[0].shape[0] for k in (1, 2, 3))
+    for p in (3, 4):
+        V = fem.functionspace(m, ("Lagrange", p))
+        assert V.num_dofs == nv + (p - 1) * ne + (p - 1) * (p - 2) // 2 * nf + (p - 1) * (p - 2) * (p - 3) // 6 * nc
+        assert V.num_dofs == (p * N + 1) ** 3  # the box mesh's dofs are the points of the refined lattice
+        X = V.tabulate_dof_coordinates()
+        assert len(np.unique(np.round(X * 1e9).astype(np.int64), axis=0)) == V.num_dofs
+        on_face = lambda x: np.isclose(x[2], 1.0)  # noqa: E731
+        bc = DirichletBC(lambda x: x[0] + 2 * x[1], LocatorMethod.GEOMETRICAL, on_face)
+        bc.create_bc(V)
+        assert bc._dofs.shape[0] == (p * N + 1) ** 2
+        facets = M.locate_entities_boundary(m, 2, on_face)
+        tags = M.meshtags(m, 2, facets, np.full(facets.shape, 7, dtype=np.int32))
+        bct = DirichletBC(1.0, LocatorMethod.TOPOLOGICAL, (tags, 7))
+        bct.create_bc(V)
+        assert (np.sort(bct._dofs) == np.sort(bc._dofs)).all()
+        assert np.allclose(bc.values_host(), X[bc._dofs, 0] + 2 * X[bc._dofs, 1])
