@@ -26,12 +26,12 @@ if real:
                                        C.byref(adj), _lib.ptr(V.adj.adj_pos), V.adj.pw, A.ref(), nb, bptr, bsl, bw,
                                        _lib.current_stream()), "ox_assemble_matrix")
     A.version += 1
-    print("value dictionary built:", A.freeze(), "entries", A._struct.n_dict)
+    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto")), "entries", A._struct.n_dict)
 npal = int(os.environ.get("PALETTE", "0"))  # > 0: values drawn from that many distinct numbers (mass /
 if npal:                                   # stiffness matrices on box meshes have 49 / 14)
     pal = torch.rand(npal, device="cuda", dtype=torch.float64) + 0.5
     A.vals.copy_(pal[torch.randint(0, npal, (A.vals.numel(),), device="cuda")])
-    print("value dictionary built:", A.freeze(), "entries", A._struct.n_dict)
+    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto")), "entries", A._struct.n_dict)
 P = V.pattern
 x = (torch.sin(torch.arange(P.n_cols*nc, device="cuda", dtype=torch.float64)*1e-3)+1).reshape(P.n_cols, nc).contiguous()
 y = torch.zeros_like(x)
@@ -59,7 +59,10 @@ for rnd in range(int(os.environ.get('ROUNDS', '7'))):
 import statistics
 for v in variants:
     med, mn = statistics.median(res[v]), min(res[v])
-    if (v & 14) == 14 and A.ps_code is not None:  # pair-slot stream: 4 B per slot + bases + vectors
+    if (v & 30) == 30 and nc == 1 and A.pw_code is not None:  # pair-window stream: 4 B per slot + 4 B per distinct pair + vectors
+        sb = 4*A.pw_code.numel() + 4*A.pw_list.numel() + 8*A.pw_ptr.numel() + 8*(P.n_slices+1) + 8*(P.n_cols+P.n_rows)
+        print(f"pair-window stream: {A._struct.pw_slices} slices per block, {A.pw_list.numel()/P.n_rows:.2f} pairs loaded per row, largest window {A._struct.pw_max} pairs, {sb/1e6:.1f} MB moved")
+    elif (v & 14) == 14 and A.ps_code is not None:  # pair-slot stream: 4 B per slot + bases + vectors
         sb = 4*A.ps_code.numel() + 8*(A.ps_code.numel()//256) + 8*(P.n_slices+1) + nc*8*(P.n_cols+P.n_rows)
         print(f"pair-slot stream: {A.ps_code.numel()/64/max(P.n_slices,1):.1f} slots per row stored for {P.nnz/P.n_rows:.1f} entries, {A.ps_wide} wide slices, {sb/1e6:.1f} MB moved")
     else: sb = stored if (v & 6) == 6 else (B if not (v & 2) else stored + (7*P.size if A.vcode is not None else 0))
