@@ -581,7 +581,11 @@ def main():
                     "pair_slots_per_row": (S._Ap.ps_code.numel() / 64 / max(Pp.n_slices, 1)) if S._Ap.ps_code is not None else None,
                     "address_unit_note": "on compressed storage this kernel is bound by vector-memory instructions per "
                                          "slice (16-20 cycles of the address unit each, any width), not by bytes: "
-                                         "tools/ubench/dispatch_rate.hip, DESIGN.md section 3",
+                                         "tools/ubench/dispatch_rate.hip, DESIGN.md section 3.  Diagnostic builds at 128^3 "
+                                         "(profiles/r03_spmv_velocity_experiments.txt): 18.7 us of the 29.9 remain with every "
+                                         "gather and code load an L1 hit (instruction issue), the 80 MB code stream adds ~10 us "
+                                         "that do not overlap, the gather misses 2.5 us; an LDS-window form with a fifth of the "
+                                         "gathers is no faster",
                     "note": "achieved = stored bytes (lossless 16-bit column codes and, with a dictionary, 1-byte value "
                             "codes; f64 arithmetic) / time; csr_equivalent_gbs prices the same launch at the metric's "
                             "12 B per nonzero and is NOT a fraction of anything.  At 128^3 the stored matrix fits the "
