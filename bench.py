@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the variant legs (zero guess, dictionaries off) and the 256^3 past-cache SpMV")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cg-merged", default=None, choices=["true", "false"],
+                    help="force the merged-reduction CG (OX_KSP_CG_MERGED: one synchronisation point, three kernels per "
+                         "iteration) for the one-column pressure solve")
     ap.add_argument("--cg-single-reduction", default=None, choices=["true", "false"],
                     help="force -ksp_cg_single_reduction for the CG solves (default: true on partitioned operators only)")
     ap.add_argument("--bcgs-merged", default=None, choices=["true", "false"],
@@ -323,6 +326,8 @@ def main():
                 so[k]["ksp_cg_single_reduction"] = args.cg_single_reduction == "true"
         if args.bcgs_merged is not None:
             so["tentative"]["ksp_bcgs_merged_reduction"] = args.bcgs_merged == "true"
+        if args.cg_merged is not None:
+            so["pressure"]["ksp_cg_merged_reduction"] = args.cg_merged == "true"
         S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                      solver_options=so, options=opts)
         return mesh, S_
@@ -519,12 +524,17 @@ def main():
         us = 1e3 * ms / max(n_its, 1.0)
         nq = S._Q.n_owned
         dcode = getattr(S._solver_p, "_dcode", None) is not None
-        vec = 8 * nq * 8 + 2 * nq * (1 if dcode else 8)
+        if cg_merged:  # mat-vec epilogue reads the diagonal; one update kernel: x, r, p, q | x, r, p, and the diagonal
+            vec = 8 * nq * 7 + 2 * nq * (1 if dcode else 8)
+        else:
+            vec = 8 * nq * 8 + 2 * nq * (1 if dcode else 8)
         spmv = stored_bytes(S._Ap)
         return {"us": us, "bytes_moved": int(spmv + vec), "spmv_bytes": int(spmv), "vector_bytes": int(vec),
                 "gbs": (spmv + vec) / (1e3 * us), "frac_of_hbm_peak": (spmv + vec) / (1e3 * us) / HBM_PEAK_GBS,
-                "kernels_per_iteration": 5}
+                "kernels_per_iteration": 3 if cg_merged else 5,
+                "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else "standard CG"}
 
+    cg_merged = bool(S._solver_p._cg_merged())  # the one-column pressure solve runs OX_KSP_CG_MERGED
     # (computed now: the variant legs below drop the dictionaries of this solver)
     piter_line = (pressure_iteration_line(phase_ms["pressure_solve"], mean_iterations(its)["pressure"])
                   if phase_ms.get("pressure_solve") else None)
@@ -541,7 +551,7 @@ def main():
         sA3, sA1 = stored_bytes(S._A, gd), stored_bytes(S._A, 1)
         sM3, sM1 = stored_bytes(S._M, gd), stored_bytes(S._M, 1)
         for name, tag, key, csr, moved in (
-                ("pressure_cg_spmv", 11, kp, b_p, stored_bytes(S._Ap)),
+                ("pressure_cg_spmv", 15 if cg_merged else 11, kp, b_p, stored_bytes(S._Ap)),
                 ("velocity_bcgs_spmv_v", 10 * gd + 2, ku, b_u, sA3), ("velocity_bcgs_spmv_t", 10 * gd + 3, ku, b_u, sA3),
                 ("velocity_bcgs_spmv_v_narrowed", 12, ku, b_u1, sA1), ("velocity_bcgs_spmv_t_narrowed", 13, ku, b_u1, sA1),
                 ("mass_cg_spmv", 10 * gd + 1, ku, b_u, sM3), ("mass_cg_spmv_narrowed", 11, ku, b_u1, sM1),
@@ -569,9 +579,10 @@ def main():
     cg = kernels.get("pressure_cg_spmv")
     roofline = None
     if cg:
-        roofline = {"kernel": ("k_spmv_ps<1,OX_EPI_DOT> (pressure-Poisson CG SpMV, SELL-64 pair-slot stream, f64)"
+        epi_name = "OX_EPI_CG_M2" if cg_merged else "OX_EPI_DOT"
+        roofline = {"kernel": (f"k_spmv_ps<1,{epi_name}> (pressure-Poisson CG SpMV, SELL-64 pair-slot stream, f64)"
                                if S._Ap.ps_code is not None else
-                               "k_spmv<1,OX_EPI_DOT,*> (pressure-Poisson CG SpMV, SELL-64, f64)"), "bound": "hbm",
+                               f"k_spmv<1,{epi_name},*> (pressure-Poisson CG SpMV, SELL-64, f64)"), "bound": "hbm",
                     # bytes the kernel really streams per launch (its stored matrix + x + y) / HIP-event time
                     "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg["frac_of_hbm_peak"],
                     "traffic": None, "traffic_detail": None,
@@ -671,7 +682,8 @@ def main():
     if args.pmc_child:  # what the parent needs to find this run's pressure SpMV in the counter CSV
         var = 7 if S._Ap.vcode is not None else (3 if Pp.frac16 > 0 else 1)
         grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)
-        prefix = "voidk_spmv_ps<1,1>" if S._Ap.ps_code is not None else f"voidk_spmv<1,1,{var}>"
+        epi = 5 if cg_merged else 1
+        prefix = f"voidk_spmv_ps<1,{epi}>" if S._Ap.ps_code is not None else f"voidk_spmv<1,{epi},{var}>"
         print(json.dumps({"pmc_child": True, "kernel_prefix": prefix, "grid_size": grid}), flush=True)
         return
 
@@ -716,7 +728,7 @@ def main():
                        # (Chronopoulos-Gear) and merged-reduction BiCGStab are the defaults there (oasisx_amd/ksp.py)
                        "krylov_sync_points_per_iteration": (
                            None if world == 1 else
-                           {"pressure cg": 1 if S._solver_p._method()[0] == _lib.KSP_CG_SINGLE else 2,
+                           {"pressure cg": 1 if (cg_merged or S._solver_p._method()[0] == _lib.KSP_CG_SINGLE) else 2,
                             "velocity bcgs": 2 if S._solver_u._method()[0] == _lib.KSP_BCGS_MERGED else 3,
                             "update cg": 1 if S._solver_c._method()[0] == _lib.KSP_CG_SINGLE else 2})},
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)

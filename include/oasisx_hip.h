@@ -66,6 +66,15 @@ extern "C" {
                               recurrence |s - omega t|^2, as PETSc's pipelined / improved BiCGStab variants do).
                               Same Krylov space and convergence test; iteration counts within +-2 of OX_KSP_BCGS */
 
+#define OX_KSP_CG_MERGED 5 /* "cg", one right-hand side, ONE synchronisation point and THREE kernels per iteration instead of
+                             two and five: the mat-vec q = A p also sums p.q and q.D^-1 q, from which alpha and -- with
+                             r' = r - alpha q:  r'.z' = r.z - 2 alpha q.z + alpha^2 q.D^-1 q,  q.z = p.q - beta_old p.q_old (z =
+                             D^-1 r = p - beta_old p_old, A symmetric), plain algebra without any orthogonality assumption --
+                             beta follow together; one kernel then updates x, r and p and sums the TRUE r.z, |z|^2 and p.q_old
+                             for the next point (the carried r.z is replaced every iteration: no drift; the convergence test
+                             sees the true |D^-1 r|, one point later: one surplus mat-vec per solve).  Same Krylov space;
+                             iteration counts equal to OX_KSP_CG's up to rounding.  With ncomp > 1 the call runs OX_KSP_CG */
+
 /* SELL-64 matrix: pattern + one value array (PETSc Mat on this path). */
 typedef struct {
   int64_t n_rows;            /* rows owned by this rank                                  */

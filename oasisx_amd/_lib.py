@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OX_LIB_PATH") or os.path.join(_HERE, "liboasisx_hip.so")  # override: tuning builds
 
-KSP_CG, KSP_BCGS, KSP_CG_SINGLE, KSP_BCGS_MERGED = 1, 2, 3, 4
+KSP_CG, KSP_BCGS, KSP_CG_SINGLE, KSP_BCGS_MERGED, KSP_CG_MERGED = 1, 2, 3, 4, 5
 CONVERGED_RTOL, CONVERGED_ATOL, CONVERGED_ITS = 2, 3, 4
 DIVERGED_ITS, DIVERGED_DTOL, DIVERGED_BREAKDOWN, DIVERGED_NANORINF = -3, -4, -5, -9
 

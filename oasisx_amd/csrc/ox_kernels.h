@@ -9,8 +9,10 @@
 #define OX_EPI_BCGS_T 3  // y = D^-1 A x, partial = {y.y, y.x_row}       (BiCGStab: t.t, t.s)
 #define OX_EPI_BCGS_T5 4 // y = D^-1 A x, partial = {y.y, y.x, aux.x, aux.y, x.x}  (merged-reduction BiCGStab:
                          //   t.t, t.s, rhat.s, rhat.t, s.s -- omega, rho and |r| from ONE reduction)
+#define OX_EPI_CG_M2 5   // y = A x, partial = {x.y, y.(D^-1 y)}   (merged-reduction CG: p.q and q.D^-1 q give alpha AND, by
+                         // r' = r - alpha q, the next r.z -- one synchronisation point; D^-1 through ox_spmv_set_epilogue_dinv)
 __host__ __device__ constexpr int ox_epi_nv(int epi, int nc) {
-  return epi == OX_EPI_NONE ? 0 : (epi == OX_EPI_BCGS_T ? 2 * nc : (epi == OX_EPI_BCGS_T5 ? 5 * nc : nc));
+  return epi == OX_EPI_NONE ? 0 : (epi == OX_EPI_BCGS_T ? 2 * nc : (epi == OX_EPI_BCGS_T5 ? 5 * nc : (epi == OX_EPI_CG_M2 ? 2 * nc : nc)));
 }
 
 #define OX_VEC_MAX_BLOCKS 4096  // upper bound of the grid cap of the BLAS-1 kernels (sizes the partial arrays)
@@ -115,6 +117,12 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
 int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
                  double *partial, const int *done, const ox_dist *dist, hipStream_t st);
 int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist);
+// optional 1-byte codes + dictionary of the diagonal the OX_EPI_CG_M2 epilogue multiplies by (nullptr: the f64 array)
+struct OxEpiDinv {
+  const uint8_t *code;
+  const double *dict;
+};
+void ox_spmv_set_epilogue_dinv(const uint8_t *code, const double *dict);
 int ox_reduce_partials(const double *partial, int nparts, int nv, double *sums, hipStream_t st);
 
 // ---- optional per-kernel HIP-event timing (bench.py: roofline.achieved is measured live, on the

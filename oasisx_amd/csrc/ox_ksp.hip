@@ -59,6 +59,27 @@ __device__ __forceinline__ void ksp_gather_t(const double *__restrict__ partial,
       if (i < nv) v[i] += partial[(size_t)p * nv + i];
   }
 }
+// v[0..NV) = this thread's share of `nparts` partial rows of exactly NV sums, up to U rows per thread requested together
+// (thread t takes rows t, t + T, ...: the order the generic gather sums in)
+template <int NV, int U, int NVT>
+__device__ __forceinline__ void ksp_gather_rows(const double *__restrict__ partial, int nparts, double (&v)[NVT]) {
+  const int T = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  for (int p0 = threadIdx.x; p0 < nparts; p0 += U * T) {
+    double t[U][NV];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * T;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t[u][i] = p < nparts ? partial[(size_t)p * NV + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += t[u][i];
+  }
+}
 template <int NVT>
 __device__ __forceinline__ void ksp_block_sum_t(double (&v)[NVT], int nv, double *lds /* [16 * NVT] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -89,7 +110,8 @@ template <int PH>
 __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
                                                                const double *__restrict__ partial,
                                                                int nparts, int nv, KspParams P, KspPart2 B) {
-  constexpr int NVT = ksp_ph_nv(PH) * OX_MAXC;
+  // (the merged-reduction CG is a one-column solver: 3 + 2 sums)
+  constexpr int NVT = PH == PH_CGM_IT ? ksp_ph_nv(PH) : ksp_ph_nv(PH) * OX_MAXC;
   __shared__ double red[16 * NVT];
   __shared__ double sums[NVT];
   __shared__ KspState sh;
@@ -97,7 +119,14 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
   ksp_state_load(&sh, S);
   double v[NVT];
-  ksp_gather_t<NVT>(partial, nparts, nv, v);
+  if constexpr (PH == PH_CGM_IT) {
+    // 8 392 x 2 partial sums of the pressure mat-vec at 128^3: every thread's rows requested in ONE round (the
+    // generic gather keeps 4 rows in flight)
+    ksp_gather_rows<2, 10>(partial, nparts, v);
+    v[2] = v[3] = v[4] = 0.0;
+  } else {
+    ksp_gather_t<NVT>(partial, nparts, nv, v);
+  }
   if (B.nv > 0) {  // second partial array of the point (single-reduction CG): its sums follow the first's
     double w[NVT];
     ksp_gather_t<NVT>(B.partial, B.nparts, B.nv, w);
@@ -351,6 +380,54 @@ __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S
     ox_st2(x, e, xx, two);
     ox_st2(vp, e, p, two);
   });
+}
+
+// Merged-reduction CG, the ONE vector kernel of an iteration (alpha and beta are both known behind the mat-vec's
+// synchronisation point, PH_CGM_IT):  x += alpha p;  r -= alpha q;  z = D^-1 r (not stored);  p = z + beta p;
+// partial = {r.z, z.z, p.q} -- the true sums, which replace the carried r.z / serve the convergence test at the next
+// point, and the new direction against the OLD q (= q_next . p_old, A being symmetric: see PH_CGM_IT).  7 vector passes
+// where k_cg_update1 + k_cg_update2 make 8, one launch and one synchronisation point less per iteration.
+template <int NC>
+__global__ __launch_bounds__(256) void k_cgm_update(int64_t n, const KspState *S, int c0, double *x, double *vr,
+                                                    const double *__restrict__ vq, KspDinv D, double *vp,
+                                                    double *partial) {
+  __shared__ double red[4 * 3 * NC];
+  __shared__ double dd[256];
+  if (S->done) return;
+  ksp_dinv_stage(D, dd);
+  double alpha[NC], beta[NC], s[3 * NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    alpha[c] = S->alpha[c0 + c];
+    beta[c] = S->beta[c0 + c];
+  }
+#pragma unroll
+  for (int i = 0; i < 3 * NC; ++i) s[i] = 0.0;
+  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t ra, int cb, int64_t rb, bool two) {
+    const double2 qq = ox_ld2(vq, e, two);
+    double2 r = ox_ld2(vr, e, two), p = ox_ld2(vp, e, two), xx = ox_ld2(x, e, two);
+    const double a0 = ox_sel<NC>(alpha, ca), a1 = ox_sel<NC>(alpha, cb);
+    const double d0 = KSP_DINV(ra), d1 = two ? KSP_DINV(rb) : 0.0;
+    xx.x = fma(a0, p.x, xx.x);
+    xx.y = fma(a1, p.y, xx.y);
+    r.x = fma(-a0, qq.x, r.x);
+    r.y = fma(-a1, qq.y, r.y);
+    const double z0 = d0 * r.x, z1 = d1 * r.y;
+    p.x = fma(ox_sel<NC>(beta, ca), p.x, z0);
+    p.y = fma(ox_sel<NC>(beta, cb), p.y, z1);
+    ox_st2(x, e, xx, two);
+    ox_st2(vr, e, r, two);
+    ox_st2(vp, e, p, two);
+    ox_acc<NC>(s, 0, ca, r.x, z0);
+    ox_acc<NC>(s, NC, ca, z0, z0);
+    ox_acc<NC>(s, 2 * NC, ca, p.x, qq.x);
+    if (two) {
+      ox_acc<NC>(s, 0, cb, r.y, z1);
+      ox_acc<NC>(s, NC, cb, z1, z1);
+      ox_acc<NC>(s, 2 * NC, cb, p.y, qq.y);
+    }
+  });
+  ksp_store_partial<3 * NC>(s, red, partial);
 }
 
 // Single-reduction CG (Chronopoulos & Gear) init: r = b - q (q = A x0) or r = b, x = 0; u = D^-1 r;
@@ -640,13 +717,13 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   const int nblk_spmv = (n_slices + 3) / 4;
   const int nb8 = (nblk_spmv + 7) & ~7;
   L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
-  L.nvec = ksp_type == OX_KSP_CG ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);  // (both BiCGStab variants: 6)
+  L.nvec = (ksp_type == OX_KSP_CG || ksp_type == OX_KSP_CG_MERGED) ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);  // (both BiCGStab variants: 6)
   L.state = 0;
   L.sums = ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
   L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (size_t)(ksp_prered_rows(L.nparts_max) + 1) * OX_MAX_NV));
   L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 5 * OX_MAXC);
-  L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * 2 * OX_MAXC);
+  L.vec0 = L.partial2 + ox_align(sizeof(double) * (size_t)L.nparts_max * 3 * OX_MAXC);
   L.vec_stride = ox_align(sizeof(double) * (size_t)n_cols * ncomp);
   L.narrow0 = L.vec0 + L.vec_stride * L.nvec;
   L.narrow_stride = ox_align(sizeof(double) * (size_t)n_cols);
@@ -665,7 +742,10 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
                           const KspParams &P, const ox_dist *dist, hipStream_t st, KspPart2 B = KspPart2{nullptr, 0, 0}) {
   {
     double *scr = sums + OX_PRERED_OFFSET;
-    if ((int64_t)nparts * nv >= OX_PRERED_MIN) {
+    // (the merged-reduction CG's scalar kernel requests up to 10 rows per thread in one round: worth a pre-reduction
+    // launch from 64 K sums on only)
+    const int64_t prered_min = PH == PH_CGM_IT ? 4 * OX_PRERED_MIN : OX_PRERED_MIN;
+    if ((int64_t)nparts * nv >= prered_min) {
       const int g = ksp_prered_rows(nparts);
       hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, st, partial, nparts, nv, scr);
       partial = scr;
@@ -750,6 +830,28 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
     OX_LAUNCH_CHECK();
     KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 0);
+    OX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// Merged-reduction CG: mat-vec with the three-sum epilogue, ONE synchronisation point (one all-reduce of
+// {p.q, q.D^-1 q, r.z, z.z, p.q_old} in a partitioned run), one update kernel -- 3 kernels per iteration instead of 5.
+template <int NC>
+static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
+  const int64_t n = C.A->n_rows;
+  const int *done = &C.S->done;
+  for (int k = 0; k < count; ++k) {
+    ox_spmv_set_epilogue_dinv(C.D.code, C.D.dict);
+    const int rc = ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_CG_M2, C.dinv, nullptr, C.partial, done, C.dist, C.st);
+    ox_spmv_set_epilogue_dinv(nullptr, nullptr);
+    if (rc) return -1;
+    KspParams Q = P;
+    Q.first = (first && k == 0) ? 1 : 0;
+    if (ksp_sync_point<PH_CGM_IT>(C.S, C.partial, C.nbs, 2 * NC, C.sums, Q, C.dist, C.st,
+                                  Q.first ? KspPart2{nullptr, 0, 0} : KspPart2{C.partial2, C.nb, 3 * NC}))
+      return -1;
+    hipLaunchKernelGGL((k_cgm_update<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.q, C.D, V.p, C.partial2);
     OX_LAUNCH_CHECK();
   }
   return 0;
@@ -896,6 +998,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
   const bool cg = ksp_type == OX_KSP_CG, cgs = ksp_type == OX_KSP_CG_SINGLE, bm = ksp_type == OX_KSP_BCGS_MERGED;
+  const bool cgm = ksp_type == OX_KSP_CG_MERGED;  // (one right-hand side only: ox_ksp_solve_dc)
   KspVecs V{};
   V.x = x;
   if (cgs) {
@@ -909,7 +1012,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     if (ox_spmv_dist(A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, nullptr, dist, st)) return -1;
     if (ksp_sync_point<PH_CGS_INIT>(C.S, C.partial, C.nb, 3 * NC, C.sums, P, dist, st, KspPart2{C.partial2, C.nbs, NC}))
       return -1;
-  } else if (cg) {
+  } else if (cg || cgm) {
     V.r = vec[0], V.p = vec[1], V.q = vec[2];
     if (guess && !ax0) {
       if (ox_spmv_dist(A, x, V.q, NC, OX_EPI_NONE, nullptr, nullptr, nullptr, nullptr, dist, st)) return -1;
@@ -934,6 +1037,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     const bool first = bm_first;
     bm_first = false;
     return cgs ? cgs_iterations<N_>(C, W, Q, check_every)
+           : cgm ? cgm_iterations<N_>(C, W, Q, check_every, first)
                : (cg ? cg_iterations<N_>(C, W, Q, check_every)
                      : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every, first) : bcgs_iterations<N_>(C, W, Q, check_every, first)));
   };
@@ -950,6 +1054,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
       const bool first = bm_first;
       bm_first = false;
       return cgs ? cgs_iterations<1>(C, V, P, count)
+             : cgm ? cgm_iterations<1>(C, V, P, count, first)
                  : (cg ? cg_iterations<1>(C, V, P, count)
                        : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count, first)));
     };
@@ -1046,8 +1151,10 @@ extern "C" int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *din
                                size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
                                const double *ax0, const uint8_t *dinv_code, const double *dinv_dict, int n_dinv_dict) {
   if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
-  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED)
+  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED &&
+      ksp_type != OX_KSP_CG_MERGED)
     OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
+  if (ksp_type == OX_KSP_CG_MERGED && ncomp > 1) ksp_type = OX_KSP_CG;  // (the merged form is the one-column solver)
   if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
   if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))
     OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes,

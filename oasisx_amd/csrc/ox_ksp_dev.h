@@ -22,9 +22,10 @@ struct KspParams {
   int c0;        // state column of launch column 0 (narrowed continuation: the one live column)
   int nc_total;  // columns of the solve
   int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
+  int first;         // merged-reduction CG: this synchronisation point is the first of the solve (no update kernel ran yet)
 };
 
-enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT, PH_BCGSM_B, PH_COUNT };
+enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT, PH_BCGSM_B, PH_CGM_IT, PH_COUNT };
 
 __device__ __forceinline__ int ksp_test(double rn, double bn, const KspParams &P) {
   if (!(rn == rn) || isinf(rn)) return OX_DIVERGED_NANORINF;
@@ -114,6 +115,46 @@ __device__ __forceinline__ void ksp_logic(KspState *S, const double *s_all, int 
         S->active[c] = 0;
         S->alpha[c] = 0.0;
         S->beta[c] = 0.0;
+      }
+    } else {
+      S->alpha[c] = 0.0;
+      S->beta[c] = 0.0;
+    }
+  } else if (PH == PH_CGM_IT) {
+    // Merged-reduction CG, the ONE point of an iteration, behind q = A p:
+    //   s = {p.q, q.D^-1 q | r.z, z.z, p.q_old of the update kernel that ran before (absent at the first point)}
+    // with z = D^-1 r.  The update r' = r - alpha q gives  r'.z' = r.z - 2 alpha q.z + alpha^2 q.D^-1 q  by algebra, and
+    // q.z = p.q - beta_old (q.p_old) because z = p - beta_old p_old, with q.p_old = p.(A p_old) = p.q_old (A symmetric),
+    // which the update kernel summed when it formed p.  No orthogonality is assumed anywhere, so beta is known HERE
+    // exactly as the two-point form would compute it, up to rounding, and x, r, p are updated by one kernel.  The
+    // carried r.z is replaced by the true one at every point: no drift.  The residual norm of iteration k is the
+    // true |z| its update kernel summed -- tested one point later (one surplus mat-vec per solve; the queued update
+    // is a no-op).
+    if (S->active[c]) {
+      int r = 0;
+      double pqo = 0.0;
+      if (!P.first) {
+        S->its[c] += 1;
+        S->rz[c] = s[2 * NC + c];
+        S->rn[c] = sqrt(s[3 * NC + c]);
+        pqo = s[4 * NC + c];
+        r = ksp_test(S->rn[c], S->bn[c], P);
+        if (r == 0 && S->its[c] >= P.max_it) r = OX_DIVERGED_ITS;
+      }
+      const double pq = s[c];
+      if (r == 0 && (pq == 0.0 || !(pq == pq))) r = (pq == pq) ? OX_DIVERGED_BREAKDOWN : OX_DIVERGED_NANORINF;
+      if (r) {
+        S->reason[c] = r;
+        S->active[c] = 0;
+        S->alpha[c] = 0.0;
+        S->beta[c] = 0.0;
+      } else {
+        const double a = S->rz[c] / pq;
+        const double qz = fma(-S->beta[c], pqo, pq);  // (beta of the previous iteration; 0 at the first point: p = z)
+        const double rz_new = fma(a, fma(a, s[NC + c], -2.0 * qz), S->rz[c]);
+        S->alpha[c] = a;
+        S->beta[c] = rz_new / S->rz[c];
+        S->rz[c] = rz_new;  // (replaced by the update kernel's own sum at the next point)
       }
     } else {
       S->alpha[c] = 0.0;
@@ -260,5 +301,5 @@ constexpr bool ksp_is_init(int ph) { return ph == PH_CG_INIT || ph == PH_BCGS_IN
 // k_ksp_scalar: a 1024-thread block has 128 registers per thread, OX_MAX_NV-wide arrays spilled)
 __host__ __device__ constexpr int ksp_ph_nv(int ph) {
   return ph == PH_CG_INIT ? 3 : ph == PH_CG_A ? 1 : ph == PH_CG_B ? 2 : ph == PH_BCGS_INIT ? 2 : ph == PH_BCGS_1 ? 1
-       : ph == PH_BCGS_2 ? 2 : ph == PH_BCGS_3 ? 2 : ph == PH_CGS_INIT ? 4 : ph == PH_CGS_IT ? 3 : 5;
+       : ph == PH_BCGS_2 ? 2 : ph == PH_BCGS_3 ? 2 : ph == PH_CGS_INIT ? 4 : ph == PH_CGS_IT ? 3 : 5;  // (PH_BCGSM_B, PH_CGM_IT: 5)
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
                                               const double *__restrict__ aux,
                                               double *__restrict__ partial,
                                               const int *__restrict__ done_flag,
-                                              const int32_t *__restrict__ slice_list, int n_list) {
+                                              const int32_t *__restrict__ slice_list, int n_list, OxEpiDinv ED) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   __shared__ double red[4 * NV];
   __shared__ double dict[(VAR & 4) ? 256 : 1];
@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
           s[3 * NC + c] = fma(ah, acc[c], s[3 * NC + c]);
           s[4 * NC + c] = fma(xs, xs, s[4 * NC + c]);
         }
+        if (EPI == OX_EPI_CG_M2) {
+          const double dd = ED.code ? ED.dict[ED.code[row]] : dinv[row];
+          s[c] = fma(x[row * NC + c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], dd * acc[c], s[NC + c]);
+        }
       }
     }
   }
@@ -181,14 +186,15 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 // (B) codes + bases of the first two groups; (C) gathers; dictionary reads from a wave-private LDS
 // copy (no block barrier).
 // ---------------------------------------------------------------------------------------
+// (the one-column OX_EPI_CG_M2 form sits at 81 registers: held to 80 = 6 waves per SIMD, where the OX_EPI_DOT form runs)
 template <int NC, int EPI>
-__global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__restrict__ x,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 && EPI == OX_EPI_CG_M2) ? 6 : 1, 8))) void k_spmv_ps(ox_sell A, const double *__restrict__ x,
                                                  double *__restrict__ y,
                                                  const double *__restrict__ dinv,
                                                  const double *__restrict__ aux,
                                                  double *__restrict__ partial,
                                                  const int *__restrict__ done_flag /* never null */,
-                                                 const int32_t *__restrict__ slice_list, int n_list) {
+                                                 const int32_t *__restrict__ slice_list, int n_list, OxEpiDinv ED) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-B load from an 8-B aligned address
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -236,10 +242,14 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
     double xe[NC], ae[NC], de = 1.0;  // epilogue operands: requested now, used after the products
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      xe[c] = (EPI == OX_EPI_DOT || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) ? x[rowc * NC + c] : 0.0;
+      xe[c] = (EPI == OX_EPI_DOT || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5 || EPI == OX_EPI_CG_M2) ? x[rowc * NC + c] : 0.0;
       ae[c] = (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T5) ? aux[rowc * NC + c] : 0.0;
     }
     if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) de = dinv[rowc];
+    // (through its dictionary: 1 B per row, hot in the L2 -- the vector kernels read the same codes; requested here with
+    // the other epilogue operands: fetched after the products instead it added two dependent rounds to every wave,
+    // 37.2 -> 39.5 us)
+    if (EPI == OX_EPI_CG_M2) de = ED.code ? ED.dict[ED.code[rowc]] : dinv[rowc];
     double acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
@@ -350,6 +360,10 @@ __global__ __launch_bounds__(256) void k_spmv_ps(ox_sell A, const double *__rest
           s[3 * NC + c] = fma(ae[c], acc[c], s[3 * NC + c]);
           s[4 * NC + c] = fma(xe[c], xe[c], s[4 * NC + c]);
         }
+        if (EPI == OX_EPI_CG_M2) {
+          s[c] = fma(xe[c], acc[c], s[c]);
+          s[NC + c] = fma(acc[c], de * acc[c], s[NC + c]);
+        }
       }
     }
     g += per;
@@ -399,6 +413,11 @@ extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench
   return 0;
 }
 
+// the Jacobi diagonal of the OX_EPI_CG_M2 epilogue through its value dictionary (ox_ksp.hip sets it around its mat-vecs;
+// one call at a time per process: include/oasisx_hip.h)
+static OxEpiDinv g_epi_dinv{nullptr, nullptr};
+void ox_spmv_set_epilogue_dinv(const uint8_t *code, const double *dict) { g_epi_dinv = OxEpiDinv{code, dict}; }
+
 static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
                             const double *dinv, const double *aux, double *partial, const int *done,
                             hipStream_t st, const int32_t *list, int n_list) {
@@ -415,14 +434,14 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
-  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list)
+  hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list, g_epi_dinv)
 #define OX_SPMV_CASE(NC, E)                                                                     \
   if (ncomp == NC && epi == E) {                                                                \
     if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                      \
     if (var == 7 && pairs) {                                                                    \
       const int *dz = done ? done : ox_zero_flag(st);                                             \
       if (!dz) OX_FAIL("ox_spmv: no device flag");                                              \
-      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list); \
+      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list, g_epi_dinv); \
     } else if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                              \
     else if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                \
     else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \
@@ -437,7 +456,8 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   OX_SPMV_CASE(NC, OX_EPI_DOT)       \
   OX_SPMV_CASE(NC, OX_EPI_BCGS_V)    \
   OX_SPMV_CASE(NC, OX_EPI_BCGS_T)    \
-  OX_SPMV_CASE(NC, OX_EPI_BCGS_T5)
+  OX_SPMV_CASE(NC, OX_EPI_BCGS_T5)   \
+  OX_SPMV_CASE(NC, OX_EPI_CG_M2)
   OX_SPMV_NC(1) OX_SPMV_NC(2) OX_SPMV_NC(3)
 #undef OX_SPMV_NC
 #undef OX_SPMV_CASE

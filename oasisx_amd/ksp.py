@@ -10,6 +10,10 @@ Option mapping (PETSc string keys, as the reference passes them):
   ksp_cg_single_reduction  PETSc's option name: the Chronopoulos-Gear recurrences with one merged
             reduction (one all-reduce) per iteration; default: true on mesh-partitioned operators,
             false (PETSc's default, faster there) on a single GPU
+  ksp_cg_merged_reduction  (extension) one-column "cg" solves: OX_KSP_CG_MERGED -- alpha and beta from ONE synchronisation
+            point (one all-reduce), three kernels per iteration instead of five, no extra vectors; same Krylov space,
+            same test on the true |D^-1 r|.  Default: true on operators of at most 2^20 local rows (launch-bound
+            iterations: the partitions of a multi-GPU run, small meshes), false above
   ksp_bcgs_merged_reduction  (extension; also selected by ksp_type ibcgs / pipebcgs / fbcgsr, PETSc's reduced-
             synchronisation BiCGStab variants): two merged reductions (all-reduces) per iteration instead of
             three -- omega, rho and the residual norm from one reduction behind the second mat-vec
@@ -36,6 +40,7 @@ from .la import SellMatrix
 __all__ = ["KSPSolver"]
 
 DIRECT_RTOL = 1e-12
+CG_MERGED_MAX_ROWS = 1 << 20
 
 
 class KSPSolver:
@@ -68,6 +73,7 @@ class KSPSolver:
         self._dinv_version = -1
         self._every = {}
         self._every_measured = set()
+        self._merged_auto = None  # decided at the first one-column CG solve on this operator (see _cg_merged)
 
     def solve(self, b, x: Function) -> int:
         """Solve A x = b for one scalar field (reference ksp.py:71-78); returns the
@@ -119,6 +125,24 @@ class KSPSolver:
         return (meth, float(o.get("ksp_rtol", 1e-5)), float(o.get("ksp_atol", 1e-50)),
                 int(o.get("ksp_max_it", 10000)), False)
 
+    def _cg_merged(self) -> bool:
+        """One-column CG solves: the merged-reduction recurrences (OX_KSP_CG_MERGED)?  Default: on operators of at
+        most CG_MERGED_MAX_ROWS (local) rows, where an iteration is bound by its launches and synchronisation points
+        (tools/cg_iter_bench.py, P1 pressure matrix: 64^3 22.5 against 27.7 us per iteration, 128^3 70 against 66,
+        256^3 482 against 432); the option forces either."""
+        v = self._options.get("ksp_cg_merged_reduction")
+        if v is not None:
+            return v not in (False, 0, "false", "0", "False")
+        if self._A is None:
+            return False
+        if getattr(self, "_merged_auto", None) is None:
+            rows = self._A.pattern.n_rows
+            if self._A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
+                # every rank must run the same recurrences (they differ in their collectives): the largest part decides
+                rows = int(self._comm.allreduce(rows, op="max"))
+            self._merged_auto = rows <= CG_MERGED_MAX_ROWS
+        return self._merged_auto
+
     def solve_block(self, B: FieldStorage, X: FieldStorage, ax0: FieldStorage | None = None):
         """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
         Returns the list of per-component converged reasons.  ``ax0``: the product A X of the initial
@@ -130,6 +154,8 @@ class KSPSolver:
         A = self._A
         nc = X.nc
         meth, rtol, atol, max_it, direct = self._method()
+        if meth in (_lib.KSP_CG, _lib.KSP_CG_SINGLE) and nc == 1 and self._cg_merged():
+            meth = _lib.KSP_CG_MERGED
         guess = bool(self._options.get("ksp_initial_guess_nonzero", False)) and not direct
         st = _lib.current_stream()
         dev = X.dev().device

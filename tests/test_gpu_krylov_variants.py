@@ -197,3 +197,65 @@ def test_merged_reduction_bicgstab_matches_standard_bicgstab_and_oracle(hip, dim
             assert abs(it[c] - its) <= (2 if merged else 1), (merged, it, its)
             assert np.abs(xs[:, c] - sol).max() < 1e-7 * max(np.abs(sol).max(), 1.0)
     assert np.abs(out[True][0] - out[False][0]).max() < 1e-7 * np.abs(out[False][0]).max()
+
+
+@pytest.mark.parametrize("dim,N,deg,pairs", [(2, 24, 2, "never"), (3, 10, 1, "never"), (3, 16, 1, "always"), (3, 8, 2, "never")])
+def test_merged_reduction_cg_matches_standard_cg_and_oracle(hip, dim, N, deg, pairs):
+    """OX_KSP_CG_MERGED (ksp_cg_merged_reduction: one synchronisation point and three kernels per iteration -- alpha AND
+    beta from the sums of the mat-vec's epilogue, r'.z' = r.z - 2 alpha q.z + alpha^2 q.D^-1 q) against the standard
+    recurrences and the oracle's PETSc-convention CG: same converged reason, iteration counts within 1 (the convergence
+    test sees the same true |D^-1 r|), same solution to solver tolerance; zero and nonzero initial guess, the iteration
+    limit, a right-hand side that converges at once; the generic and the pair-slot SpMV kernel."""
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oracle import ipcs_oracle as O
+
+    V, A, Acsr = _system(dim, N, deg)
+    if pairs == "always":
+        assert A.freeze(pairs="always") and A.ps_code is not None
+    n = V.num_dofs
+    x = V.x.cpu().numpy()
+    b = np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1]) + 1e-3 * np.sin(5.0 * x[:, 0] * x[:, -1])
+    B = FieldStorage(n, 1, "cuda")
+    B.dev()[:, 0] = torch.from_numpy(b).cuda()
+    sol, reason, its, _ = O.jacobi_cg(Acsr, b, rtol=1e-10, atol=1e-50)
+    out = {}
+    for merged in (True, False):
+        ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
+                               "ksp_cg_merged_reduction": merged, "ksp_cg_single_reduction": False})
+        ksp.setOperators(A)
+        X = FieldStorage(n, 1, "cuda")
+        rs = ksp.solve_block(B, X)
+        out[merged] = (X.dev()[:, 0].cpu().numpy().copy(), ksp.iterations[0], rs[0], float(ksp.last_result.rnorm[0]))
+        assert rs[0] == reason == 2
+        assert abs(ksp.iterations[0] - its) <= 1, (merged, ksp.iterations, its)
+        assert np.abs(out[merged][0] - sol).max() < 1e-8 * max(np.abs(sol).max(), 1.0)
+    assert abs(out[True][1] - out[False][1]) <= 1
+    assert abs(out[True][3] - out[False][3]) <= 0.5 * max(out[True][3], out[False][3])  # the same (true) residual norm, up to one iteration
+    # nonzero initial guess: fewer iterations, same answer; a guess that already satisfies the test: zero iterations
+    opts = {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_initial_guess_nonzero": True,
+            "ksp_cg_merged_reduction": True, "ksp_cg_single_reduction": False}
+    ksp = KSPSolver(None, opts)
+    ksp.setOperators(A)
+    X = FieldStorage(n, 1, "cuda")
+    X.dev()[:, 0] = torch.from_numpy(sol * (1.0 + 1e-4)).cuda()
+    assert ksp.solve_block(B, X)[0] == 2 and 0 < ksp.iterations[0] < its
+    assert np.abs(X.dev()[:, 0].cpu().numpy() - sol).max() < 1e-8 * max(np.abs(sol).max(), 1.0)
+    its_g = ksp.iterations[0]
+    assert ksp.solve_block(B, X)[0] == 2 and ksp.iterations[0] <= 1 < its_g + 1
+    # iteration limit: DIVERGED_ITS after exactly max_it iterations, x = the max_it-th iterate of the standard form
+    xs = {}
+    for merged in (True, False):
+        ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-14, "ksp_max_it": 5,
+                               "ksp_cg_merged_reduction": merged, "ksp_cg_single_reduction": False})
+        ksp.setOperators(A)
+        X = FieldStorage(n, 1, "cuda")
+        assert ksp.solve_block(B, X)[0] == -3 and ksp.iterations[0] == 5
+        xs[merged] = X.dev()[:, 0].cpu().numpy().copy()
+    assert np.abs(xs[True] - xs[False]).max() < 1e-12 * np.abs(xs[False]).max()
+    # b = 0: converged at once (atol), x = 0
+    ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-30,
+                           "ksp_cg_merged_reduction": True})
+    ksp.setOperators(A)
+    Z, X = FieldStorage(n, 1, "cuda"), FieldStorage(n, 1, "cuda")
+    assert ksp.solve_block(Z, X)[0] in (2, 3) and ksp.iterations[0] == 0 and float(X.dev().abs().max()) == 0.0
