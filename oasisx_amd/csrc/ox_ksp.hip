@@ -138,7 +138,10 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   }
   nv += B.nv;
   ksp_block_sum_t<NVT>(v, nv, red);  // contains a __syncthreads(): sh is complete after it
-  if (!ksp_is_init(PH) && sh.done) return;  // uniform: nothing is stored
+  if (!ksp_is_init(PH) && sh.done) {  // uniform: the state stays as it is; the host's copy of it is still due
+    if (P.mirror) ksp_state_store(P.mirror, &sh);
+    return;
+  }
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < NVT; ++i) sums[i] = v[i];  // (the logic indexes the sums at run time: from LDS, not scratch)
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   }
   __syncthreads();
   ksp_state_store(S, &sh);
+  if (P.mirror) ksp_state_store(P.mirror, &sh);  // the host reads the state of a batch from here: no copy kernel in the stream
 }
 
 // The same on the direct xGMI transport: the block's sums are all-reduced over the ranks' windows
@@ -177,7 +181,10 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
   }
   __syncthreads();
   ox_p2p_allreduce_block(vals, nv, ar, stage);
-  if (idle) return;
+  if (idle) {
+    if (P.mirror) ksp_state_store(P.mirror, &sh);
+    return;
+  }
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < OX_MAX_NV; ++i) v[i] = i < nv ? vals[i] : 0.0;
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
   }
   __syncthreads();
   ksp_state_store(S, &sh);
+  if (P.mirror) ksp_state_store(P.mirror, &sh);
 }
 
 // Logic only (distributed runs: the sums were all-reduced over the ranks first).
@@ -193,16 +201,20 @@ template <int PH>
 __global__ __launch_bounds__(64) void k_ksp_logic(KspState *S, const double *__restrict__ sums, KspParams P) {
   __shared__ KspState sh;
   __shared__ double sv[OX_MAX_NV];
-  if (!ksp_is_init(PH) && S->done) return;
   ksp_state_load(&sh, S);
   if (threadIdx.x < OX_MAX_NV) sv[threadIdx.x] = sums[threadIdx.x];
   __syncthreads();
+  if (!ksp_is_init(PH) && sh.done) {
+    if (P.mirror) ksp_state_store(P.mirror, &sh);
+    return;
+  }
   if (threadIdx.x == 0) {
     for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, sv, c, P);
     ksp_finish(&sh, P.nc_total);
   }
   __syncthreads();
   ksp_state_store(S, &sh);
+  if (P.mirror) ksp_state_store(P.mirror, &sh);
 }
 
 // ------------------------------- vector kernels ------------------------------------------
@@ -736,6 +748,16 @@ extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, i
 }
 
 static KspState *g_state_host = nullptr;
+// Where the last synchronisation point of the batch being queued writes the host's copy of the state (pinned, host
+// mapped: g_state_host[1 + slot]); nullptr outside ksp_run_ahead.  An in-stream copy of these 400 bytes is a blit
+// kernel of ~18 us plus ~6 us of stream bubble (rocprofv3, r03: 0.7 ms of a 16-ms pressure solve at 8 iterations a
+// batch); the kernel's own posted stores cost it ~1 us.
+static KspState *g_batch_mirror = nullptr;
+static inline KspParams ksp_last_point(const KspParams &P, int k, int count) {
+  KspParams Q = P;
+  Q.mirror = (k + 1 == count) ? g_batch_mirror : nullptr;
+  return Q;
+}
 
 template <int PH>
 static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, double *sums,
@@ -828,7 +850,7 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
     KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
     hipLaunchKernelGGL((k_cg_update1<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.q, C.D, C.partial);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_CG_B, C.partial, C.nb, 2 * NC);
+    if (ksp_sync_point<PH_CG_B>(C.S, C.partial, C.nb, 2 * NC, C.sums, ksp_last_point(P, k, count), C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 0);
     OX_LAUNCH_CHECK();
   }
@@ -846,7 +868,7 @@ static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
     const int rc = ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_CG_M2, C.dinv, nullptr, C.partial, done, C.dist, C.st);
     ox_spmv_set_epilogue_dinv(nullptr, nullptr);
     if (rc) return -1;
-    KspParams Q = P;
+    KspParams Q = ksp_last_point(P, k, count);
     Q.first = (first && k == 0) ? 1 : 0;
     if (ksp_sync_point<PH_CGM_IT>(C.S, C.partial, C.nbs, 2 * NC, C.sums, Q, C.dist, C.st,
                                   Q.first ? KspPart2{nullptr, 0, 0} : KspPart2{C.partial2, C.nb, 3 * NC}))
@@ -868,7 +890,7 @@ static int cgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
                        C.dinv, C.partial);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(C.A, V.u, V.w, NC, OX_EPI_DOT, nullptr, nullptr, C.partial2, done, C.dist, C.st)) return -1;
-    if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, P, C.dist, C.st,
+    if (ksp_sync_point<PH_CGS_IT>(C.S, C.partial, C.nb, 2 * NC, C.sums, ksp_last_point(P, k, count), C.dist, C.st,
                                   KspPart2{C.partial2, C.nbs, NC}))
       return -1;
   }
@@ -893,7 +915,7 @@ static int bcgs_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P
     hipLaunchKernelGGL((k_bcgs_x<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s,
                        V.t, C.partial, 0);
     OX_LAUNCH_CHECK();
-    KSP_SYNC(PH_BCGS_3, C.partial, C.nb, 2 * NC);
+    if (ksp_sync_point<PH_BCGS_3>(C.S, C.partial, C.nb, 2 * NC, C.sums, ksp_last_point(P, k, count), C.dist, C.st)) return -1;
   }
   return 0;
 }
@@ -914,7 +936,7 @@ static int bcgsm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &
     hipLaunchKernelGGL((k_bcgs_s<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.r, V.v, V.s);
     OX_LAUNCH_CHECK();
     if (ox_spmv_dist(C.A, V.s, V.t, NC, OX_EPI_BCGS_T5, C.dinv, V.rhat, C.partial, done, C.dist, C.st)) return -1;
-    if (ksp_sync_point<PH_BCGSM_B>(C.S, C.partial, C.nbs, 5 * NC, C.sums, P, C.dist, C.st)) return -1;
+    if (ksp_sync_point<PH_BCGSM_B>(C.S, C.partial, C.nbs, 5 * NC, C.sums, ksp_last_point(P, k, count), C.dist, C.st)) return -1;
     hipLaunchKernelGGL((k_bcgs_xp<NC>), dim3(C.nb), dim3(256), 0, C.st, n, C.S, P.c0, V.x, V.r, V.rhat, V.p, V.s, V.t, V.v, 0);
     OX_LAUNCH_CHECK();
   }
@@ -944,21 +966,24 @@ template <class Iterate>
 static int ksp_run_ahead(const KspCtx &C, Iterate &&iterate, int batch, int &it, int max_it) {
   for (int i = 0; i < 2; ++i)
     if (!g_state_ev[i]) OX_HIP(hipEventCreateWithFlags(&g_state_ev[i], hipEventDisableTiming));
-  auto copy = [&](int slot) -> int {
-    OX_HIP(hipMemcpyAsync(g_state_host + 1 + slot, C.S, sizeof(KspState), hipMemcpyDeviceToHost, C.st));
+  // batch -> state in g_state_host[1 + slot]: written by the batch's last synchronisation point itself (g_batch_mirror)
+  auto queue = [&](int slot) -> int {
+    g_state_host[1 + slot].done = 0;
+    g_batch_mirror = g_state_host + 1 + slot;
+    const int rc = iterate(batch);
+    g_batch_mirror = nullptr;
+    if (rc) return -1;
     OX_HIP(hipEventRecord(g_state_ev[slot], C.st));
     return 0;
   };
-  if (iterate(batch)) return -1;
+  if (queue(0)) return -1;
   it += batch;
-  if (copy(0)) return -1;
   int cur = 0;
   for (;;) {
     const bool more = it <= max_it;  // (the kernels stop by themselves at max_it: reason DIVERGED_ITS)
     if (more) {
-      if (iterate(batch)) return -1;
+      if (queue(1 - cur)) return -1;
       it += batch;
-      if (copy(1 - cur)) return -1;
     }
     OX_HIP(hipEventSynchronize(g_state_ev[cur]));
     if (C.dist && ox_dist_status(C.dist)) return -1;

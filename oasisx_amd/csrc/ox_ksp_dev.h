@@ -23,6 +23,7 @@ struct KspParams {
   int nc_total;  // columns of the solve
   int max_restarts;  // BiCGStab restarts allowed on a rho/omega breakdown (0 = PETSc: report -5)
   int first;         // merged-reduction CG: this synchronisation point is the first of the solve (no update kernel ran yet)
+  KspState *mirror;  // host-mapped copy of the state, written by the LAST synchronisation point of a batch (nullptr: none)
 };
 
 enum { PH_CG_INIT = 0, PH_CG_A, PH_CG_B, PH_BCGS_INIT, PH_BCGS_1, PH_BCGS_2, PH_BCGS_3, PH_CGS_INIT, PH_CGS_IT, PH_BCGSM_B, PH_CGM_IT, PH_COUNT };
