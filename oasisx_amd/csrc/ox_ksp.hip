@@ -124,6 +124,14 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
     // generic gather keeps 4 rows in flight)
     ksp_gather_rows<2, 10>(partial, nparts, v);
     v[2] = v[3] = v[4] = 0.0;
+  } else if (nv == 1) {  // one right-hand side: a thread's <= 10 rows requested in ONE round (same order of sums as the
+    ksp_gather_rows<1, 10>(partial, nparts, v);  // generic gather, which keeps 4 rows in flight: 2-3 rounds)
+#pragma unroll
+    for (int i = 1; i < NVT; ++i) v[i] = 0.0;
+  } else if (nv == 2 && NVT >= 2) {
+    ksp_gather_rows<(NVT >= 2 ? 2 : 1), 10>(partial, nparts, v);
+#pragma unroll
+    for (int i = 2; i < NVT; ++i) v[i] = 0.0;
   } else {
     ksp_gather_t<NVT>(partial, nparts, nv, v);
   }
