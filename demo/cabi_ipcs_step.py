@@ -104,8 +104,9 @@ class IPCS:
     """FractionalStep_AB_CN for Dirichlet velocity data on the whole boundary, no pressure condition,
     low_memory_version=True, Jacobi-BiCGStab / Jacobi-CG -- every operation a C-ABI call."""
 
-    def __init__(self, coords, cells, u_deg, rtol=1e-11, compress=False):
+    def __init__(self, coords, cells, u_deg, rtol=1e-11, compress=False, cg_merged=False):
         self.L, self.lib = L, lib = load_binding()
+        self.cg_pressure = L.KSP_CG_MERGED if cg_merged else L.KSP_CG  # OX_KSP_CG_MERGED: one synchronisation point per iteration
         self.dev = dev = Device(L, lib)
         self.gdim = d = coords.shape[1]
         self.rtol = rtol
@@ -230,7 +231,7 @@ class IPCS:
         ck(lib.ox_assemble_div_vector(1, vv.degree, cs, vv.cell_dofs, C.byref(qv.adj), nq, self.U, -1.0 / dt, self.B2, None),
            "b2")  # :538-546
         ck(lib.ox_remove_mean(nq, nq, self.B2, None, float(nq), None, None), "nullspace.remove")  # :573-574
-        self._solve(self.L.KSP_CG, self.Ap, self.dinvP, self.B2, self.DP, 1, "pressure")  # :578
+        self._solve(self.cg_pressure, self.Ap, self.dinvP, self.B2, self.DP, 1, "pressure")  # :578
         ck(lib.ox_remove_mean(nq, nq, self.DP, self.wq, self.vol, None, None), "mean shift")  # :579-591
         ck(lib.ox_axpby(nq, 1.0, self.P, 1.0, self.DP, self.PS, None), "ps = p + dp")  # :604
         ck(lib.ox_spmv(C.byref(self.M), self.U, self.B3, d, None, None), "M u")  # :615
@@ -265,9 +266,9 @@ def tg(dim, nu):
     return [u, v, w][:dim], p
 
 
-def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=False):
+def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=False, cg_merged=False):
     coords, cells = box_mesh(dim, N)
-    S = IPCS(coords, cells, u_deg, rtol, compress)
+    S = IPCS(coords, cells, u_deg, rtol, compress, cg_merged)
     fns, pf = tg(dim, nu)
     X, Xq = S.x_v.T, S.x_q.T
     S.set_field(S.U2, np.stack([f(X, -dt) for f in fns], axis=1))
@@ -294,8 +295,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default=None)
     ap.add_argument("--compress", action="store_true", help="value dictionaries and the pair-slot stream for M, K, Ap")
+    ap.add_argument("--cg-merged", action="store_true", help="OX_KSP_CG_MERGED for the pressure solve")
     a = ap.parse_args()
-    r = run(a.dim, a.N, a.udeg, a.steps, compress=a.compress)
+    r = run(a.dim, a.N, a.udeg, a.steps, compress=a.compress, cg_merged=a.cg_merged)
     ex = [f(r["x_v"].T, r["t"]) for f in tg(a.dim, 0.01)[0]]
     print("C-ABI step: n_u", r["x_v"].shape[0], "n_p", r["x_q"].shape[0], "max |u - u_exact| =",
           float(max(np.abs(r["u"][:, i] - ex[i]).max() for i in range(a.dim))), "pressure iterations", r["its_pressure"])

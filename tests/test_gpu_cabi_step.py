@@ -14,16 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dim,N,udeg,compress", [(2, 12, 2, False), (3, 5, 2, False), (3, 6, 1, False), (3, 6, 2, True),
-                                                 (2, 16, 1, True)])
-def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress):
+@pytest.mark.parametrize("dim,N,udeg,compress,merged", [(2, 12, 2, False, False), (3, 5, 2, False, True), (3, 6, 1, False, False),
+                                                        (3, 6, 2, True, True), (2, 16, 1, True, False)])
+def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, merged):
     from oracle import ipcs_oracle as O
     from oracle.cpu_baseline import match_by_coordinates
     from tests.helpers import KRYLOV
 
     out = str(tmp_path / "step.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "cabi_ipcs_step.py"), "--dim", str(dim), "-N", str(N),
-                        "--udeg", str(udeg), "--steps", "2", "--out", out] + (["--compress"] if compress else []),
+                        "--udeg", str(udeg), "--steps", "2", "--out", out] + (["--compress"] if compress else [])
+                       + (["--cg-merged"] if merged else []),  # (OX_KSP_CG_MERGED for the pressure solve)
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     g = np.load(out)
