@@ -237,11 +237,34 @@ def make_workload(name, N, np, torch):
     return {"nu": nu, "dt": dt, "box": box, "fns": fns, "p": pres, "desc": desc, "analytic": name != "cavity"}
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher (no WORLD_SIZE in the environment): this process -- which has
+    not touched the GPU -- starts the driver's own N > 1 command line as a CHILD process (one rank per GPU under
+    ``torch.distributed.run``), relays its output and returns its exit code."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=dict(os.environ, OX_BENCH_SELF_LAUNCHED="1")).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # a launch line whose rank count is not the one asked for must not print a figure
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                         f"(use `python bench.py --gpus N`, or torch.distributed.run --nproc-per-node N ... --gpus N)")
 
     def log(*a):
         if args.verbose and rank == 0:
@@ -391,11 +414,28 @@ def main():
         el = time.perf_counter() - t0
         res = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
                "workload": f"{W2['desc']}, {N}^3x6 tets P{args.udeg}-P1, nu={W2['nu']}, dt={W2['dt']:g}",
-               "krylov_iterations_per_step": mean_iterations(its2), "setup_s": t_set}
+               "krylov_iterations_per_step": mean_iterations(its2), "krylov_iterations_series": iteration_series(its2),
+               "setup_s": t_set}
         if W2["analytic"]:
             Xd2 = S2._Vi[0][0].x[: S2._n_u].T
             res["max_nodal_error_u_vs_analytic"] = max(
                 float((S2._U.dev()[: S2._n_u][:, i] - f(Xd2, clk["t"])).abs().max()) for i, f in enumerate(W2["fns"]))
+        if not args.no_cpu:
+            # the next step of THIS workload on the host (oracle/ipcs_cpu.c on its own mesh, numbering and operators,
+            # fed the device's state through the dof coordinates) against the device's: a timed figure with its check
+            try:
+                from oracle.cpu_baseline import run_cpu_baseline
+
+                chk = run_cpu_baseline(
+                    S2, clk, W2["dt"], W2["nu"], {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess},
+                    lambda X, t: np.stack([np.asarray(f(X, t), dtype=np.float64) for f in W2["fns"]]), gpu_step=one,
+                    mesh_def=(q0, q1, [N, N, N]), threads_1=False, scipy_check=False)
+                res["cpu_cross_check"] = {k: chk[k] for k in (
+                    "gpu_vs_cpu_rel_l2_u", "gpu_vs_cpu_rel_l2_p", "gpu_vs_cpu_max_abs_u", "gpu_vs_cpu_shared", "value", "cores",
+                    "seconds", "setup_seconds", "krylov_iterations", "gpu_krylov_iterations") if k in chk}
+                res["cpu_cross_check"]["step"] = warmup + steps + 1
+            except Exception as e:
+                res["cpu_cross_check"] = {"error": repr(e)}
         del S2, m2
         torch.cuda.empty_cache()
         return res
@@ -498,6 +538,10 @@ def main():
 
     def mean_iterations(its):
         return {k: float(np.mean([np.max(i[k]) if len(i[k]) else 0 for i in its])) for k in its[0]}
+
+    def iteration_series(its):
+        """Per timed step: the lockstep's iteration count of each solve (the slowest column)."""
+        return {k: [int(np.max(i[k])) if len(i[k]) else 0 for i in its] for k in its[0]}
 
     elapsed, its = timed_run(args.steps, args.warmup, True)
     phase_ms = {k: sum(a.elapsed_time(b) for a, b in v) / args.steps for k, v in phase_events.items() if k != "_on"}
@@ -625,15 +669,26 @@ def main():
 
     # ---- variant legs on the same solver (reported beside the headline, never instead of it) -------
     variants = {}
+    steady = None
     if world == 1 and not args.no_extras and not args.pmc_child:
         sv = min(args.steps, 5)
 
-        def leg(label, note):
-            el, it = timed_run(sv, 1, False)
+        def leg(label, note, warm=1):
+            el, it = timed_run(sv, warm, False)
             kt = kernel_table()
             variants[label] = {"value": sv / el, "unit": "steps/s", "ms_per_step": 1e3 * el / sv, "steps": sv,
                                "krylov_iterations_per_step": mean_iterations(it),
+                               "krylov_iterations_series": iteration_series(it),
                                "pressure_cg_spmv": kt.get("pressure_cg_spmv"), "note": note}
+            return variants[label]
+
+        # the headline's settings past the start-up transient: steps 41.. of the same run (the driver's command line
+        # times steps 6-25, where the previous field is still a better and better initial guess step after step)
+        done = args.warmup + args.steps
+        first = max(done, 40)
+        steady = dict(leg("steady_state", "the headline's own solver and settings, timed after step %d" % first,
+                          warm=first - done), first_timed_step=first + 1)
+        del variants["steady_state"]
 
         guess_now = not args.zero_guess
         for sol in (S._solver_u, S._solver_p, S._solver_c):
@@ -704,12 +759,21 @@ def main():
         # both device transports' exchange times, measured here (collective)
         transport_us = {"velocity_space": comm.time_transports(S._Vi[0][0]), "pressure_space": comm.time_transports(S._Q)}
     nnz_glob = [Pu.nnz, Pp.nnz]
+    per_rank = None
     if world > 1:
         import torch.distributed as dist
 
         tn = torch.tensor(nnz_glob, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tn)
         nnz_glob = [int(v) for v in tn.tolist()]
+        # every rank's share: owned rows and ghosts of both spaces, its peers, what ITS communicator reports
+        Vu_, Q_ = S._Vi[0][0], S._Q
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "cells": int(Vu_.local_cells.shape[0]),
+                "velocity_rows": int(Vu_.n_owned), "velocity_ghosts": int(Vu_.n_local - Vu_.n_owned),
+                "pressure_rows": int(Q_.n_owned), "pressure_ghosts": int(Q_.n_local - Q_.n_owned),
+                "peers": [int(p_) for p_ in (Vu_.halo["peers"] if Vu_.halo is not None else [])], "comm": comm.info()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         mean_its = mean_iterations(its)
         short = {"tg": "Taylor-Green", "beltrami": "Beltrami (Ethier-Steinman)", "cavity": "lid-driven cavity"}[args.workload]
@@ -733,6 +797,13 @@ def main():
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
                        if world > 1 else None,
                        "transport_check": transport_check, "transport_exchange_us": transport_us,
+                       # N > 1: the rank count the library's RCCL communicator reports (ncclCommCount; None in a gloo
+                       # rehearsal, which has none), and every rank's rows / ghosts / peers
+                       "rccl_nranks": (None if world == 1 or not per_rank[0]["comm"]["rccl"] else
+                                       sorted({r_["comm"]["nranks"] for r_ in per_rank})),
+                       "ranks": per_rank,
+                       "launched_by": "bench.py --gpus N (self-launched torch.distributed.run child)"
+                       if os.environ.get("OX_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "python"),
                        # all-reduces per Krylov iteration on a partitioned operator: single-reduction CG
                        # (Chronopoulos-Gear) and merged-reduction BiCGStab are the defaults there (oasisx_amd/ksp.py)
                        "krylov_sync_points_per_iteration": (
@@ -743,6 +814,8 @@ def main():
             "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
+            "krylov_iterations_series": iteration_series(its),  # per timed step (the warm start's transient shows here)
+            "steady_state": steady,  # 5 steps after step 40 with the same solver and settings
             # the last step's solves, column by column: |D^-1 b|, final |D^-1 r| (what the convergence test compares with
             # rtol |D^-1 b| and atol = 1e-14) and iterations -- on the z-extruded field the w column's right-hand side is
             # what the other solves' tolerance leaves of the z-invariance (|D^-1 b_w| ~ 3e-8 |D^-1 b_u|); it is solved to

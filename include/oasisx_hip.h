@@ -64,7 +64,11 @@ extern "C" {
                               iteration instead of three -- rhat.v behind the first mat-vec; t.t, t.s, rhat.s,
                               rhat.t, s.s behind the second give omega, rho and |r| together (|r| by the
                               recurrence |s - omega t|^2, as PETSc's pipelined / improved BiCGStab variants do).
-                              Same Krylov space and convergence test; iteration counts within +-2 of OX_KSP_BCGS */
+                              Same Krylov space; iteration counts within +-2 of OX_KSP_BCGS.  The convergence test
+                              compares the RECURRENCE norm sqrt(max(0, s.s - 2 omega t.s + omega^2 t.t)), not the norm
+                              of the stored residual, and result->rnorm reports that value: near 1e-10..1e-12 relative
+                              it can sit below the true residual norm, so set rtol with that margin (the standard
+                              variant tests the stored residual) */
 
 #define OX_KSP_CG_MERGED 5 /* "cg", one right-hand side, ONE synchronisation point and THREE kernels per iteration instead of
                              two and five: the mat-vec q = A p also sums p.q and q.D^-1 q, from which alpha and -- with
@@ -330,6 +334,15 @@ int ox_assemble_matrix(int kind, int degree, const ox_cells *cells, const int32_
  * the weights of assemble_scalar(phi*dx): fracstep.py:585-590). */
 int ox_assemble_weights(int degree, const ox_cells *cells, const ox_adj *adj, int64_t n_rows,
                         double *w, void *stream);
+/* Load vector of a non-constant source: b[row] = int f phi_row dx, the `force * v * dx` of a body force that is a
+ * UFL expression (fracstep.py:284-289, assembled once at :387-390) and the `inner(function, v) * dx` of a
+ * Projector (function.py:75,110-113).  The caller tabulates: fq[cell][q] = f at the n_q quadrature points of every
+ * cell (kernel cell order), wphi[q][i] = w_q phi_i(x_q) on the reference simplex (any rule, any of the n_d basis
+ * functions of the space `adj` belongs to); the kernel forms, per row, sum over its (cell, i) pairs in adjacency
+ * order of |det J_cell| * sum_q wphi[q][i] fq[cell][q] -- one lane per row, no atomics, fixed order.
+ * n_q * n_d <= 4096. */
+int ox_assemble_load_vector(const ox_cells *cells, const ox_adj *adj, int64_t n_rows, int n_d, int n_q,
+                            const double *wphi, const double *fq, double *b, void *stream);
 
 /* ---- A4 + S3 + S1, fused: assemble_first (fracstep.py:432-469) ---------------------- */
 /* With uab = 1.5*u1 - 0.5*u2 already formed (ox_axpby), for every row:
@@ -431,9 +444,17 @@ int ox_profile_get(int tag, long long key, long long *count, double *total_ms); 
                                    n_rows for SpMV records (tells the pressure matrix from the
                                    velocity matrix), -1 = any */
 
+/* roctx ranges on the calling host thread (rocprofv3 --kernel-trace --marker-trace segments the trace by them):
+ * FractionalStep_AB_CN brackets its six phase methods (fracstep.py:411-658) with them -- what PETSc's log stages are
+ * to the reference.  No-ops without librocprofiler-sdk-roctx / libroctx64 or without a profiler attached. */
+int ox_range_push(const char *name);
+int ox_range_pop(void);
+
 /* ---- H1 + collectives: mesh-partitioned runs (one process per GPU, RCCL) -------------- */
 int ox_comm_unique_id(char *id128);   /* ncclGetUniqueId on rank 0 (broadcast it out of band) */
 int ox_comm_create(const char *id128, int rank, int nranks, void **comm_out); /* ncclCommInitRank */
+int ox_comm_info(void *comm, int *nranks, int *rank, int *device); /* ncclCommCount / UserRank / CuDevice: what the
+                                   communicator itself reports (bench.py's N > 1 line prints it); NULL outputs are skipped */
 int ox_comm_destroy(void *comm);
 /* Halo plan of one function space on communicator `comm`.  send_idx: device, owned rows to
  * pack, grouped per peer by send_off; ghosts arrive contiguously per peer at

@@ -174,6 +174,7 @@ SIGNATURES = {
     "ox_assemble_matrix": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
                                 C.POINTER(ox_sell), _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
     "ox_assemble_weights": (_I, [_I, C.POINTER(ox_cells), C.POINTER(ox_adj), _L, _P, _P]),
+    "ox_assemble_load_vector": (_I, [C.POINTER(ox_cells), C.POINTER(ox_adj), _L, _I, _I, _P, _P, _P, _P]),
     "ox_assemble_first": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
                                C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
                                _D, _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P]),
@@ -199,8 +200,11 @@ SIGNATURES = {
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),
+    "ox_range_push": (_I, [C.c_char_p]),
+    "ox_range_pop": (_I, []),
     "ox_comm_unique_id": (_I, [C.c_char_p]),
     "ox_comm_create": (_I, [C.c_char_p, _I, _I, C.POINTER(_P)]),
+    "ox_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ox_comm_destroy": (_I, [_P]),
     "ox_dist_create": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P,
                             C.POINTER(_L), _L, _L, C.POINTER(_P)]),

@@ -164,8 +164,18 @@ struct FirstArgs {
   const uint8_t *Mc, *Kc;
   const double *Md, *Kd;
   int nMd, nKd;
-  int dbg;  // tuning only (OX_AF_DBG): bit 0 skips the pair loop, bit 1 the epilogue -- wrong results
+#ifdef OX_DIAG
+  int dbg;  // DIAGNOSTIC BUILDS ONLY (-DOX_DIAG, tools/build_diag.sh; never the product .so): OX_AF_DBG bit 0 skips the
+            // pair loop, bit 1 the epilogue -- wrong results, for timing the two halves
+#endif
 };
+#ifdef OX_DIAG
+#define OX_AF_SKIP_PAIRS(F) ((F).dbg & 1)
+#define OX_AF_SKIP_EPILOGUE(F) ((F).dbg & 2)
+#else
+#define OX_AF_SKIP_PAIRS(F) false
+#define OX_AF_SKIP_EPILOGUE(F) false
+#endif
 
 template <int GDIM, int DEG, int KIND, int PW, bool DICT = false, int U = 1>
 __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
   // rounds of a pair (adjacency -> cell dofs + geometry -> coefficient gathers) are paid once per U
   // pairs.  The wide (vertex-row) bins run ONE wave per SIMD (their accumulators fill the LDS), so
   // nothing else hides those ~3 us: with U = 1 the loop sat at 7 us per pair for 0.5 us of arithmetic.
-  for (int t0 = 0; t0 < ((F.dbg & 1) ? 0 : T); t0 += U) {
+  for (int t0 = 0; t0 < (OX_AF_SKIP_PAIRS(F) ? 0 : T); t0 += U) {
     int e[U], iloc[U];
     bool ok[U];
     uint8_t pos[U][PW];
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
   }
   // epilogue: stream the slice (coalesced 16-B values, 8-B columns)
   const int64_t row = (int64_t)slice * 64 + lane;
-  const int npair = (F.dbg & 2) ? 0 : width >> 1;
+  const int npair = OX_AF_SKIP_EPILOGUE(F) ? 0 : width >> 1;
   double2 *__restrict__ av = reinterpret_cast<double2 *>(A.vals + base) + lane;
   if constexpr (KIND != OX_KIND_CONV) {
     for (int k = 0; k < npair; ++k) {
@@ -522,13 +532,14 @@ extern "C" int ox_assemble_first_au(int degree, const ox_cells *cells, const int
   if (M->slice_ptr != A->slice_ptr || K->slice_ptr != A->slice_ptr)
     OX_FAIL("ox_assemble_first: M, K and A must share one sparsity pattern");
   if (!(dt > 0.0)) OX_FAIL("ox_assemble_first: dt=%g", dt);
-  static int dbg = -1;
-  if (dbg < 0) {
-    const char *e = getenv("OX_AF_DBG");
-    dbg = e ? atoi(e) : 0;
-  }
   FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, a_u1, 1.0 / dt, nu,
-              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict, dbg};
+              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict};
+#ifdef OX_DIAG
+  {
+    const char *e = getenv("OX_AF_DBG");
+    F.dbg = e ? atoi(e) : 0;
+  }
+#endif
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
   const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
                                            bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
@@ -591,6 +602,38 @@ extern "C" int ox_assemble_weights(int degree, const ox_cells *cells, const ox_a
   OX_W_CASE(2, 1) OX_W_CASE(2, 2) OX_W_CASE(3, 1) OX_W_CASE(3, 2)
 #undef OX_W_CASE
   OX_FAIL("ox_assemble_weights: unsupported gdim=%d degree=%d", g, degree);
+}
+
+// b[row] = sum_(cell e, local i) |det J_e| sum_q wphi[q][i] fq[e][q]: the load vector of a tabulated source
+// (include/oasisx_hip.h).  The reference table sits in LDS; every lane walks its own row's cells.
+__global__ __launch_bounds__(256) void k_load_vector(ox_cells cells, ox_adj adj, int64_t n_rows, int n_d, int n_q,
+                                                     const double *__restrict__ wphi, const double *__restrict__ fq,
+                                                     double *__restrict__ b) {
+  extern __shared__ double tab[];  // [n_q][n_d]
+  for (int k = threadIdx.x; k < n_q * n_d; k += blockDim.x) tab[k] = wphi[k];
+  __syncthreads();
+  const int gs = cells.gdim == 2 ? 6 : 10, ia = cells.gdim * cells.gdim;
+  double s = 0.0;
+  OX_ADJ_WALK_BEGIN
+  const double *__restrict__ f = fq + (size_t)e * n_q;
+  double v = 0.0;
+  for (int q = 0; q < n_q; ++q) v = fma(tab[q * n_d + i], f[q], v);
+  s = fma(cells.geom[(size_t)e * gs + ia], v, s);
+  OX_ADJ_WALK_END
+  if (row < n_rows) b[row] = s;
+}
+
+extern "C" int ox_assemble_load_vector(const ox_cells *cells, const ox_adj *adj, int64_t n_rows, int n_d, int n_q,
+                                       const double *wphi, const double *fq, double *b, void *stream) {
+  if (!cells || !adj || !wphi || !fq || !b) OX_FAIL("ox_assemble_load_vector: null argument");
+  if (cells->gdim != 2 && cells->gdim != 3) OX_FAIL("ox_assemble_load_vector: gdim=%d", cells->gdim);
+  if (n_d < 1 || n_q < 1 || (int64_t)n_d * n_q > 4096) OX_FAIL("ox_assemble_load_vector: n_d=%d n_q=%d", n_d, n_q);
+  const int nblk = (adj->n_slices + 3) / 4;
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(k_load_vector, dim3(nblk), dim3(256), (size_t)n_d * n_q * sizeof(double), ox_stream(stream), *cells,
+                     *adj, n_rows, n_d, n_q, wphi, fq, b);
+  OX_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------

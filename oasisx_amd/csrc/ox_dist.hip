@@ -42,6 +42,16 @@ extern "C" int ox_comm_create(const char *id128, int rank, int nranks, void **co
   return 0;
 }
 
+extern "C" int ox_comm_info(void *comm, int *nranks, int *rank, int *device) {
+  if (!comm) OX_FAIL("ox_comm_info: null communicator");
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  int v = 0;
+  if (nranks) { OX_NCCL(ncclCommCount(c, &v)); *nranks = v; }
+  if (rank) { OX_NCCL(ncclCommUserRank(c, &v)); *rank = v; }
+  if (device) { OX_NCCL(ncclCommCuDevice(c, &v)); *device = v; }
+  return 0;
+}
+
 extern "C" int ox_comm_destroy(void *comm) {
   if (comm) ncclCommDestroy(static_cast<ncclComm_t>(comm));
   return 0;

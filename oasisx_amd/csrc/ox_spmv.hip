@@ -1092,3 +1092,41 @@ extern "C" int ox_profile_get(int tag, long long key, long long *count, double *
   if (total_ms) *total_ms = t;
   return 0;
 }
+
+// ---- roctx ranges (the reference leaves tracing to PETSc's -log_view stages) -------------------
+// ox_range_push / ox_range_pop bracket a phase of the time step on the HOST thread; rocprofv3 --marker-trace
+// (with --kernel-trace) then segments the trace by phase.  librocprofiler-sdk-roctx is looked up at the first
+// call (no link-time dependency); without it, or without a profiler attached, the calls do nothing.
+#include <dlfcn.h>
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+int g_roctx_state = 0;  // 0 = not looked up, 1 = available, -1 = absent
+void roctx_lookup() {
+  g_roctx_state = -1;
+  const char *names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+  for (const char *n : names) {
+    void *h = dlopen(n, RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) continue;
+    g_roctx_push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+    g_roctx_pop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+    if (g_roctx_push && g_roctx_pop) {
+      g_roctx_state = 1;
+      return;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ox_range_push(const char *name) {
+  if (g_roctx_state == 0) roctx_lookup();
+  if (g_roctx_state == 1 && name) g_roctx_push(name);
+  return 0;
+}
+
+extern "C" int ox_range_pop(void) {
+  if (g_roctx_state == 1) g_roctx_pop();
+  return 0;
+}

@@ -1032,8 +1032,10 @@ class FieldStorage:
         self._shared = self._dev.device.type == "cpu"
         self._host = self._dev.numpy()[: self.n] if self._shared else None
         self._out = False
-        # bumped whenever the block may have been written from outside the solver's own kernels (a host
-        # check-out copied back, ``mark_written``): FractionalStep_AB_CN keeps "u still equals u1" on it
+        # bumped whenever the block MAY have been written: every hand-out of a writable view -- a host check-out,
+        # ``dev()``, ``ptr()`` (DirichletBC.apply, KSPSolver.solve_block and any ``S._U.dev()[...] = ...`` go through
+        # them) -- counts as a write.  FractionalStep_AB_CN keeps "u still equals u1 bit for bit" on it and reads the
+        # two blocks through ``rdev()`` / ``rptr()`` (read-only by contract) while that matters.
         self.generation = 0
 
     def mark_written(self):
@@ -1050,15 +1052,30 @@ class FieldStorage:
             self._out = True
         return self._host
 
-    def dev(self) -> torch.Tensor:
+    def _sync(self) -> torch.Tensor:
         if self._out:
             self._dev[: self.n].copy_(torch.from_numpy(self._host))
             self._out = False
             self.generation += 1
         return self._dev
 
+    def dev(self) -> torch.Tensor:
+        """The device block, writable: counts as a write (see ``generation``)."""
+        self._sync()
+        self.generation += 1
+        return self._dev
+
     def ptr(self):
+        """Device pointer for a kernel that may write the block: counts as a write."""
         return C.c_void_p(self.dev().data_ptr())
+
+    def rdev(self) -> torch.Tensor:
+        """The device block for READING only (the caller promises not to write through it)."""
+        return self._sync()
+
+    def rptr(self):
+        """Device pointer for a kernel that only reads the block."""
+        return C.c_void_p(self._sync().data_ptr())
 
 
 class Vector:

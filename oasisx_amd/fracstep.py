@@ -43,6 +43,24 @@ def _degree(element):
     return int(element[1])
 
 
+def _phase(fn):
+    """roctx range around a phase method (``ox_range_push/pop``: rocprofv3 --marker-trace segments a trace by
+    phase; two no-op C calls otherwise)."""
+    import functools
+
+    name = ("oasisx::" + fn.__name__).encode()
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        self._lib.ox_range_push(name)
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._lib.ox_range_pop()
+
+    return wrapped
+
+
 class _RotationalUpdate:
     """The linear form int (p + dp - xi nu div(u)) q dx of the rotational pressure update
     (reference fracstep.py:240): M_Q (p + dp) - xi nu int div(u) q."""
@@ -177,7 +195,11 @@ class FractionalStep_AB_CN:
         self._options = dict(options)
         if body_force is None:
             body_force = (0.0,) * gdim
-        self._body_force = [float(f) for f in body_force]
+        # per component: a float, a Constant, a spatial expression f(x) (x: (3, npts) -> (npts,)) or a Function on
+        # the component space -- `force * v * dx` is assembled ONCE (reference fracstep.py:284-289,387-390)
+        self._body_force = [f if (callable(f) or isinstance(f, Function)) else float(f) for f in body_force]
+        if len(self._body_force) != gdim:
+            raise ValueError(f"body_force: {gdim} components expected")
 
         self._compile_and_allocate_forms()
         self._preassemble()
@@ -263,19 +285,34 @@ class FractionalStep_AB_CN:
                                            _lib.ptr(self._wV), st), "ox_assemble_weights")
         _lib.check(lib.ox_assemble_weights(Q.degree, C.byref(self._cells), C.byref(self._adj_q), Q.n_owned,
                                            _lib.ptr(self._wQ), st), "ox_assemble_weights")
-        f = torch.tensor(self._body_force, dtype=torch.float64, device=dev)
-        self._B0.dev()[: Vi.n_owned] = self._wV.unsqueeze(1) * f.unsqueeze(0)
+        B0 = self._B0.dev()
+        for i, f in enumerate(self._body_force):
+            if isinstance(f, Function):  # a field of the component space: int f v dx = M f
+                if getattr(f.function_space, "scalar", f.function_space) is not Vi:
+                    raise ValueError("body_force: a Function must live on the velocity component space")
+                src = f._storage.rdev()[:, 0 if f._comp is None else f._comp].contiguous().unsqueeze(1)
+                tmp = torch.zeros(Vi.n_local, 1, dtype=torch.float64, device=dev)
+                self._M.mult(src, tmp, 1)
+                B0[: Vi.n_owned, i] = tmp[: Vi.n_owned, 0]
+            elif callable(f):  # a spatial expression: tabulated at quadrature points, summed by ox_assemble_load_vector
+                from .function import load_vector, metadata_points
+
+                q = metadata_points({"quadrature_degree": self._options.get("body_force_quadrature_degree")}, Vi.degree)
+                B0[: Vi.n_owned, i] = load_vector(Vi, f, self._geom, q)[: Vi.n_owned]
+            else:
+                B0[: Vi.n_owned, i] = self._wV * float(f)
         vol = float(self._wQ.sum().item())  # assemble_scalar(1*dx) + allreduce (:581-584)
         self._vol = vol if self._part is None else float(self._comm.allreduce(vol))
 
     # ------------------------------------------------------------------------------------
+    @_phase
     def assemble_first(self, dt: float, nu: float):
         """Reference fracstep.py:411-472: A = M/dt + C/2 + nu K/2 and the part of the RHS that
         depends on the previous time step, b_k = (M/dt - C/2 - nu K/2) u_k^{n-1} + b0_k."""
         lib, st = self._lib, _lib.current_stream()
         n = self._n_u * self._gdim
         # u_ab = 1.5 u_1 - 0.5 u_2 (:432-434)
-        _lib.check(lib.ox_axpby(n, 1.5, self._U1.ptr(), -0.5, self._U2.ptr(), self._UAB.ptr(), st), "ox_axpby")
+        _lib.check(lib.ox_axpby(n, 1.5, self._U1.rptr(), -0.5, self._U2.rptr(), self._UAB.ptr(), st), "ox_axpby")
         Vi = self._Vi[0][0]
         nb, bptr, bsl, bw = Vi.pattern.bins_args()
         # With a nonzero initial guess the tentative solve starts from u (= u1 bit for bit unless someone
@@ -288,7 +325,7 @@ class FractionalStep_AB_CN:
         _lib.check(lib.ox_assemble_first_au(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
                                             C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
                                             self._A.ref(), self._M.ref(), self._K.ref(),
-                                            self._UAB.ptr(), self._U1.ptr(), self._B0.ptr(), self._BFIRST.ptr(),
+                                            self._UAB.rptr(), self._U1.rptr(), self._B0.rptr(), self._BFIRST.ptr(),
                                             float(dt), float(nu), nb, bptr, bsl, bw, st,
                                             self._B3.ptr() if want_au else None), "ox_assemble_first")
         self._A.version += 1
@@ -299,9 +336,10 @@ class FractionalStep_AB_CN:
         # NOTE (reference :470): rows of the FIRST component's BCs only
         for bcu in self._bcs_u[0]:  # identity rows; (A @ u1)[row] = u1[row] there, in the same launch
             self._A.zero_rows(bcu._rows_dev, 1.0, self._B3.ptr() if want_au else None,
-                              self._U1.ptr() if want_au else None, self._gdim)
+                              self._U1.rptr() if want_au else None, self._gdim)
         self._AU1_valid = want_au
 
+    @_phase
     def velocity_tentative_assemble(self):
         """rhs1_k = b_first_k + int p* dv/dx_k (reference fracstep.py:474-506)."""
         Vi, Q = self._Vi[0][0], self._Q
@@ -313,6 +351,7 @@ class FractionalStep_AB_CN:
                                                      self._PS.ptr(), self._BFIRST.ptr(), 1.0, self._RHS1.ptr(),
                                                      _lib.current_stream()), "ox_assemble_grad_vector")
 
+    @_phase
     def velocity_tentative_solve(self):
         """Apply the Dirichlet values to the RHS and solve the gdim tentative-velocity systems
         (reference fracstep.py:508-525).  Returns (diff, errors)."""
@@ -322,14 +361,15 @@ class FractionalStep_AB_CN:
             for bc in self._bcs_u[i]:
                 bc.apply(self._rhs1[i].x)
         n = self._n_u * gdim
-        _lib.check(lib.ox_axpby(n, 1.0, self._U.ptr(), 0.0, None, self._WRK.ptr(), st), "ox_axpby")
+        _lib.check(lib.ox_axpby(n, 1.0, self._U.rptr(), 0.0, None, self._WRK.ptr(), st), "ox_axpby")
         ax0 = None
         if getattr(self, "_AU1_valid", False):  # one use per assemble_first, and only if u still is u1
             self._AU1_valid = False
             # u was copied into u1 at the end of the last step (solve()); since then neither block has been
-            # written by one of this class's phases (they clear the token) nor from outside (host check-outs
-            # copied back, interpolate, KSPSolver.solve bump FieldStorage.generation): no device compare,
-            # no host synchronisation
+            # written by one of this class's phases (they clear the token; this class reads the two blocks through
+            # rptr() meanwhile) nor from outside: EVERY hand-out of a writable view or pointer -- host check-outs,
+            # dev(), ptr(): DirichletBC.apply, KSPSolver.solve/solve_block, interpolate, S._U.dev()[...] = ... --
+            # bumps FieldStorage.generation.  No device compare, no host synchronisation
             same = getattr(self, "_u_is_u1", None) == (self._U.generation, self._U1.generation)
             if self._part is not None and getattr(self._comm, "size", 1) > 1:
                 # every rank must take the same branch: the skipped mat-vec carries a halo exchange
@@ -345,6 +385,7 @@ class FractionalStep_AB_CN:
         diff = float(sum(np.sqrt(out[i]) for i in range(gdim)))
         return diff, errors
 
+    @_phase
     def pressure_assemble(self, dt: float):
         """b2 = -(1/dt) int div(u) q (reference fracstep.py:527-551)."""
         Vi, Q = self._Vi[0][0], self._Q
@@ -358,6 +399,7 @@ class FractionalStep_AB_CN:
         for bcp in self._bcs_p:  # homogeneous Dirichlet condition on the correction (:549-550)
             bcp.apply_homogeneous(self._b2.x)
 
+    @_phase
     def pressure_solve(self, nu: float | None = None, rotational: bool = False):
         """Solve the pressure-correction problem (reference fracstep.py:553-605)."""
         lib, st = self._lib, _lib.current_stream()
@@ -385,6 +427,7 @@ class FractionalStep_AB_CN:
             _lib.check(lib.ox_axpby(nq, 1.0, self._P.ptr(), 1.0, self._DP.ptr(), self._PS.ptr(), st), "ox_axpby")
         return converged
 
+    @_phase
     def velocity_update(self, dt) -> np.ndarray:
         """M u_k = M u*_k - dt int dphi/dx_k v (reference fracstep.py:607-658; un-BC'd mass
         matrix, no Dirichlet re-imposition, exactly as the reference)."""

@@ -44,14 +44,15 @@ def grad(u: Function) -> Grad:
 class Projector:
     def __init__(self, function, space, bcs=None, petsc_options=None, jit_options=None,
                  form_compiler_options=None, metadata=None):
-        if bcs:
-            raise NotImplementedError("Projector: Dirichlet conditions on the projection are not supported")
         lib = _lib.load()
+        self._bcs = list(bcs or [])
         self._function = function
         self._space = space
         self._metadata = metadata or {}
         mesh = space.mesh
         self._dg = isinstance(space, DGSpace)
+        if self._bcs and self._dg:
+            raise NotImplementedError("Projector: Dirichlet conditions on a discontinuous space")
         if self._dg:
             # Discontinuous P1 target (test_projector.py:26-35): the mass matrix is block diagonal, one
             # (gdim+1) x (gdim+1) block per cell and component; its inverse is applied cell by cell in closed
@@ -84,6 +85,25 @@ class Projector:
                                           _lib.current_stream()), "ox_assemble_matrix")
         self._A.version += 1
         dev = mesh.device
+        if self._bcs:
+            # assemble_matrix(lhs, bcs=bcs) (function.py:69-70): rows AND columns of the constrained dofs -> identity;
+            # the untouched matrix is kept for the lifting of the right-hand side (function.py:114-115)
+            for bc in self._bcs:
+                if getattr(bc, "_V", None) is None:
+                    bc.create_bc(space)
+                elif bc._V is not space:
+                    raise ValueError("Projector: a Dirichlet condition created on another space")
+            self._A0 = SellMatrix(space.pattern, symmetric=True, name="projector_mass_unconstrained")
+            self._A0.vals.copy_(self._A.vals)
+            self._A0.version += 1
+            is_bc = torch.zeros(space.n_local, dtype=torch.uint8, device=dev)
+            for bc in self._bcs:
+                is_bc[bc._dofs_dev.to(torch.int64)] = 1
+            _lib.check(lib.ox_zero_rows_cols(self._A.ref(), _lib.ptr(is_bc), 1.0, _lib.current_stream()),
+                       "ox_zero_rows_cols")
+            self._A.version += 1
+            self._G = FieldStorage(space.n_local, 1, dev)  # the Dirichlet values as a field, zero elsewhere
+            self._L = FieldStorage(space.n_local, 1, dev)  # its image under the unconstrained matrix
         self._B = FieldStorage(space.n_local, 1, dev)
         self._X = FieldStorage(space.n_local, 1, dev)
         self._b = Function(space, "b", self._B, 0)
@@ -98,10 +118,12 @@ class Projector:
             lib, st = _lib.load(), _lib.current_stream()
             if isinstance(f, Grad):  # assemble_vector(inner(grad(u), v) * dx)
                 Vu = f.u.function_space
+                # one column of an interleaved block is gathered into a buffer this object OWNS until the next
+                # assembly (a temporary would be released before the kernel runs)
+                us = f.u._storage
+                self._ucol = us.rdev() if us.nc == 1 else us.rdev()[:, f.u._comp].contiguous()
                 _lib.check(lib.ox_dg1_grad_rhs(Vu.degree, C.byref(self._cells), _lib.ptr(Vu.cell_dofs),
-                                               C.c_void_p(f.u._storage.dev().data_ptr() if f.u._storage.nc == 1 else
-                                                          f.u._storage.dev()[:, f.u._comp].contiguous().data_ptr()),
-                                               self._B.ptr(), st), "ox_dg1_grad_rhs")
+                                               C.c_void_p(self._ucol.data_ptr()), self._B.ptr(), st), "ox_dg1_grad_rhs")
             elif isinstance(f, Function) and f.function_space is self._space:  # b = M f
                 _lib.check(lib.ox_dg1_mass(0, C.byref(self._cells), self._space.dim, f._storage.ptr(), self._B.ptr(), st),
                            "ox_dg1_mass")
@@ -109,16 +131,35 @@ class Projector:
                 raise TypeError("Projector into a DG space: `function` must be grad(u) of a Lagrange field or a "
                                 "Function on the space")
             return
+        A0 = self._A0 if self._bcs else self._A
         if isinstance(f, Function):
-            self._A.mult(f._storage.dev(), self._B.dev(), 1)
+            src = f._storage.rdev() if f._storage.nc == 1 else f._storage.rdev()[:, f._comp].contiguous().unsqueeze(1)
+            A0.mult(src, self._B.dev(), 1)
         elif hasattr(f, "assemble_rhs_into"):
             f.assemble_rhs_into(self._B)
         elif callable(f):
-            self._B.dev()[: self._space.n_local, 0] = load_vector(self._space, f, self._geom,
-                                                                 (metadata_points(self._metadata, self._space.degree)))
+            load_vector(self._space, f, self._geom, metadata_points(self._metadata, self._space.degree),
+                        out=self._B.dev()[:, 0])
         else:
             raise TypeError("Projector: `function` must be a Function on the space, a callable f(x) or provide "
                             "assemble_rhs_into()")
+        if self._bcs:
+            # apply_lifting(b, [lhs], bcs=[bcs]): b -= A0 g with g the Dirichlet values (zero elsewhere), then
+            # set_bc(b, bcs): b[dofs] = g                                            (function.py:114-118)
+            lib, st = _lib.load(), _lib.current_stream()
+            n = self._space.n_local
+            self._G.dev().zero_()
+            for bc in self._bcs:
+                bc.apply(self._G_vec())
+            self._A0.mult(self._G.dev(), self._L.dev(), 1)
+            _lib.check(lib.ox_axpby(n, 1.0, self._B.ptr(), -1.0, self._L.ptr(), self._B.ptr(), st), "ox_axpby")
+            for bc in self._bcs:
+                bc.apply(self._b.x)
+
+    def _G_vec(self):
+        from .fem import Vector
+
+        return Vector(self._G, 0)
 
     def solve(self, assemble_rhs: bool = True):
         """Compute the projection; returns the KSP converged reason (function.py:121-135)."""
@@ -145,61 +186,46 @@ def metadata_points(metadata: dict, degree: int) -> int:
     return int(q) // 2 + 1
 
 
-def load_vector(V: FunctionSpace, f, geom: torch.Tensor, n_points: int, chunk: int = 1 << 20) -> torch.Tensor:
-    """b_i = int f phi_i dx over the local cells, for a callable ``f(x)``, x: (3, npts).  Element vectors
-    cell by cell, then every dof SUMS its (cell, local index) contributions in the fixed order of the
-    space's dof -> cell adjacency (no atomics: bit-reproducible).  A set-up / diagnostics functional in
-    torch, not part of the time-step path.  A callable marked ``supports_torch`` is evaluated on the
-    device, any other on the host."""
+def load_vector(V: FunctionSpace, f, geom: torch.Tensor, n_points: int, chunk: int = 1 << 20, out=None) -> torch.Tensor:
+    """b_i = int f phi_i dx over the local cells, for a callable ``f(x)``, x: (3, npts) -> (npts,): the
+    ``force * v * dx`` / ``inner(function, v) * dx`` of a spatial expression (reference fracstep.py:284-289,
+    function.py:75).  ``f`` is tabulated at the quadrature points of every cell (collapsed Gauss-Jacobi rule with
+    ``n_points`` per direction; a callable marked ``supports_torch`` on the device, any other on the host); the
+    sums are the library's (``ox_assemble_load_vector``: one lane per row over the row's cells in adjacency order,
+    no atomics -- bit-reproducible)."""
     mesh = V.mesh
     d, dev = mesh.gdim, mesh.device
     bary_np, w_np = _simplex_rule(d, n_points)
     nv = d + 1
     if V.degree == 1:
         phi_np = bary_np
-    else:
+    elif V.degree == 2:
         cols = [bary_np[:, a] * (2 * bary_np[:, a] - 1) for a in range(nv)]
         cols += [4 * bary_np[:, a] * bary_np[:, b] for a, b in local_edges(d)]
         phi_np = np.stack(cols, axis=1)
+    else:
+        raise NotImplementedError("load_vector: Lagrange degree 1 and 2")
     bary = torch.from_numpy(bary_np).to(dev)
-    wphi = torch.from_numpy(w_np[:, None] * phi_np).to(dev)  # (NQ, nd)
+    wphi = torch.from_numpy(np.ascontiguousarray(w_np[:, None] * phi_np)).to(dev)  # (NQ, nd)
     cells = mesh.cells[V.local_cells]
-    nc, nd = int(cells.shape[0]), V.nd
-    adet = geom[:, d * d]
-    bloc = torch.empty((nc, nd), dtype=torch.float64, device=dev)
+    nc, nq = int(cells.shape[0]), int(bary_np.shape[0])
+    fq = torch.empty((nc, nq), dtype=torch.float64, device=dev)
     on_dev = getattr(f, "supports_torch", False)
     for c0 in range(0, nc, chunk):
         xc = mesh.coords[cells[c0:c0 + chunk]]  # (m, d+1, d)
         xq = torch.einsum("qa,mak->mqk", bary, xc)  # (m, NQ, d)
         X = torch.zeros((3, xq.shape[0] * xq.shape[1]), dtype=torch.float64, device=dev)
         X[:d] = xq.reshape(-1, d).T
-        fq = f(X) if on_dev else torch.from_numpy(np.asarray(f(X.cpu().numpy()), dtype=np.float64)).to(dev)
-        fq = fq.reshape(xq.shape[0], xq.shape[1])
-        bloc[c0:c0 + chunk] = adet[c0:c0 + chunk, None] * (fq @ wphi)
-    # gather: pair (t, lane) of slice s sits at adj_ptr[s] + t*64 + lane
-    adj = V.adj
-    n = V.n_local
-    out = torch.zeros(n, dtype=torch.float64, device=dev)
-    bflat = bloc.reshape(-1)
-    T_all = ((adj.adj_ptr[1:] - adj.adj_ptr[:-1]) // SLICE)
-    rows_per = max(SLICE, (chunk // max(int(T_all.max().item()), 1)) // SLICE * SLICE)
-    for r0 in range(0, n, rows_per):
-        r = torch.arange(r0, min(r0 + rows_per, n), device=dev)
-        sl, lane = r // SLICE, r % SLICE
-        T = T_all[sl]
-        tmax = int(T.max().item())
-        t = torch.arange(tmax, device=dev)
-        idx = adj.adj_ptr[sl][:, None] + t[None, :] * SLICE + lane[:, None]
-        ok = t[None, :] < T[:, None]
-        idx = torch.where(ok, idx, torch.zeros_like(idx))
-        cell = adj.adj_cell[idx].to(torch.int64)
-        ok = ok & (cell >= 0)
-        val = bflat[torch.where(ok, cell * nd + adj.adj_loc[idx].to(torch.int64), torch.zeros_like(cell))]
-        val = torch.where(ok, val, torch.zeros_like(val))
-        acc = torch.zeros(r.shape[0], dtype=torch.float64, device=dev)
-        for k in range(tmax):  # fixed order of the adjacency: the same sum on every run
-            acc = acc + val[:, k]
-        out[r] = acc
+        v = f(X) if on_dev else torch.from_numpy(np.ascontiguousarray(np.broadcast_to(
+            np.asarray(f(X.cpu().numpy()), dtype=np.float64), (X.shape[1],)))).to(dev)
+        fq[c0:c0 + chunk] = v.reshape(xq.shape[0], xq.shape[1])
+    if out is None:
+        out = torch.zeros(V.n_local, dtype=torch.float64, device=dev)
+    cstruct = _lib.ox_cells(d, 0, int(geom.shape[0]), geom.data_ptr())
+    adj = V.adj.struct()
+    _lib.check(_lib.load().ox_assemble_load_vector(C.byref(cstruct), C.byref(adj), V.n_owned, V.nd, nq, _lib.ptr(wphi),
+                                                   _lib.ptr(fq), _lib.ptr(out), _lib.current_stream()),
+               "ox_assemble_load_vector")
     return out
 
 

@@ -227,6 +227,15 @@ class Comm:
                 lib.ox_dist_destroy(tmp)
         return res
 
+    def info(self) -> dict:
+        """What the library's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice);
+        a job without one (gloo rehearsals, one rank) says so."""
+        if self.handle is None:
+            return {"rccl": False, "nranks": self.size, "rank": self.rank}
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().ox_comm_info(self.handle, C.byref(n), C.byref(r), C.byref(d)), "ox_comm_info")
+        return {"rccl": True, "nranks": int(n.value), "rank": int(r.value), "device": int(d.value)}
+
     def allreduce(self, v, op=None):
         import torch.distributed as dist
 
@@ -450,8 +459,10 @@ class MeshPartition:
     # -- window look-ups ---------------------------------------------------------------------------------
     def _win_pos(self, cell_ids: torch.Tensor) -> torch.Tensor:
         pos = torch.searchsorted(self.win_cells, cell_ids)
-        assert bool((self.win_cells[pos.clamp_max(self.win_cells.shape[0] - 1)] == cell_ids).all()), \
-            "cell outside this rank's window"
+        # a cell outside the window would silently read a neighbouring cell's edges (wrong owners, a wrong halo plan):
+        # an error, not a debug assertion; one device round trip per call, set-up only
+        if not bool((self.win_cells[pos.clamp_max(self.win_cells.shape[0] - 1)] == cell_ids).all()):
+            raise ValueError("MeshPartition: a cell outside this rank's window was looked up")
         return pos
 
     def cell_edges_of(self, cell_ids: torch.Tensor) -> torch.Tensor:

@@ -336,6 +336,21 @@ class Forms:
         be = f * self.adet[:, None] * np.einsum("q,qi->i", self.w, self.phi_v)[None]
         return self._vec(be, self.vd, self.nv)
 
+    def load_vec(self, f, space="v", nq=5):
+        """f * v * dx for a spatial expression ``f(x)``, x: (3, npts) -> (npts,) -- what a UFL expression of the
+        coordinates is as a body force (reference fracstep.py:284-289: ``force * v * dx`` for any ``force``) or as
+        a projector's source (function.py:75) -- with a degree-(2 nq - 1) collapsed Gauss-Jacobi rule."""
+        bary, w = simplex_quadrature(self.d, nq)
+        deg = self.u_deg if space == "v" else self.p_deg
+        dofs, n = (self.vd, self.nv) if space == "v" else (self.qd, self.nq)
+        phi, _ = tabulate(self.d, deg, bary)
+        xq = np.einsum("qa,cak->cqk", bary, self.coords[self.cells], optimize=True)
+        X = np.zeros((3, xq.shape[0] * xq.shape[1]))
+        X[: self.d] = xq.reshape(-1, self.d).T
+        fq = np.asarray(f(X), dtype=np.float64).reshape(xq.shape[0], xq.shape[1])
+        be = self.adet[:, None] * np.einsum("q,cq,qi->ci", w, fq, phi, optimize=True)
+        return self._vec(be, dofs, n)
+
     def p_vdxi_vec(self, ps, i):
         """ps * v.dx(i) * dx (reference fracstep.py:306-309,487-497)."""
         pq = np.einsum("qs,cs->cq", self.phi_q, ps[self.qd], optimize=True)
@@ -682,7 +697,9 @@ class OracleFractionalStep:
             D = sp.diags(keep)
             self.Ap = (D @ self.Ap @ D + sp.diags(1.0 - keep)).tocsr()
             self.p_bc_dofs = pd
-        self.b0 = np.stack([forms.body_force_vec(float(f[i])) for i in range(d)], axis=1)
+        # a constant or a spatial expression per component (fracstep.py:284-289,387-390)
+        self.b0 = np.stack([forms.load_vec(f[i]) if callable(f[i]) else forms.body_force_vec(float(f[i]))
+                            for i in range(d)], axis=1)
         if not low_memory:
             self.P = [forms.p_vdxi_mat(i) for i in range(d)]
             self.Gm = [forms.grad_p_mat(i) for i in range(d)]
@@ -869,7 +886,7 @@ def boundary_dofs(xdofs, p0, p1, tol=1e-10):
 
 def taylor_green_problem(N, dim=2, u_deg=2, p_deg=1, nu=0.01, dt=0.005, t0=0.0,
                          solver_options=None, low_memory=True, mesh=None, vd=None, qd=None,
-                         x_v=None, x_q=None, rotational=False):
+                         x_v=None, x_q=None, rotational=False, body_force=None):
     """Set up the demo's problem (demo/taylor_green.py:104-182): exact Dirichlet
     velocity on every exterior facet, no pressure BC, u2(t0-dt), u1(t0), p(t0-dt/2).
     Returns (solver, clock) where clock['t'] is the time the BC callables read."""
@@ -893,7 +910,7 @@ def taylor_green_problem(N, dim=2, u_deg=2, p_deg=1, nu=0.01, dt=0.005, t0=0.0,
     bd = boundary_dofs(x_v, lo, hi)
     bcs_u = [[DirichletData(bd, (lambda x, f=f: f(x, clock["t"], nu)))] for f in fns]
     S = OracleFractionalStep(F, x_v, x_q, bcs_u, solver_options=solver_options,
-                             low_memory=low_memory, rotational=rotational)
+                             low_memory=low_memory, rotational=rotational, body_force=body_force)
     X = np.zeros((3, x_v.shape[0]))
     X[:d] = x_v.T
     Xq = np.zeros((3, x_q.shape[0]))

@@ -56,6 +56,41 @@ def test_bench_runs_and_prints_one_json_line():
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
 
 
+def test_bench_refuses_a_rank_count_other_than_the_one_asked_for():
+    """`--gpus N` is the rank count: a launcher that started another number of ranks must not get a figure
+    (decided before anything touches the GPU, so this runs anywhere)."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr and "WORLD_SIZE=3" in out.stderr, (out.returncode, out.stderr[-500:])
+    assert not out.stdout.strip()
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and not out.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent (which never touches the GPU) runs the driver's
+    N > 1 command line as a child process and relays its one JSON line.  Rehearsed over gloo on the one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OX_P2P_TIMEOUT_S"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "-N", "16", "--backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    _check(d, live_cpu=False)
+    assert d["n_gpus"] == 2 and d["config"]["launched_by"].startswith("bench.py --gpus N")
+    ranks = d["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and d["config"]["rccl_nranks"] is None  # gloo rehearsal: no RCCL communicator
+    assert sum(r["velocity_rows"] for r in ranks) == 33 ** 3 and sum(r["pressure_rows"] for r in ranks) == 17 ** 3
+    assert all(r["velocity_ghosts"] > 0 and r["peers"] == [1 - r["rank"]] for r in ranks)
+    assert len(d["krylov_iterations_series"]["pressure"]) == 2
+
+
 @pytest.mark.gpu
 def test_bench_under_the_driver_launch_line_with_two_ranks():
     """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N

@@ -138,20 +138,67 @@ def test_fused_assembly_returns_the_first_matvec_of_the_tentative_solve(hip):
         for bc in bcu:
             bc.update_bc()
     S.assemble_first(dt, nu)
-    assert S._AU1_valid and torch.equal(S._U.dev(), S._U1.dev())
+    assert S._AU1_valid and torch.equal(S._U.rdev(), S._U1.rdev())
     ref = torch.zeros_like(S._B3.dev())
-    S._A.mult(S._U1.dev(), ref, S._gdim)
+    S._A.mult(S._U1.rdev(), ref, S._gdim)
     assert torch.equal(ref, S._B3.dev())
-    # the whole step with and without the shortcut
+    # the whole step with and without the shortcut (read-only views: the token must survive until the solve)
     S.velocity_tentative_assemble()
-    u_before = S._U.dev().clone()
+    u_before = S._U.rdev().clone()
+    assert S._u_is_u1 == (S._U.generation, S._U1.generation)
+    spy = {}
+    solve_block = S._solver_u.solve_block
+    S._solver_u.solve_block = lambda B, X, ax0=None: (spy.update(ax0=ax0), solve_block(B, X, ax0=ax0))[1]
     _, err = S.velocity_tentative_solve()
+    assert spy["ax0"] is S._B3  # the shortcut was really taken
     its_with, u_with = list(S._solver_u.iterations), S._U.dev().clone()
     S._U.dev().copy_(u_before)
     S._AU1_valid = False
     _, err2 = S.velocity_tentative_solve()
     assert (err > 0).all() and (err2 > 0).all()
+    assert spy["ax0"] is None
     assert its_with == list(S._solver_u.iterations) and torch.equal(u_with, S._U.dev())
+
+
+@pytest.mark.parametrize("how", ["bc.apply", "dev()", "host", "ksp.solve"])
+def test_a_write_to_u_between_two_steps_drops_the_first_matvec_shortcut(hip, how):
+    """A u1 from the fused assembly may stand in for the tentative solve's first mat-vec only while u
+    still equals u1 bit for bit.  Every way of writing u (or u1) from outside between two steps -- DirichletBC.apply on
+    the field, a device view, the host array, a KSPSolver.solve into it -- must drop the shortcut, and the step must
+    equal the one computed without it."""
+    from tests.helpers import KRYLOV, make_hip_problem
+
+    opts = {k: dict(v, ksp_initial_guess_nonzero=True) for k, v in KRYLOV.items()}
+    dt, nu = 0.005, 0.01
+    out = []
+    for force_off in (False, True):
+        S, clock, mesh = make_hip_problem(3, 5, u_deg=2, solver_options=opts)
+        for _ in range(2):
+            clock["t"] += dt
+            S.solve(dt, nu)
+        # an outside write to u: a different initial guess for the next tentative solve (u != u1 from here on)
+        if how == "bc.apply":
+            clock["t"] += 7 * dt  # other Dirichlet values than the ones u carries
+            S._bcs_u[0][0].update_bc()
+            S._bcs_u[0][0].apply(S._u[0].x)
+            clock["t"] -= 7 * dt
+        elif how == "dev()":
+            S._U.dev()[::3, 1] *= 1.25
+        elif how == "host":
+            S._u[2].x.array[::5] += 0.125
+        else:
+            S._solver_c.solve(S._rhs1[1], S._u[1])
+        spy = {}
+        solve_block = S._solver_u.solve_block
+        S._solver_u.solve_block = lambda B, X, ax0=None, f=solve_block, spy=spy: (spy.update(ax0=ax0), f(B, X, ax0=ax0))[1]
+        if force_off:
+            af = S.assemble_first
+            S.assemble_first = lambda *a, af=af, S=S: (af(*a), setattr(S, "_AU1_valid", False))[0]
+        clock["t"] += dt
+        S.solve(dt, nu)
+        assert spy["ax0"] is None, how  # no stale A u1 as the product of another initial guess
+        out.append((S._U.rdev().clone(), list(S._solver_u.iterations)))
+    assert out[0][1] == out[1][1] and torch.equal(out[0][0], out[1][0])
 
 
 @pytest.mark.parametrize("dim,N,deg,nc", [(2, 24, 2, 1), (3, 8, 2, 3), (3, 10, 1, 2), (3, 16, 2, 3)])
