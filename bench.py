@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--mesh", default="box", choices=["box", "delaunay"],
                     help="box: the N^3 x 6 tetrahedra of the BASELINE configurations; delaunay: Delaunay triangulation of "
                          "a jittered (N+1)^3 lattice (unstructured: no value dictionaries, Z-order numbering); implies --no-extras")
+    ap.add_argument("--refine", type=int, default=0,
+                    help="--mesh delaunay: levels of uniform refinement of the triangulation (Qhull takes minutes beyond "
+                         "~3e5 points; -N 32 --refine 2 = 14.0 M tetrahedra, 18.9 M P2 dofs per component in seconds)")
     ap.add_argument("--profile-every", type=int, default=32,
                     help="HIP-event pair around every n-th launch of a kernel tag inside the timed region")
     ap.add_argument("--verbose", action="store_true")
@@ -144,6 +147,8 @@ def pmc_traffic(args, log):
                     cmd.append(flag)
             if args.window:
                 cmd += ["--window", str(args.window)]
+            if args.mesh != "box":
+                cmd += ["--mesh", args.mesh, "--refine", str(args.refine)]
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if p.returncode != 0:
                 return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode}): "
@@ -190,7 +195,7 @@ def pmc_traffic(args, log):
 # ---- workloads ----------------------------------------------------------------------------------
 def make_workload(name, N, np, torch):
     """Analytic fields as array-API callables (numpy on the host, torch tensors on the device for the
-    per-step Dirichlet values)."""
+    per-step Dirichlet values).  ``N``: cells per direction the time step is sized for (dt ~ 1/N)."""
     pi = math.pi
 
     def xp(x):
@@ -299,7 +304,7 @@ def main():
     N = args.N
     if args.mesh != "box":
         args.no_extras = True  # the 256^3 box line and the dictionary-off leg describe the box workload
-    W = make_workload(args.workload, N, np, torch)
+    W = make_workload(args.workload, N << args.refine, np, torch)  # dt follows the refined mesh's spacing
     nu, dt, fns = W["nu"], W["dt"], W["fns"]
     clock = {"t": 0.0}
     p0, p1 = W["box"]
@@ -331,7 +336,7 @@ def main():
 
     def build(n, udeg, opts, zero_guess):
         if args.mesh == "delaunay":  # Delaunay triangulation of a jittered (n+1)^3 lattice: "what an unstructured mesh gets"
-            mesh = M.create_delaunay_box(comm, [p0, p1], n)
+            mesh = M.create_delaunay_box(comm, [p0, p1], n, refine=args.refine)
         else:
             mesh = M.create_box(comm, [p0, p1], [n, n, n])
         bcs_u = [[ox.DirichletBC(bc_value(f), ox.LocatorMethod.GEOMETRICAL, on_boundary)] for f in fns]
@@ -784,7 +789,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{W['desc']}, "
                                    + (f"{N}^3x6 tets" if args.mesh == "box" else
-                                      f"Delaunay mesh of a jittered {N + 1}^3 lattice ({mesh.num_cells} tets)")
+                                      f"Delaunay mesh of a jittered {N + 1}^3 lattice"
+                                      + (f", uniformly refined {args.refine}x" if args.refine else "") + f" ({mesh.num_cells} tets)")
                                    + f" P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
                                    f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
                                    f"initial_guess_nonzero={not args.zero_guess}, max_iter=1, "

@@ -331,12 +331,51 @@ def create_box(comm, points, n, cell_type=CellType.tetrahedron, device=None, **k
     return Mesh(coords, cells.reshape(-1, 4), comm if comm is not None else COMM_WORLD)
 
 
-def create_delaunay_box(comm, points, n, seed: int = 0, jitter: float = 0.35, device=None) -> Mesh:
+def refine_uniform(coords: np.ndarray, cells: np.ndarray):
+    """One level of regular ("red") refinement of a simplicial mesh: every edge gets a midpoint vertex; a triangle
+    becomes 4 triangles, a tetrahedron 4 corner tetrahedra plus its inner octahedron cut along its SHORTEST diagonal
+    into 4 (Bey / Zhang: the cut that keeps the shape regularity).  Returns (coords, cells) with the old vertices
+    first.  How large unstructured meshes are usually produced: a generator's mesh, refined uniformly."""
+    coords = np.asarray(coords, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.int64)
+    nv, d = coords.shape
+    le = [(0, 1), (0, 2), (1, 2)] if d == 2 else [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    a = np.stack([cells[:, i] for i, _ in le], axis=1)
+    b = np.stack([cells[:, j] for _, j in le], axis=1)
+    key = np.minimum(a, b) * np.int64(nv) + np.maximum(a, b)
+    ukey, inv = np.unique(key.reshape(-1), return_inverse=True)
+    mid = (nv + inv.reshape(key.shape)).astype(np.int64)  # midpoint vertex of each local edge
+    new = 0.5 * (coords[ukey // nv] + coords[ukey % nv])
+    X = np.concatenate([coords, new], axis=0)
+    v = cells
+    if d == 2:
+        m01, m02, m12 = mid[:, 0], mid[:, 1], mid[:, 2]
+        out = [np.stack(t, axis=1) for t in ((v[:, 0], m01, m02), (m01, v[:, 1], m12), (m02, m12, v[:, 2]), (m01, m12, m02))]
+        return X, np.concatenate(out, axis=0)
+    m01, m02, m03, m12, m13, m23 = (mid[:, k] for k in range(6))
+    out = [np.stack(t, axis=1) for t in ((v[:, 0], m01, m02, m03), (m01, v[:, 1], m12, m13), (m02, m12, v[:, 2], m23),
+                                          (m03, m13, m23, v[:, 3]))]
+    # the octahedron m01 m02 m03 m12 m13 m23: its three diagonals join the midpoints of opposite edges
+    diag = [(m01, m23, (m02, m03, m13, m12)), (m02, m13, (m01, m03, m23, m12)), (m03, m12, (m01, m02, m23, m13))]
+    length = np.stack([np.linalg.norm(X[p_] - X[q_], axis=1) for p_, q_, _ in diag], axis=1)
+    pick = np.argmin(length, axis=1)  # (ties: the first diagonal -- deterministic)
+    octa = np.empty((cells.shape[0], 4, 4), dtype=np.int64)
+    for k, (p_, q_, ring) in enumerate(diag):
+        sel = pick == k
+        for t in range(4):  # the 4 tetrahedra around the diagonal: (p, q, ring[t], ring[t+1])
+            octa[sel, t] = np.stack([p_[sel], q_[sel], ring[t][sel], ring[(t + 1) % 4][sel]], axis=1)
+    return X, np.concatenate(out + [octa.reshape(-1, 4)], axis=0)
+
+
+def create_delaunay_box(comm, points, n, seed: int = 0, jitter: float = 0.35, device=None, refine: int = 0) -> Mesh:
     """A genuinely unstructured simplicial mesh of the box ``points = [p0, p1]``: Delaunay triangulation
     (scipy / Qhull) of a jittered (n+1)^dim lattice whose boundary points slide only inside their face /
     edge.  Vertex valence ranges from 1 to ~40 cells in 3-D -- nothing of a box mesh's topology is left.
     Flat cells on the hull are dropped and the total volume is checked.  The test and benchmark mesh for
-    "what an unstructured mesh gets" (no reference counterpart: DOLFINx reads such meshes from files)."""
+    "what an unstructured mesh gets" (no reference counterpart: DOLFINx reads such meshes from files).
+    ``refine`` > 0 refines the triangulation uniformly that many times (``refine_uniform``): Qhull takes minutes
+    beyond ~3 x 10^5 points, a refined coarse Delaunay mesh reaches the BASELINE sizes in seconds and keeps the
+    irregular valence of its coarse vertices."""
     import math
 
     from scipy.spatial import Delaunay
@@ -358,6 +397,8 @@ def create_delaunay_box(comm, points, n, seed: int = 0, jitter: float = 0.35, de
     T = T[keep]
     assert abs(det[keep].sum() / math.factorial(dim) - 2.0 ** dim) < 1e-9
     X = p0 + (P + 1.0) * 0.5 * (p1 - p0)  # [-1, 1]^dim -> the box
+    for _ in range(int(refine)):  # ``refine`` levels of uniform refinement: the Delaunay mesh at 8^refine times the cells
+        X, T = refine_uniform(X, T)
     return from_arrays(X, T, comm=comm, device=device)
 
 
