@@ -83,6 +83,8 @@ def parse():
                          "terms instead of the pre-assembled rectangular operators (reference "
                          "fracstep.py:392-404; the demo's default is the pre-assembled form)")
     ap.add_argument("--no-dictionary", action="store_true", help="options['value_dictionary'] = False for the main run")
+    ap.add_argument("--spmv-windows", default=None, choices=["true", "false"],
+                    help="force the LDS-window stream of the velocity matrices on / off (default: on for P2 on one GPU)")
     ap.add_argument("--window", type=int, default=None,
                     help="rows per length-sorting window of the SELL-64 numbering (tuning; default: the library's)")
     ap.add_argument("--profile-setup", action="store_true",
@@ -361,7 +363,8 @@ def main():
         return mesh, S_
 
     options = dict({"low_memory_version": args.matrix_free, "value_dictionary": not args.no_dictionary},
-                   **({"sell_window": args.window} if args.window else {}))
+                   **({"sell_window": args.window} if args.window else {}),
+                   **({"spmv_windows": args.spmv_windows == "true"} if args.spmv_windows else {}))
     mesh, S = build(N, args.udeg, options, args.zero_guess)
 
     def workload_leg(wname, steps=5, warmup=3):

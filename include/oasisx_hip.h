@@ -119,6 +119,29 @@ typedef struct {
                                 which base, bits 16-23 code a, bits 24-31 code b                */
   const int32_t *ps_base;    /* device [ps_ptr[n_slices] / 256][2] column bases per group of 4
                                 slots x 64 lanes                                                */
+  /* optional LDS-window stream (ox_window_size / ox_window_fill; all NULL / 0 = not built).  The mat-vecs on the
+   * velocity matrices are bound by their gather instructions, not by bytes (every x operand of a lane = row kernel
+   * is one gather wave-instruction: DESIGN.md 3).  A WINDOW BLOCK = up to 8 slices (512 rows) whose rows lie close
+   * together in the mesh; the sorted list of the distinct columns its entries touch is its window.  The kernel
+   * copies x[window] into LDS once (|window| gathers instead of one per entry: 6-9 x fewer) and reads every operand
+   * from there through a 16-bit index.  Same entries, same per-row order of fused multiply-adds: bit-identical
+   * results.  Blocks whose window exceeds the kernel's LDS budget are multiplied from `cols` as before. */
+  const int32_t *wb_slices;  /* device [n_wblocks][8] slice ids of each block (-1: none)                */
+  const uint16_t *wb_waves;  /* device [n_wblocks]: 2 bits per slot j = the wave (0..3) that multiplies
+                                slice wb_slices[b][j] -- a schedule that balances the slices' widths     */
+  const int64_t *wb_ptr;     /* device [n_wblocks+1] offsets into wlist                                  */
+  const int32_t *wlist;      /* device [wb_ptr[n_wblocks]] ascending distinct columns of each block      */
+  const int64_t *wt_ptr;     /* device [n_slices+1]: first TILE of each slice in wcode / wvcode; a tile = 2 storage
+                                pairs (4 entries) of the 64 lanes, lane-contiguous: entry 2j + i (i = 0, 1) of pair
+                                2t + j of lane l of slice s at ((wt_ptr[s] + t) * 64 + l) * 4 + 2j + i; a slice of
+                                npair pairs has ceil(npair / 2) tiles, the surplus pair of an odd slice's last tile is
+                                unused.  One 8-byte (wcode) and one 4-byte (wvcode) load per lane serve 4 entries     */
+  const uint16_t *wcode;     /* device [wt_ptr[n_slices] * 256]: cols[e] == wlist[wb_ptr[b] + wcode[tile slot of e]]
+                                for every slot e of a slice of block b                                    */
+  const uint8_t *wvcode;     /* device [wt_ptr[n_slices] * 256] or NULL: vcode in the tile layout (per matrix, with
+                                its value dictionary: ox_window_retile)                                    */
+  int32_t n_wblocks;         /* 0: no window stream                                                      */
+  int32_t w_max;             /* largest window (entries)                                                 */
 } ox_sell;
 
 /* Cells of the mesh as the element kernels read them. */
@@ -215,6 +238,11 @@ int ox_mesh_destroy(ox_mesh *mesh);
 /* scalar Lagrange space of degree 1 or 2 (functionspace(mesh, ("Lagrange", k)), fracstep.py:187-216);
  * window: rows per length-sorting window of the SELL-64 numbering (< 64: the default 4096). */
 int ox_space_create(const ox_mesh *mesh, int degree, int window, ox_space **out);
+/* The same with a choice of the dof order: order_flags bit 0 = BRICK order on lattice meshes -- (tile, brick_z, brick_y,
+ * brick_x, z, y, x) with bricks of about 8 points a side instead of whole x-lines: the rows of 8 consecutive slices
+ * then share a compact window of columns, what the LDS-window SpMV (ox_sell.wb_*) needs.  The lane = row kernels
+ * gather worse in this order (mass mat-vec 487 -> 630 us at 128^3): only together with the window stream. */
+int ox_space_create_ordered(const ox_mesh *mesh, int degree, int window, int order_flags, ox_space **out);
 /* One rank's piece of a mesh-partitioned space (what DOLFINx's functionspace() returns on a distributed mesh,
  * reference fracstep.py:186-216): built from that rank's cells only (its own cells + one ghost layer).
  *   ox_mesh_create_sub   the part as a mesh of its own (vertices renumbered 0..n-1 in ascending global id) whose
@@ -250,6 +278,9 @@ int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *co
  * ps_ptr (bit 0) the slices whose columns do not fit two 15-bit windows per group -- they keep their
  * int32 columns -- and returns their number in *n_wide.  Then set A->ps_ptr / ps_code / ps_base. */
 int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, void *stream);
+/* Re-tile a per-slot array of A's pattern (elem_bytes = 1: vcode, 2: 16-bit codes) from the pair layout of
+ * slice_ptr into the tile layout of wt_ptr (ox_sell.wt_ptr); unused entries of a slice's last tile are zeroed. */
+int ox_window_retile(const ox_sell *A, const int64_t *wt_ptr, const void *src, int elem_bytes, void *dst, void *stream);
 int ox_pair_stream_fill(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, uint32_t *ps_code,
                         int32_t *ps_base, int64_t *n_wide, void *stream);
 /* plain device memory for callers without a device array library (numpy + ctypes) */

@@ -40,6 +40,15 @@ class ox_sell(C.Structure):
         ("ps_ptr", C.c_void_p),
         ("ps_code", C.c_void_p),
         ("ps_base", C.c_void_p),
+        ("wb_slices", C.c_void_p),
+        ("wb_waves", C.c_void_p),
+        ("wb_ptr", C.c_void_p),
+        ("wlist", C.c_void_p),
+        ("wt_ptr", C.c_void_p),
+        ("wcode", C.c_void_p),
+        ("wvcode", C.c_void_p),
+        ("n_wblocks", C.c_int32),
+        ("w_max", C.c_int32),
     ]
 
 
@@ -146,6 +155,7 @@ SIGNATURES = {
     "ox_mesh_view": (_I, [_P, C.POINTER(ox_mesh_info)]),
     "ox_mesh_destroy": (_I, [_P]),
     "ox_space_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "ox_space_create_ordered": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "ox_mesh_create_sub": (_I, [_P, _L, _P, _L, _I, _I, C.POINTER(_D), C.POINTER(_D), _I, _I, _L, C.POINTER(_P)]),
     "ox_space_create_part": (_I, [_P, _I, _I, _P, _L, _I, _L, C.POINTER(_P)]),
     "ox_space_view": (_I, [_P, C.POINTER(ox_space_info)]),
@@ -196,6 +206,7 @@ SIGNATURES = {
     "ox_ksp_solve_dc": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, _D, _D, _I, _I, _I, _I, _P,
                              C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P, _P, _P, _I]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
+    "ox_window_retile": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),

@@ -116,7 +116,7 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
 // interior / boundary split) and the number of per-block partials its fused epilogue writes
 int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, const double *dinv, const double *aux,
                  double *partial, const int *done, const ox_dist *dist, hipStream_t st);
-int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist);
+int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist, int ncomp);
 // optional 1-byte codes + dictionary of the diagonal the OX_EPI_CG_M2 epilogue multiplies by (nullptr: the f64 array)
 struct OxEpiDinv {
   const uint8_t *code;

@@ -1047,7 +1047,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.dist = dist;
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
-  C.nbs = ox_spmv_dist_nparts(A, dist);
+  C.nbs = ox_spmv_dist_nparts(A, dist, NC);
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));

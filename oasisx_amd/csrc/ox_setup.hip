@@ -132,6 +132,7 @@ struct KeySpec {
   double lo[3], inv[3];  // (x - lo) * inv in [0, 2^bits - 1]
   int d, bits, tb;
   int curve;  // 0: tiled lexicographic (lattice meshes), 1: Z-order curve (everything else)
+  int bs;     // > 0 (tiled order only): bricks of 2^bs lattice steps a side -- (tile, brick_z, brick_y, brick_x, z, y, x)
 };
 __device__ __forceinline__ uint64_t locality_key(const double *p, const KeySpec &K) {
   uint64_t q[3] = {0, 0, 0};
@@ -148,6 +149,11 @@ __device__ __forceinline__ uint64_t locality_key(const double *p, const KeySpec 
     return key;
   }
   for (int k = K.d - 1; k >= 1; --k) key = (key << K.tb) | (q[k] >> (K.bits - K.tb));
+  if (K.bs > 0) {  // brick order: the rows of 8 consecutive slices then share a compact window of columns (k_spmv_win)
+    for (int k = K.d - 1; k >= 0; --k) key = (key << (K.bits - K.bs)) | (q[k] >> K.bs);
+    for (int k = K.d - 1; k >= 0; --k) key = (key << K.bs) | (q[k] & ((1ull << K.bs) - 1ull));
+    return key;
+  }
   for (int k = K.d - 1; k >= 0; --k) key = (key << K.bits) | q[k];
   return key;
 }
@@ -589,7 +595,27 @@ int default_key_bits(int64_t n_points, int d, int tb) {
   return std::min(18, std::max(b + 2, tb + 1));
 }
 
-KeySpec key_spec(const ox_mesh *M, int tb, int64_t n_points) {
+// Brick order of the degree-2 spaces on lattice meshes (fem.default_brick_shift is the twin): bricks of about 8 points
+// a side (512 rows: one window block of k_spmv_win); shift = bits - floor(log2(L / 8)) with L = points per direction
+// as default_key_bits counts them; 0 (no bricks) below 16 points per direction.
+int default_brick_shift(int64_t n_points, int d, int bits) {
+  auto pw = [&](int64_t L) {
+    __int128 v = 1;
+    for (int k = 0; k < d; ++k) v *= L;
+    return v;
+  };
+  int64_t L = 1;
+  while (pw(L) < (__int128)n_points) L += L < 64 ? 1 : std::max<int64_t>(1, L / 64);
+  while (L > 1 && pw(L - 1) >= (__int128)n_points) --L;
+  const int64_t nb = L / 8;
+  if (nb < 2) return 0;
+  int lg = 0;
+  while (((int64_t)2 << lg) <= nb) ++lg;
+  const int bs = bits - lg;
+  return bs > 0 && bs < bits ? bs : 0;
+}
+
+KeySpec key_spec(const ox_mesh *M, int tb, int64_t n_points, bool brick = false) {
   KeySpec K;
   K.d = M->gdim;
   K.tb = tb;
@@ -598,6 +624,7 @@ KeySpec key_spec(const ox_mesh *M, int tb, int64_t n_points) {
   while (bits > 4 && (K.curve ? K.d * bits : (K.d - 1) * tb + K.d * bits) > 63) --bits;
   if (tb > bits) K.tb = bits;
   K.bits = bits;
+  K.bs = (!K.curve && brick) ? default_brick_shift(n_points, M->gdim, bits) : 0;
   for (int k = 0; k < 3; ++k) {
     K.lo[k] = M->lo[k];
     K.inv[k] = (double)((1ull << bits) - 1) / M->span[k];
@@ -896,7 +923,7 @@ __global__ __launch_bounds__(256) void k_window_keys_part(const int32_t *__restr
 }
 
 static int space_create_impl(const ox_mesh *M, int degree, int window, const int32_t *owner, int rank, int64_t n_initial,
-                             int64_t n_dofs_whole, ox_space **out) {
+                             int64_t n_dofs_whole, ox_space **out, int brick = 0) {
   if (!M || !out) OX_FAIL("ox_space_create: null argument");
   if (degree != 1 && degree != 2) OX_FAIL("ox_space_create: Lagrange degree %d (1 and 2 are built)", degree);
   if (window < SLICE) window = 4096;
@@ -973,7 +1000,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {
-    const KeySpec K = key_spec(M, M->tile_bits, owner ? n_dofs_whole : n);
+    const KeySpec K = key_spec(M, M->tile_bits, owner ? n_dofs_whole : n, brick != 0);
     DevBuf k_in, k_out, v_in, perm1;
     OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)n));
     OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)n));
@@ -1090,6 +1117,11 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
 
 extern "C" int ox_space_create(const ox_mesh *M, int degree, int window, ox_space **out) {
   return space_create_impl(M, degree, window, nullptr, 0, 0, 0, out);
+}
+
+extern "C" int ox_space_create_ordered(const ox_mesh *M, int degree, int window, int order_flags, ox_space **out) {
+  if (order_flags & ~1) OX_FAIL("ox_space_create_ordered: order_flags=%d", order_flags);
+  return space_create_impl(M, degree, window, nullptr, 0, 0, 0, out, order_flags & 1);
 }
 
 extern "C" int ox_space_create_part(const ox_mesh *M, int degree, int window, const int32_t *owner, int64_t n_initial, int rank,

@@ -386,6 +386,197 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_spmv_win: y = A x with the x operands read from an LDS copy of the block's WINDOW (ox_sell.wb_* / wlist / wcode).
+// The lane = row kernels above issue one gather wave-instruction per entry (two with three right-hand sides), and
+// the texture path takes ~32 cycles for each whatever its width or footprint: they are bound by those gathers, not by
+// bytes (profiles/r03_spmv_u128_counters.txt: TA 85-90 %, TD 87-98 % busy).  Here a block of 4 waves owns up to 8
+// slices (512 rows) that lie close together in the mesh; the distinct columns of all their entries -- the window,
+// 1.3-2.5 K dofs on a box mesh in brick order, against 14.6 K entries -- are gathered ONCE into LDS (coalesced list
+// reads, |window| gathers), and every operand of the products is a ds_read through the entry's 16-bit window index.
+// Same entries, same per-row order of fused multiply-adds as k_spmv: bit-identical results.
+// The 8 slices are dealt to the 4 waves by a stored schedule (wb_waves) that balances their widths -- a P2 block
+// holds one 66-wide vertex slice, four 28-wide and three 20-wide edge slices: 66 / 56 / 56 / 60 --, a block whose
+// window exceeds w_cap (the launch's LDS budget) multiplies from the int32 columns like k_spmv.
+// ---------------------------------------------------------------------------------------
+template <int NC, int EPI, int VAR>
+__global__ __launch_bounds__(256) void k_spmv_win(ox_sell A, const double *__restrict__ x, double *__restrict__ y,
+                                                  const double *__restrict__ dinv, const double *__restrict__ aux,
+                                                  double *__restrict__ partial, const int *__restrict__ done_flag,
+                                                  int w_cap, OxEpiDinv ED) {
+  constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
+  extern __shared__ double xw[];  // [NC][w_cap]: one plane per right-hand side -- the 64 lanes of a wave mostly read
+                                  // consecutive window entries: consecutive 8-byte words, no bank conflicts (the
+                                  // interleaved [w_cap][3] form spent 48 % of its LDS cycles on conflicts)
+  __shared__ double red[4 * NV];
+  __shared__ double dict[(VAR & 4) ? 256 : 1];
+  if (done_flag && *done_flag) return;
+  if (VAR & 4) {
+    if ((int)threadIdx.x < A.n_dict) dict[threadIdx.x] = A.vdict[threadIdx.x];
+  }
+  const int b = ox_xcd_remap(blockIdx.x, gridDim.x);  // blocks of one XCD: a contiguous eighth of the window blocks
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double s[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s[i] = 0.0;
+  const bool live = b < A.n_wblocks;
+  int64_t w0 = 0;
+  int W = 0;
+  if (live) {
+    w0 = A.wb_ptr[b];
+    W = (int)(A.wb_ptr[b + 1] - w0);
+  }
+  const bool windowed = live && W <= w_cap;
+  if (windowed) {  // fill: the list is read coalesced, x[list] gathered once per window entry
+    const int32_t *__restrict__ wl = A.wlist + w0;
+    for (int i0 = threadIdx.x; i0 < W; i0 += 1024) {
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = wl[min(i0 + u * 256, W - 1)];
+      double v[4][NC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v[u][cc] = x[(size_t)c[u] * NC + cc];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 256 < W) {
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) xw[(size_t)cc * w_cap + (i0 + u * 256)] = v[u][cc];
+        }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const unsigned sched = A.wb_waves[b];
+    const int32_t *__restrict__ sl = A.wb_slices + (size_t)b * 8;
+    for (int j = 0; j < 8; ++j) {
+      if ((int)((sched >> (2 * j)) & 3u) != wave) continue;
+      const int slice = __builtin_amdgcn_readfirstlane(sl[j]);
+      if (slice < 0) continue;
+      const int64_t row = (int64_t)slice * 64 + lane;
+      double acc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+      const int64_t base = A.slice_ptr[slice];
+      const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
+      const unsigned short *__restrict__ vcp =
+          (VAR & 4) ? reinterpret_cast<const unsigned short *>(A.vcode + base) + lane : nullptr;
+      auto load_vals = [&](int k) {
+        double2 v;
+        if (VAR & 4) {
+          const unsigned cc = __builtin_nontemporal_load(vcp + (size_t)k * 64);
+          v.x = dict[cc & 0xff];
+          v.y = dict[cc >> 8];
+        } else {
+          const v2d vv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(vp + (size_t)k * 64));
+          v.x = vv.x;
+          v.y = vv.y;
+        }
+        return v;
+      };
+      if (windowed) {
+        // tile layout: one 8-byte load = the window indices of 2 pairs (4 entries) of this lane, one 4-byte load
+        // their value codes; f64 values stay in the pair layout (16 bytes per pair).  Two tiles are in flight; the
+        // products keep the stored order of the entries.
+        typedef unsigned short v4h __attribute__((ext_vector_type(4)));
+        typedef unsigned char v4b __attribute__((ext_vector_type(4)));
+        const int64_t t0 = A.wt_ptr[slice];
+        const int ntile = (npair + 1) >> 1;
+        const v4h *__restrict__ hp = reinterpret_cast<const v4h *>(A.wcode) + t0 * 64 + lane;
+        const v4b *__restrict__ bp = (VAR & 4) ? reinterpret_cast<const v4b *>(A.wvcode) + t0 * 64 + lane : nullptr;
+        auto tile = [&](int t, auto full_tag) {
+          constexpr bool FULL = decltype(full_tag)::value;
+          const v4h d = __builtin_nontemporal_load(hp + (size_t)t * 64);
+          double2 v[2];
+          if (VAR & 4) {
+            const v4b cc = __builtin_nontemporal_load(bp + (size_t)t * 64);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[j].x = dict[cc[2 * j]], v[j].y = dict[cc[2 * j + 1]];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int k = FULL ? 2 * t + j : min(2 * t + j, npair - 1);
+              const v2d vv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(vp + (size_t)k * 64));
+              v[j].x = vv.x, v[j].y = vv.y;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (FULL || 2 * t + j < npair) {
+              const double *x0 = xw + d[2 * j];
+              const double *x1 = xw + d[2 * j + 1];
+#pragma unroll
+              for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v[j].x, x0[(size_t)cc * w_cap], acc[cc]);
+#pragma unroll
+              for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v[j].y, x1[(size_t)cc * w_cap], acc[cc]);
+            }
+          }
+        };
+        const int nfull = npair >> 1;
+#pragma unroll 4
+        for (int t = 0; t < nfull; ++t) tile(t, std::true_type{});
+        if (nfull < ntile) tile(nfull, std::false_type{});
+      } else {
+        const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
+#pragma unroll 4
+        for (int k = 0; k < npair; ++k) {
+          const double2 v = load_vals(k);
+          const v2i ci = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(cp + (size_t)k * 64));
+          const double *x0 = x + (size_t)ci.x * NC;
+          const double *x1 = x + (size_t)ci.y * NC;
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.x, x0[cc], acc[cc]);
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(v.y, x1[cc], acc[cc]);
+        }
+      }
+      if (row < A.n_rows) {
+        if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) {
+          const double d = dinv[row];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] *= d;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[row * NC + c] = acc[c];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (EPI == OX_EPI_DOT) s[c] = fma(x[row * NC + c], acc[c], s[c]);
+          if (EPI == OX_EPI_BCGS_V) s[c] = fma(aux[row * NC + c], acc[c], s[c]);
+          if (EPI == OX_EPI_BCGS_T) {
+            s[c] = fma(acc[c], acc[c], s[c]);
+            s[NC + c] = fma(acc[c], x[row * NC + c], s[NC + c]);
+          }
+          if (EPI == OX_EPI_BCGS_T5) {
+            const double xs = x[row * NC + c], ah = aux[row * NC + c];
+            s[c] = fma(acc[c], acc[c], s[c]);
+            s[NC + c] = fma(acc[c], xs, s[NC + c]);
+            s[2 * NC + c] = fma(ah, xs, s[2 * NC + c]);
+            s[3 * NC + c] = fma(ah, acc[c], s[3 * NC + c]);
+            s[4 * NC + c] = fma(xs, xs, s[4 * NC + c]);
+          }
+          if (EPI == OX_EPI_CG_M2) {
+            const double dd = ED.code ? ED.dict[ED.code[row]] : dinv[row];
+            s[c] = fma(x[row * NC + c], acc[c], s[c]);
+            s[NC + c] = fma(acc[c], dd * acc[c], s[NC + c]);
+          }
+        }
+      }
+    }
+  }
+  if (EPI != OX_EPI_NONE) {
+    ox_block_sum_256<NV>(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) partial[(size_t)blockIdx.x * NV + i] = s[i];
+    }
+  }
+}
+
 // a device int that is always 0: stands in for a null done flag so the kernel can load it unconditionally.
 // One allocation per device for the whole process, zeroed on the caller's stream before its first use there.
 #include <mutex>
@@ -407,13 +598,39 @@ static const int *ox_zero_flag(hipStream_t st) {
 }
 
 // bit 0: nontemporal matrix stream; bit 1: 16-bit column stream, bit 2: 1-byte value codes, bit 3: the
-// pair-slot stream, each where the matrix carries them (measured: tools/spmv_bench.py)
-#define OX_SPMV_DEFAULT_VARIANT 15
+// pair-slot stream, bit 4: the LDS-window stream, each where the matrix carries them (measured: tools/spmv_bench.py).
+// Every level multiplies the same entries in the same order: the switch never changes a result.
+#define OX_SPMV_DEFAULT_VARIANT 31
 static int g_spmv_variant = -1;
 extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 15;
+  g_spmv_variant = v & 31;
   return 0;
 }
+static int spmv_variant() {
+  if (g_spmv_variant < 0) {
+    const char *e = getenv("OX_SPMV_VARIANT");
+    g_spmv_variant = e ? atoi(e) & 31 : OX_SPMV_DEFAULT_VARIANT;
+  }
+  return g_spmv_variant;
+}
+
+// LDS-window stream: window entries the kernel's LDS budget holds with ncomp right-hand sides (48 / 48 / 51 KB: three
+// resident blocks per CU with three columns); OX_WIN_CAP overrides (tuning).  0: the matrix has no window stream, or
+// the launch cannot use it (slice lists of a partitioned operator).
+static int spmv_window_cap(const ox_sell *A, int ncomp, const int32_t *list) {
+  if (list || !(spmv_variant() & 16) || !A->wcode || !A->wt_ptr || !A->wlist || !A->wb_ptr || !A->wb_slices ||
+      !A->wb_waves || A->n_wblocks <= 0 || ncomp < 1 || ncomp > 3)
+    return 0;
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("OX_WIN_CAP");
+    env = e ? atoi(e) : 0;
+  }
+  const int dflt = ncomp == 1 ? 6144 : (ncomp == 2 ? 3072 : 2176);
+  const int cap = env > 0 ? env : dflt;
+  return A->w_max < cap ? A->w_max : cap;
+}
+static inline int spmv_window_grid(const ox_sell *A) { return (A->n_wblocks + 7) & ~7; }
 
 // the Jacobi diagonal of the OX_EPI_CG_M2 epilogue through its value dictionary (ox_ksp.hip sets it around its mat-vecs;
 // one call at a time per process: include/oasisx_hip.h)
@@ -425,16 +642,39 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
                             hipStream_t st, const int32_t *list, int n_list) {
   const int nblk = list ? ox_spmv_blocks_n(n_list) : ox_spmv_blocks(A);
   if (nblk == 0) return 0;
-  if (g_spmv_variant < 0) {
-    const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 15 : OX_SPMV_DEFAULT_VARIANT;
-  }
+  spmv_variant();
   int var = (A->cols16 && A->cbase) ? (g_spmv_variant & 7) : (g_spmv_variant & 1);
   // bit 3 off: ignore the pair-slot stream (tools/spmv_bench.py A/B)
   const bool pairs = (g_spmv_variant & 8) && A->ps_ptr && A->ps_code && A->ps_base;
   // value codes ride on the 16-bit column stream (one kernel family: 7 = all three)
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
+  const int w_cap = pairs ? 0 : spmv_window_cap(A, ncomp, list);
+  if (w_cap > 0) {
+    const bool codes = var == 7 && A->wvcode;  // a dictionary matrix without tiled value codes multiplies its f64 values
+    const int wgrid = spmv_window_grid(A);
+    const size_t lds = (size_t)w_cap * ncomp * sizeof(double);
+#define OX_WIN_CASE(NC, E)                                                                                          \
+  if (ncomp == NC && epi == E) {                                                                                    \
+    auto go = [&](auto kern) -> int {                                                                               \
+      if (lds > 48 * 1024)                                                                                          \
+        OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds));                                                                      \
+      if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                             \
+      hipLaunchKernelGGL(kern, dim3(wgrid), dim3(256), lds, st, *A, x, y, dinv, aux, partial, done, w_cap, g_epi_dinv); \
+      if (ox_prof_on) ox_prof_stop(st);                                                                             \
+      OX_LAUNCH_CHECK();                                                                                            \
+      return 0;                                                                                                     \
+    };                                                                                                              \
+    return codes ? go(k_spmv_win<NC, E, 5>) : go(k_spmv_win<NC, E, 1>);                                             \
+  }
+#define OX_WIN_NC(NC)                                                                                   \
+  OX_WIN_CASE(NC, OX_EPI_NONE) OX_WIN_CASE(NC, OX_EPI_DOT) OX_WIN_CASE(NC, OX_EPI_BCGS_V) OX_WIN_CASE(NC, OX_EPI_BCGS_T) \
+  OX_WIN_CASE(NC, OX_EPI_BCGS_T5) OX_WIN_CASE(NC, OX_EPI_CG_M2)
+    OX_WIN_NC(1) OX_WIN_NC(2) OX_WIN_NC(3)
+#undef OX_WIN_NC
+#undef OX_WIN_CASE
+  }
 #define OX_SPMV_LAUNCH(NC, E, V)                                                                   \
   hipLaunchKernelGGL((k_spmv<NC, E, V>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, done, list, n_list, g_epi_dinv)
 #define OX_SPMV_CASE(NC, E)                                                                     \
@@ -489,8 +729,12 @@ static bool ox_overlap_on(const ox_sell *A, const ox_dist *dist) {
   return !(dist->comm && !dist->p2p && !dist->halo_cb);  // RCCL plan: off by default
 }
 
-int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist) {
-  if (!ox_overlap_on(A, dist)) return ox_spmv_blocks(A);
+int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist, int ncomp) {
+  if (!ox_overlap_on(A, dist)) {
+    const bool pairs = (spmv_variant() & 8) && A->ps_ptr && A->ps_code && A->ps_base;
+    if (!pairs && spmv_window_cap(A, ncomp, nullptr) > 0) return spmv_window_grid(A);
+    return ox_spmv_blocks(A);
+  }
   return ox_spmv_blocks_n(A->n_interior) + ox_spmv_blocks_n(A->n_slices - A->n_interior);
 }
 
@@ -1090,6 +1334,44 @@ extern "C" int ox_profile_get(int tag, long long key, long long *count, double *
     }
   if (count) *count = n;
   if (total_ms) *total_ms = t;
+  return 0;
+}
+
+// ---- tile layout of the LDS-window stream (ox_sell.wt_ptr): re-tile a per-slot array from the pair layout --------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_window_retile(ox_sell A, const int64_t *__restrict__ wt_ptr, const T *__restrict__ src,
+                                                       T *__restrict__ dst) {
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= A.n_slices) return;
+  const int64_t base = A.slice_ptr[slice];
+  const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
+  const int64_t t0 = wt_ptr[slice];
+  const int ntile = (npair + 1) >> 1;
+  for (int t = 0; t < ntile; ++t)
+    for (int j = 0; j < 2; ++j) {
+      const int k = 2 * t + j;
+      T a = 0, b = 0;
+      if (k < npair) {
+        a = src[base + (int64_t)k * 128 + lane * 2];
+        b = src[base + (int64_t)k * 128 + lane * 2 + 1];
+      }
+      dst[((t0 + t) * 64 + lane) * 4 + 2 * j] = a;
+      dst[((t0 + t) * 64 + lane) * 4 + 2 * j + 1] = b;
+    }
+}
+
+extern "C" int ox_window_retile(const ox_sell *A, const int64_t *wt_ptr, const void *src, int elem_bytes, void *dst, void *stream) {
+  if (!A || !wt_ptr || !src || !dst) OX_FAIL("ox_window_retile: null argument");
+  if (elem_bytes != 1 && elem_bytes != 2) OX_FAIL("ox_window_retile: elem_bytes=%d", elem_bytes);
+  const int nblk = (A->n_slices + 3) / 4;
+  if (nblk == 0) return 0;
+  if (elem_bytes == 1)
+    hipLaunchKernelGGL(k_window_retile<uint8_t>, dim3(nblk), dim3(256), 0, ox_stream(stream), *A, wt_ptr,
+                       static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst));
+  else
+    hipLaunchKernelGGL(k_window_retile<uint16_t>, dim3(nblk), dim3(256), 0, ox_stream(stream), *A, wt_ptr,
+                       static_cast<const uint16_t *>(src), static_cast<uint16_t *>(dst));
+  OX_LAUNCH_CHECK();
   return 0;
 }
 

@@ -69,6 +69,26 @@ def default_key_bits(n_points: int, gdim: int, tile_bits: int) -> int:
     return int(min(18, max(b + 2, tile_bits + 1)))
 
 
+def default_brick_shift(n_points: int, gdim: int, bits: int) -> int:
+    """Brick order of the degree-2 spaces on lattice meshes (``locality_key(brick_shift=)``): bricks of about 8
+    points a side -- 512 rows, one window block of the LDS-window SpMV (``k_spmv_win``); shift = bits -
+    floor(log2(L / 8)) with L = points per direction as ``default_key_bits`` counts them, 0 (no bricks) below 16
+    points per direction.  The library's twin: ox_setup.hip ``default_brick_shift``."""
+    L = 1
+    while L ** gdim < n_points:
+        L += 1 if L < 64 else max(1, L // 64)
+    while L > 1 and (L - 1) ** gdim >= n_points:
+        L -= 1
+    nb = L // 8
+    if nb < 2:
+        return 0
+    lg = 0
+    while (2 << lg) <= nb:
+        lg += 1
+    bs = bits - lg
+    return bs if 0 < bs < bits else 0
+
+
 def mesh_is_lattice(mesh: Mesh) -> bool:
     """Vertices on a tensor grid?  Such a mesh has about n^(1/d) distinct values per coordinate, an
     unstructured one about n.  Lattice meshes are ordered by ``locality_key``'s tiles (whole x-lines stay
@@ -96,7 +116,7 @@ def mesh_is_lattice(mesh: Mesh) -> bool:
 
 
 def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bits: int,
-                 bits: int = 18, curve: bool = False) -> torch.Tensor:
+                 bits: int = 18, curve: bool = False, brick_shift: int = 0) -> torch.Tensor:
     """Ordering key of points: (tile_z, tile_y, z, y, x) -- lexicographic inside tiles that span the
     whole x extent and 1/2^tile_bits of the y and z extents.
 
@@ -119,6 +139,12 @@ def locality_key(x: torch.Tensor, lo: torch.Tensor, span: torch.Tensor, tile_bit
         return key
     for k in range(d - 1, 0, -1):  # tile index of the slow directions, slowest first
         key = (key << tile_bits) | (q[:, k] >> (bits - tile_bits))
+    if brick_shift > 0:  # (tile, brick_z, brick_y, brick_x, z, y, x): bricks of 2^brick_shift lattice steps a side
+        for k in range(d - 1, -1, -1):
+            key = (key << (bits - brick_shift)) | (q[:, k] >> brick_shift)
+        for k in range(d - 1, -1, -1):
+            key = (key << brick_shift) | (q[:, k] & ((1 << brick_shift) - 1))
+        return key
     for k in range(d - 1, -1, -1):
         key = (key << bits) | q[:, k]
     return key
@@ -212,6 +238,111 @@ class SellPattern:
     def new_values(self) -> torch.Tensor:
         return torch.zeros(self.size, dtype=torch.float64, device=self.device)
 
+    def build_windows(self, row_pos: torch.Tensor, sort_window: int, slices_per_block: int = 8):
+        """LDS-window stream of the pattern (``ox_sell.wb_*`` / ``wlist`` / ``wcode``; kernel: k_spmv_win).
+
+        ``row_pos[r]``: position of row r in the pure locality order (before the length sort inside windows of
+        ``sort_window`` rows).  Inside every sort window the slices are ordered by the mean position of their rows and
+        cut into blocks of ``slices_per_block``: on a box mesh in brick order a block is then the rows of one 8^3
+        brick, whatever their lengths; on any mesh, rows that are neighbours along the curve.  Per block: the sorted
+        distinct columns of its entries (the window), a 16-bit index into it for every entry, and the wave that
+        multiplies each of its slices (longest-processing-time schedule over 4 waves)."""
+        dev = self.device
+        ns = self.n_slices
+        if ns == 0 or self.size == 0:
+            return False
+        spb = int(slices_per_block)
+        assert 1 <= spb <= 8
+        width = torch.from_numpy(self.widths.astype(np.int64)).to(dev)  # entries per row of each slice
+        # mean locality position of each slice's rows
+        pos = torch.zeros(ns * SLICE, dtype=torch.float64, device=dev)
+        pos[: self.n_rows] = row_pos[: self.n_rows].to(torch.float64)
+        if self.n_rows < ns * SLICE:
+            pos[self.n_rows:] = pos[self.n_rows - 1]
+        cent = pos.reshape(ns, SLICE).mean(dim=1)
+        spw = max(1, sort_window // SLICE)
+        sl = torch.arange(ns, device=dev)
+        wkey = (sl // spw).to(torch.float64) * float(2 * ns * SLICE + 2) + cent  # (sort window, centroid)
+        order = torch.argsort(wkey, stable=True)
+        # blocks never straddle a sort window
+        win_of = (order // spw)
+        first = torch.ones(ns, dtype=torch.bool, device=dev)
+        first[1:] = win_of[1:] != win_of[:-1]
+        idx_in_win = torch.arange(ns, device=dev) - torch.cummax(torch.where(first, torch.arange(ns, device=dev), torch.zeros_like(sl)), 0).values
+        newblk = first | (idx_in_win % spb == 0)
+        blk_of_ordered = torch.cumsum(newblk.to(torch.int64), 0) - 1
+        nb = int(blk_of_ordered[-1].item()) + 1
+        slot_in_blk = torch.arange(ns, device=dev) - torch.cummax(torch.where(newblk, torch.arange(ns, device=dev), torch.zeros_like(sl)), 0).values
+        wb_slices = torch.full((nb, 8), -1, dtype=torch.int32, device=dev)
+        wb_slices[blk_of_ordered, slot_in_blk] = order.to(torch.int32)
+        blk_of_slice = torch.empty(ns, dtype=torch.int64, device=dev)
+        blk_of_slice[order] = blk_of_ordered
+        # longest-processing-time schedule of each block's slices over 4 waves
+        wmat = torch.zeros((nb, 8), dtype=torch.int64, device=dev)
+        ok = wb_slices >= 0
+        wmat[ok] = width[wb_slices[ok].to(torch.int64)]
+        by_w = torch.argsort(-wmat, dim=1, stable=True)
+        load = torch.zeros((nb, 4), dtype=torch.int64, device=dev)
+        waves = torch.zeros((nb, 8), dtype=torch.int64, device=dev)
+        rows_b = torch.arange(nb, device=dev)
+        for j in range(8):
+            col = by_w[:, j]
+            w = torch.argmin(load, dim=1)
+            waves[rows_b, col] = w
+            load[rows_b, w] += wmat[rows_b, col]
+        sched = torch.zeros(nb, dtype=torch.int64, device=dev)
+        for j in range(8):
+            sched |= waves[:, j] << (2 * j)
+        # windows: distinct (block, column) keys, chunked over blocks to bound the sort's memory
+        slot_per_slice = width * SLICE
+        wb_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        wcode = torch.zeros(self.size, dtype=torch.int16, device=dev)
+        lists = []
+        ncols = self.n_cols
+        # slices of a block are scattered: go through the slot array once per chunk of SLICES (in storage order)
+        chunk_slices = max(1, int((1 << 27) // max(int(slot_per_slice.max().item()), 1)))
+        sp = self.slice_ptr
+        uk_all = []
+        for s0 in range(0, ns, chunk_slices):
+            s1 = min(ns, s0 + chunk_slices)
+            a, b = int(sp[s0].item()), int(sp[s1].item())
+            bs = torch.repeat_interleave(blk_of_slice[s0:s1], slot_per_slice[s0:s1])
+            uk_all.append(torch.unique(bs * ncols + self.cols[a:b].to(torch.int64)))
+        ukey = torch.unique(torch.cat(uk_all)) if len(uk_all) > 1 else uk_all[0]
+        del uk_all
+        ub = torch.div(ukey, ncols, rounding_mode="floor")
+        wb_ptr[1:] = torch.cumsum(torch.bincount(ub, minlength=nb), 0)
+        wlist = (ukey - ub * ncols).to(torch.int32)
+        w_all = wb_ptr[1:] - wb_ptr[:-1]
+        w_max = int(w_all.max().item())
+        big = w_all > 65535  # a 16-bit index cannot address such a window: its codes stay 0, the kernel reads `cols`
+        for s0 in range(0, ns, chunk_slices):
+            s1 = min(ns, s0 + chunk_slices)
+            a, b = int(sp[s0].item()), int(sp[s1].item())
+            bs = torch.repeat_interleave(blk_of_slice[s0:s1], slot_per_slice[s0:s1])
+            code = torch.searchsorted(ukey, bs * ncols + self.cols[a:b].to(torch.int64)) - wb_ptr[bs]
+            code = torch.where(big[bs], torch.zeros_like(code), code)
+            wcode[a:b] = (code & 0xffff).to(torch.int32).to(torch.int16)  # two's complement: the kernel reads uint16
+        # tile layout of the code stream (ox_sell.wt_ptr): 2 pairs = 4 entries of a lane per 8-byte load
+        npair = width // KV
+        wt_ptr = torch.zeros(ns + 1, dtype=torch.int64, device=dev)
+        wt_ptr[1:] = torch.cumsum((npair + 1) // 2, 0)
+        n_tiles = int(wt_ptr[-1].item())
+        plain = _lib.ox_sell(self.n_rows, self.n_cols, self.n_slices, 0, self.slice_ptr.data_ptr(), self.cols.data_ptr())
+        tiled = torch.empty(n_tiles * 256, dtype=torch.int16, device=dev)
+        _lib.check(_lib.load().ox_window_retile(C.byref(plain), _lib.ptr(wt_ptr), _lib.ptr(wcode), 2, _lib.ptr(tiled),
+                                                _lib.current_stream()), "ox_window_retile")
+        del wcode
+        self.wb_slices, self.wb_waves = wb_slices.contiguous(), sched.to(torch.int32).to(torch.int16).contiguous()
+        self.wb_ptr, self.wlist, self.wcode, self.wt_ptr = wb_ptr, wlist.contiguous(), tiled, wt_ptr
+        self.n_wblocks, self.w_max = nb, w_max
+        wq = torch.quantile(w_all.to(torch.float64), torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev))
+        self.w_stats = {"blocks": nb, "w_mean": float(w_all.to(torch.float64).mean().item()), "w_max": w_max,
+                        "w_p50_p90_p99": [int(v) for v in wq.tolist()],
+                        "share_over_2176": float((w_all > 2176).to(torch.float64).mean().item()),
+                        "list_bytes": int(wlist.numel()) * 4, "over_16bit": int(big.sum().item())}
+        return True
+
     def struct(self, vals: torch.Tensor, compress: bool = True) -> _lib.ox_sell:
         """ox_sell of a value array on this pattern.  On the GPU the pattern's 16-bit column stream
         is built on first use (``ox_sell_compress_cols``) and shared by all its matrices."""
@@ -233,6 +364,10 @@ class SellPattern:
                          self.cols.data_ptr(), vals.data_ptr(), c16, cb, None, None)
         if self.ib_slices is not None:
             S.ib_slices, S.n_interior = self.ib_slices.data_ptr(), self.n_interior
+        if getattr(self, "wcode", None) is not None:
+            S.wb_slices, S.wb_waves, S.wb_ptr = self.wb_slices.data_ptr(), self.wb_waves.data_ptr(), self.wb_ptr.data_ptr()
+            S.wlist, S.wcode, S.n_wblocks, S.w_max = self.wlist.data_ptr(), self.wcode.data_ptr(), self.n_wblocks, self.w_max
+            S.wt_ptr = self.wt_ptr.data_ptr()
         return S
 
     def bins_args(self):
@@ -315,15 +450,22 @@ class FunctionSpace:
     an owned dof (own cells + one ghost layer), so that every owned row is assembled locally."""
 
     def __init__(self, mesh: Mesh, degree: int, window: int = 4096, part=None,
-                 block_pairs: int = 1 << 24, block_nnz: int = 1 << 27):
+                 block_pairs: int = 1 << 24, block_nnz: int = 1 << 27, brick: bool | None = None):
         if degree not in (1, 2):
             raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
+        # brick order of the numbering (lattice meshes, one GPU): what the LDS-window SpMV needs, a loss for the
+        # lane = row kernels -- only together with ``build_windows`` (FractionalStep_AB_CN options["spmv_windows"]);
+        # OX_BRICK=1 forces it for tuning runs
+        if brick is None:
+            brick = _os.environ.get("OX_BRICK", "0") == "1"
+        self.brick = bool(brick) and part is None and degree >= 2
         self.mesh = mesh
         self.degree = degree
         self.element = _Element(degree, mesh.gdim)
         self.num_sub_spaces = 0
         self.part = part
         self.native = None
+        self.window = int(window)
         dev = mesh.device
         if dev.type == "cuda" and _os.environ.get("OX_SETUP", "native") != "torch":
             # the whole set-up runs inside liboasisx_hip.so (csrc/ox_setup.hip, behind the C ABI of
@@ -392,7 +534,10 @@ class FunctionSpace:
             xL[~isv] = 0.5 * (mesh.coords[torch.div(ek, nverts, rounding_mode="floor")] + mesh.coords[ek % nverts])
         del isv
         # ---- 2. owned dofs in tiled spatial order, then ghosts by (owner, global id) --------------
-        skey = locality_key(xL, lo, span, tb, default_key_bits(self.num_dofs_global, mesh.gdim, tb), curve)
+        kb = default_key_bits(self.num_dofs_global, mesh.gdim, tb)
+        bs = default_brick_shift(self.num_dofs_global, mesh.gdim, kb) if (self.brick and not curve) else 0
+        self._key = (lo, span, tb, kb, curve, bs)
+        skey = locality_key(xL, lo, span, tb, kb, curve, bs)
         if owned is None:
             perm1 = torch.argsort(skey, stable=True)
             n_owned = nL
@@ -483,13 +628,32 @@ class FunctionSpace:
         if part is not None:
             self.halo = self._build_halo(part, ghost_owner, cd0g)
 
+    def build_windows(self) -> bool:
+        """LDS-window stream of the space's square pattern (M, K, A share it): see ``SellPattern.build_windows``.
+        The rows' positions in the pure locality order are recomputed from the dof coordinates with the key the
+        numbering was made with."""
+        mesh = self.mesh
+        if mesh.device.type != "cuda" or self.pattern.size == 0 or getattr(self.pattern, "wcode", None) is not None:
+            return getattr(self.pattern, "wcode", None) is not None
+        lo = mesh.coords.min(dim=0).values
+        span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
+        tb = self.native.nmesh.tile_bits if self.native is not None else default_tile_bits(mesh)
+        curve = not mesh_is_lattice(mesh)
+        kb = default_key_bits(self.num_dofs_global, mesh.gdim, tb)
+        bs = default_brick_shift(self.num_dofs_global, mesh.gdim, kb) if (self.brick and not curve) else 0
+        key = locality_key(self.x[: self.n_owned], lo, span, tb, kb, curve, bs)
+        order = torch.argsort(key, stable=True)
+        row_pos = torch.empty_like(order)
+        row_pos[order] = torch.arange(order.shape[0], device=order.device)
+        return self.pattern.build_windows(row_pos, self.window)
+
     def _init_native(self, window: int, part=None):
         from . import native as N
 
         mesh, dev = self.mesh, self.mesh.device
         d = mesh.gdim
         if part is None:
-            ns = N.NativeSpace(mesh, self.degree, window)
+            ns = N.NativeSpace(mesh, self.degree, window, brick=self.brick)
             nc = mesh.num_cells
         else:
             # initial dof ids of this rank's part: its vertices (ascending global id), then its edges (ascending key)

@@ -123,7 +123,11 @@ class FractionalStep_AB_CN:
 
             part = MeshPartition(mesh, comm.rank, comm.size, comm)
         self._part = part
-        Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part)
+        # options["spmv_windows"]: brick order of the velocity numbering + the LDS-window stream of its pattern
+        # (measured a wash on the whole step at 128^3 -- off unless asked for)
+        windows = bool((options or {}).get("spmv_windows", False)) and part is None
+        Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part,
+                                                                                  brick=windows)
         if isinstance(p_element, FunctionSpace):
             Q = p_element
         else:
@@ -238,6 +242,9 @@ class FractionalStep_AB_CN:
             self._p_vdxi_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "p_vdxi")
             self._grad_p_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "grad_p")
             self._divu_Mat = MultiSellMatrix(self._pat_qv, mesh.gdim, "divu")
+        # LDS-window stream of the velocity pattern (M, K, A share it): single-GPU operators of a degree-2 space
+        if self._options.get("spmv_windows", False) and Vi.degree >= 2 and self._part is None and mesh.device.type == "cuda":
+            Vi.build_windows()
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
         self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")
         self._A = SellMatrix(Vi.pattern, symmetric=False, name="A")

@@ -21,6 +21,7 @@ class SellMatrix:
         self.vcode = self.vdict = self._vc_version = None  # value dictionary, see freeze()
         self.ps_ptr = self.ps_code = self.ps_base = None  # pair-slot stream, see freeze()
         self.ps_wide = 0
+        self.wvcode = None  # value codes in the tile layout of the pattern's LDS-window stream, see freeze()
         self._struct = pattern.struct(self.vals)
 
     @property
@@ -38,6 +39,8 @@ class SellMatrix:
         self._struct.n_dict = 0
         self.ps_ptr = self.ps_code = self.ps_base = None
         self._struct.ps_ptr = self._struct.ps_code = self._struct.ps_base = None
+        self.wvcode = None
+        self._struct.wvcode = None
 
     def freeze(self, block: int = 1 << 27, pairs: str = "auto") -> bool:
         """Value dictionary for a matrix whose values will not change any more (M, Ap: assembled
@@ -64,6 +67,13 @@ class SellMatrix:
         self._struct.n_dict = int(nd.value)
         if pairs != "never":
             self._build_pair_stream(force=pairs == "always")
+        if getattr(P, "wt_ptr", None) is not None and self.ps_code is None:
+            # the pattern carries an LDS-window stream: the value codes once more in its tile layout (4 codes of a
+            # lane per 4-byte load)
+            self.wvcode = torch.empty(int(P.wt_ptr[-1].item()) * 256, dtype=torch.uint8, device=P.device)
+            _lib.check(_lib.load().ox_window_retile(C.byref(self._struct), _lib.ptr(P.wt_ptr), _lib.ptr(self.vcode), 1,
+                                                    _lib.ptr(self.wvcode), _lib.current_stream()), "ox_window_retile")
+            self._struct.wvcode = self.wvcode.data_ptr()
         return True
 
     def _build_pair_stream(self, force: bool = False):

@@ -142,7 +142,7 @@ class NativeSubMesh:
 
 
 class NativeSpace:
-    def __init__(self, mesh, degree: int, window: int, part=None, owner=None, n_dofs_whole: int = 0):
+    def __init__(self, mesh, degree: int, window: int, part=None, owner=None, n_dofs_whole: int = 0, brick: bool = False):
         lib = _lib.load()
         out = C.c_void_p()
         if part is not None:  # one rank's piece of a mesh-partitioned space
@@ -152,7 +152,8 @@ class NativeSpace:
                        "ox_space_create_part")
         else:
             self.nmesh = NativeMesh.of(mesh)
-            _lib.check(lib.ox_space_create(self.nmesh.handle.ptr, int(degree), int(window), C.byref(out)), "ox_space_create")
+            _lib.check(lib.ox_space_create_ordered(self.nmesh.handle.ptr, int(degree), int(window), 1 if brick else 0,
+                                                   C.byref(out)), "ox_space_create_ordered")
         self.handle = _Handle(out, lib.ox_space_destroy)
         self.handle._mesh = self.nmesh  # the space reads the mesh object: keep it alive
         v = _lib.ox_space_info()
