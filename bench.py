@@ -367,10 +367,13 @@ def main():
                    **({"spmv_windows": args.spmv_windows == "true"} if args.spmv_windows else {}))
     mesh, S = build(N, args.udeg, options, args.zero_guess)
 
-    def workload_leg(wname, steps=5, warmup=3):
+    def workload_leg(wname, steps=5, warmup=3, delaunay=None):
         """Another workload with the main run's mesh size, options and Krylov settings: its own solver, set up,
-        warmed up and timed here (barrier + synchronize on both sides), then released."""
-        W2 = make_workload(wname, N, np, torch)
+        warmed up and timed here (barrier + synchronize on both sides), then released.  ``delaunay=(n, refine)``: on
+        an UNSTRUCTURED mesh of the same size instead -- the Delaunay triangulation of a jittered (n+1)^3 lattice,
+        refined uniformly ``refine`` times (32, 2: 14.0 M tetrahedra, 18.9 M P2 dofs per component; no value
+        dictionaries, Z-order numbering, the velocity mat-vecs on the LDS-window stream)."""
+        W2 = make_workload(wname, N if delaunay is None else delaunay[0] << delaunay[1], np, torch)
         q0, q1 = W2["box"]
         clk = {"t": 0.0}
 
@@ -387,7 +390,11 @@ def main():
             return g
 
         t0 = time.perf_counter()
-        m2 = M.create_box(comm, [q0, q1], [N, N, N])
+        if delaunay is None:
+            m2 = M.create_box(comm, [q0, q1], [N, N, N])
+        else:
+            m2 = M.create_delaunay_box(comm, [q0, q1], delaunay[0], refine=delaunay[1])
+        t_mesh = time.perf_counter() - t0
         ksp = {"pc_type": "jacobi", "ksp_rtol": args.rtol, "ksp_atol": 1e-14, "ksp_max_it": 10000,
                "ksp_initial_guess_nonzero": not args.zero_guess}
         tent = dict(ksp, ksp_type="bcgs")
@@ -414,16 +421,29 @@ def main():
         for _ in range(warmup):
             one()
         torch.cuda.synchronize()
+        _lib.check(lib.ox_profile_begin(200000, args.profile_every), "ox_profile_begin")
         t0 = time.perf_counter()
         for _ in range(steps):
             one()
             its2.append(S2.iteration_counts())
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        _lib.check(lib.ox_profile_end(), "ox_profile_end")
+        leg_kernels = kernel_table(S2, bool(S2._solver_p._cg_merged()))
+        mesh_txt = (f"{N}^3x6 tets" if delaunay is None else
+                    f"Delaunay mesh of a jittered {delaunay[0] + 1}^3 lattice refined uniformly {delaunay[1]}x "
+                    f"({m2.num_cells} tets, {S2._Vi[0][0].num_dofs_global} P2 dofs per component)")
         res = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
-               "workload": f"{W2['desc']}, {N}^3x6 tets P{args.udeg}-P1, nu={W2['nu']}, dt={W2['dt']:g}",
+               "workload": f"{W2['desc']}, {mesh_txt} P{args.udeg}-P1, nu={W2['nu']}, dt={W2['dt']:g}",
                "krylov_iterations_per_step": mean_iterations(its2), "krylov_iterations_series": iteration_series(its2),
-               "setup_s": t_set}
+               "setup_s": t_set, "mesh_generation_s": t_mesh,
+               "kernels": {k: {a: b for a, b in v.items() if a in ("launches", "avg_us", "bytes_moved", "gbs", "frac_of_hbm_peak")}
+                           for k, v in leg_kernels.items()}}
+        if delaunay is not None:
+            P2_ = S2._M.pattern
+            res["storage"] = {"nnz_velocity": P2_.nnz, "slots": P2_.size, "padding": P2_.size / P2_.nnz - 1.0,
+                              "cols16_fraction": P2_.frac16, "value_dictionary": S2._M.vcode is not None,
+                              "spmv_windows": getattr(P2_, "w_stats", None)}
         if W2["analytic"]:
             Xd2 = S2._Vi[0][0].x[: S2._n_u].T
             res["max_nodal_error_u_vs_analytic"] = max(
@@ -437,7 +457,9 @@ def main():
                 chk = run_cpu_baseline(
                     S2, clk, W2["dt"], W2["nu"], {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess},
                     lambda X, t: np.stack([np.asarray(f(X, t), dtype=np.float64) for f in W2["fns"]]), gpu_step=one,
-                    mesh_def=(q0, q1, [N, N, N]), threads_1=False, scipy_check=False)
+                    mesh_def=((q0, q1, [N, N, N]) if delaunay is None else
+                              {"coords": m2.coords.cpu().numpy(), "cells": m2.cells.cpu().numpy(), "lo": q0, "hi": q1}),
+                    threads_1=False, scipy_check=False)
                 res["cpu_cross_check"] = {k: chk[k] for k in (
                     "gpu_vs_cpu_rel_l2_u", "gpu_vs_cpu_rel_l2_p", "gpu_vs_cpu_max_abs_u", "gpu_vs_cpu_shared", "value", "cores",
                     "seconds", "setup_seconds", "krylov_iterations", "gpu_krylov_iterations") if k in chk}
@@ -570,6 +592,13 @@ def main():
         elsewhere), the per-pair bases, slice offsets and the x / y vectors -- padding included.  A matrix
         with a pair-slot stream is read from that instead (4 B per slot of two adjacent columns)."""
         P = A.pattern
+        if getattr(A, "ps_code", None) is None and getattr(P, "wcode", None) is not None and A._struct.n_wblocks > 0:
+            # LDS-window stream: values (f64, or 1-byte codes in the tile layout), 2-byte window indices (tile layout),
+            # the window lists, x[window] per block, y
+            tiles = P.wcode.numel()
+            vals = tiles if getattr(A, "wvcode", None) is not None else 8 * P.size
+            return int(vals + 2 * tiles + 4 * P.wlist.numel() + 8 * (P.n_slices + 1) + 8 * (P.n_wblocks + 1)
+                       + nc * 8 * (P.wlist.numel() + P.n_rows))
         if getattr(A, "ps_code", None) is not None:  # pair-slot stream: 4 B per slot, per-group bases, slice offsets
             n = A.ps_code.numel()
             return int(4 * n + 8 * (n // 256) + 8 * (P.n_slices + 1) + nc * 8 * (P.n_cols + P.n_rows))
@@ -595,7 +624,8 @@ def main():
                 "kernels_per_iteration": 3 if cg_merged else 5,
                 "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else "standard CG"}
 
-    cg_merged = bool(S._solver_p._cg_merged())  # the one-column pressure solve runs OX_KSP_CG_MERGED
+    S_main = S
+    cg_merged = cg_merged_main = bool(S._solver_p._cg_merged())  # the one-column pressure solve runs OX_KSP_CG_MERGED
     # (computed now: the variant legs below drop the dictionaries of this solver)
     piter_line = (pressure_iteration_line(phase_ms["pressure_solve"], mean_iterations(its)["pressure"])
                   if phase_ms.get("pressure_solve") else None)
@@ -607,7 +637,14 @@ def main():
     b_u1 = spmv_bytes(Pu.nnz, Pu.n_rows, Pu.n_cols)  # narrowed (1-column) solves on the velocity matrix
     ku, kp = Pu.n_rows, Pp.n_rows  # SpMV records are keyed by the matrix's row count
 
-    def kernel_table():
+    def kernel_table(S=None, cg_merged=None):
+        S = S_main if S is None else S
+        cg_merged = cg_merged_main if cg_merged is None else cg_merged
+        Pp, Pu = S._Ap.pattern, S._M.pattern
+        b_p = spmv_bytes(Pp.nnz, Pp.n_rows, Pp.n_cols)
+        b_u = 12 * Pu.nnz + 4 * (Pu.n_rows + 1) + gd * 8 * (Pu.n_cols + Pu.n_rows)  # matrix once, gd x/y vectors
+        b_u1 = spmv_bytes(Pu.nnz, Pu.n_rows, Pu.n_cols)  # narrowed (1-column) solves on the velocity matrix
+        ku, kp = Pu.n_rows, Pp.n_rows  # SpMV records are keyed by the matrix's row count
         kernels = {}
         sA3, sA1 = stored_bytes(S._A, gd), stored_bytes(S._A, 1)
         sM3, sM1 = stored_bytes(S._M, gd), stored_bytes(S._M, 1)
@@ -869,6 +906,7 @@ def main():
             import gc
 
             del S  # (the phase wrappers hold it in a cycle: collect before the next 49 GiB solver is built)
+            S_main = None
             gc.collect()
             torch.cuda.empty_cache()
             for wname in ("beltrami", "cavity"):
@@ -876,6 +914,15 @@ def main():
                     out["variants"]["workload=" + wname] = workload_leg(wname)
                 except Exception as e:
                     out["variants"]["workload=" + wname] = {"error": repr(e)}
+            # what an UNSTRUCTURED mesh of the metric's size gets (north_star: "the unstructured mesh"): same fields,
+            # same Krylov settings, a refined Delaunay mesh of 18.9 M P2 dofs per component
+            if args.udeg == 2 and N >= 96:
+                try:
+                    # (Beltrami: all three components live -- on this mesh the z-extruded field's w column, a round-off
+                    # right-hand side, would add ~180 narrowed BiCGStab iterations per step to both sides of the check)
+                    out["variants"]["mesh=delaunay"] = workload_leg("beltrami", delaunay=(32, 2))
+                except Exception as e:
+                    out["variants"]["mesh=delaunay"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -227,6 +227,19 @@ typedef struct {
   ox_pattern_info pattern;
 } ox_rect_info;
 
+/* LDS-window stream of a space's square pattern: the arrays ox_sell.wb_* / wlist / wt_ptr / wcode point to */
+typedef struct {
+  int32_t n_wblocks, w_max;     /* window blocks (8 slices each); entries of the largest window           */
+  int64_t n_list, n_tiles;      /* entries of wlist; tiles of wcode (256 codes each)                      */
+  int64_t n_over_16bit;         /* slices in blocks whose window exceeds 65535 entries (codes 0: read from cols) */
+  const int32_t *wb_slices;
+  const uint16_t *wb_waves;
+  const int64_t *wb_ptr;
+  const int32_t *wlist;
+  const int64_t *wt_ptr;
+  const uint16_t *wcode;
+} ox_window_info;
+
 /* coords [n_vertices][gdim] f64, cells [n_cells][gdim+1] int32 (any order, any orientation);
  * on_device: the two pointers are device pointers; tile_bits < 0: default.
  * Cells (and later the dofs) are ordered for the kernels: a lattice mesh (few distinct values per
@@ -260,6 +273,11 @@ int ox_mesh_create_sub(const double *coords, int64_t n_vertices, const int32_t *
 int ox_space_create_part(const ox_mesh *mesh, int degree, int window, const int32_t *owner, int64_t n_initial, int rank,
                          int64_t n_dofs_whole, ox_space **out);
 int ox_space_view(const ox_space *space, ox_space_info *view);
+/* LDS-window stream of the space's square pattern (M, K, A share it), built on the first call and owned by the space:
+ * copy the pointers into the ox_sell of every matrix on the pattern (the value codes of a dictionary matrix are
+ * re-tiled per matrix: ox_window_retile).  Worth it where the rows of 8 consecutive slices share their columns:
+ * any mesh in Z-order, box meshes in brick order (ox_space_create_ordered). */
+int ox_space_windows(ox_space *space, ox_window_info *view);
 int ox_space_destroy(ox_space *space);
 /* pattern of a mixed operator, rows = dofs of `rows`, columns = dofs of `cols` (fracstep.py:315,336,352) */
 int ox_rect_create(const ox_space *rows, const ox_space *cols, ox_rect **out);

@@ -52,6 +52,22 @@ class ox_sell(C.Structure):
     ]
 
 
+class ox_window_info(C.Structure):
+    _fields_ = [
+        ("n_wblocks", C.c_int32),
+        ("w_max", C.c_int32),
+        ("n_list", C.c_int64),
+        ("n_tiles", C.c_int64),
+        ("n_over_16bit", C.c_int64),
+        ("wb_slices", C.c_void_p),
+        ("wb_waves", C.c_void_p),
+        ("wb_ptr", C.c_void_p),
+        ("wlist", C.c_void_p),
+        ("wt_ptr", C.c_void_p),
+        ("wcode", C.c_void_p),
+    ]
+
+
 class ox_cells(C.Structure):
     _fields_ = [
         ("gdim", C.c_int32),
@@ -159,6 +175,7 @@ SIGNATURES = {
     "ox_mesh_create_sub": (_I, [_P, _L, _P, _L, _I, _I, C.POINTER(_D), C.POINTER(_D), _I, _I, _L, C.POINTER(_P)]),
     "ox_space_create_part": (_I, [_P, _I, _I, _P, _L, _I, _L, C.POINTER(_P)]),
     "ox_space_view": (_I, [_P, C.POINTER(ox_space_info)]),
+    "ox_space_windows": (_I, [_P, C.POINTER(ox_window_info)]),
     "ox_space_destroy": (_I, [_P]),
     "ox_rect_create": (_I, [_P, _P, C.POINTER(_P)]),
     "ox_rect_view": (_I, [_P, C.POINTER(ox_rect_info)]),

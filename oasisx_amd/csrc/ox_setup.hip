@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -566,6 +567,12 @@ struct ox_space {
   DevBuf start, pair;   // pairs grouped by final dof (kept for rectangular patterns)
   DevBuf adj_ptr, adj_cell, adj_loc, adj_pos, adj_count;
   ox_pattern_store P;
+  DevBuf row_pos;       // [n] int32: position of final row r in the pure locality order (before the length sort)
+  // LDS-window stream of the square pattern (ox_space_windows; built on first request)
+  DevBuf wb_slices, wb_waves, wb_ptr, wlist, wt_ptr, wcode;
+  int32_t n_wblocks = 0, w_max = 0;
+  int64_t n_list = 0, n_tiles = 0, n_over_16bit = 0;
+  bool windows_built = false;
 };
 
 struct ox_rect {
@@ -1086,7 +1093,9 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
                      n_owned, P.row_len.as<int32_t>());
   OX_LAUNCH_CHECK();
   OX_HIP(hipStreamSynchronize(st));
-  cd0.release(), xL.release(), rank1.release(), rank2.release(), perm2.release(), len1.release();
+  V->row_pos.p = perm2.detach();  // final row r was row perm2[r] of the locality order: what ox_space_windows clusters by
+  V->row_pos.bytes = sizeof(int32_t) * (size_t)n;
+  cd0.release(), xL.release(), rank1.release(), rank2.release(), len1.release();
   // ---- 5. final adjacency, SELL layout, columns and position bytes ------------------------------------
   OX_TRY(group_pairs(V->cell_dofs.as<int32_t>(), nc, nd, n, V->start, V->pair, st));
   OX_TRY(layout_slices(P, V->start.as<int64_t>(), &V->adj_ptr, &V->npairs, st));
@@ -1163,6 +1172,322 @@ extern "C" int ox_space_view(const ox_space *V, ox_space_info *v) {
   v->adj_pos = V->adj_pos.as<uint8_t>();
   v->pair_start = V->start.as<int64_t>();
   fill_pattern_view(V->P, &v->pattern);
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-window stream of a space's square pattern (ox_sell.wb_* / wlist / wt_ptr / wcode; kernel k_spmv_win, ox_spmv.hip).
+// Inside every length-sort window (V->window rows = spw slices, contiguous in storage) the slices are ordered by the
+// mean locality position of their rows and cut into blocks of 8: on a box mesh in brick order a block is the rows of
+// one brick, whatever their lengths; on any mesh, rows that are neighbours along the ordering curve.  Per block: the
+// ascending distinct columns of its entries (the window), a 16-bit index into it for every entry (tile layout: 2
+// storage pairs of a lane per 8-byte load) and the wave (0..3) that multiplies each of its slices (longest-processing-
+// time schedule).  Everything on the device; the window lists come from radix sorts of (block, column) keys over
+// chunks of whole sort windows.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_win_slice_keys(const int32_t *__restrict__ row_pos, int64_t n_rows, int n_slices, int spw,
+                                                        uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= n_slices) return;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  long long v = row < n_rows ? (long long)row_pos[row] : 0;
+  int cnt = row < n_rows ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_down(v, off, 64);
+    cnt += __shfl_down(cnt, off, 64);
+  }
+  if (lane == 0) {
+    const uint64_t mean64 = cnt > 0 ? (uint64_t)((v * 64) / cnt) : 0;  // < 2^37
+    keys[slice] = ((uint64_t)(slice / spw) << 40) | mean64;
+    ids[slice] = slice;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_win_blocks(const int32_t *__restrict__ order, int n_slices, int spw, int bpw,
+                                                    int32_t *__restrict__ wb_slices, int32_t *__restrict__ blk_of_slice) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_slices) return;
+  const int slice = order[i];
+  const int w = i / spw, j = i - w * spw;  // the windows are contiguous runs of spw slices, in the sorted order too
+  const int b = w * bpw + (j >> 3);
+  wb_slices[(size_t)b * 8 + (j & 7)] = slice;
+  blk_of_slice[slice] = b;
+}
+
+__global__ __launch_bounds__(256) void k_win_schedule(const int32_t *__restrict__ wb_slices, const int64_t *__restrict__ slice_ptr,
+                                                      int n_blocks, uint16_t *__restrict__ wb_waves) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  int w[8], idx[8];
+  for (int j = 0; j < 8; ++j) {
+    const int s = wb_slices[(size_t)b * 8 + j];
+    w[j] = s >= 0 ? (int)((slice_ptr[s + 1] - slice_ptr[s]) >> 7) : 0;
+    idx[j] = j;
+  }
+  for (int a = 1; a < 8; ++a) {  // stable insertion sort by decreasing width
+    const int wa = w[a], ia = idx[a];
+    int q = a - 1;
+    while (q >= 0 && w[q] < wa) {
+      w[q + 1] = w[q], idx[q + 1] = idx[q];
+      --q;
+    }
+    w[q + 1] = wa, idx[q + 1] = ia;
+  }
+  int load[4] = {0, 0, 0, 0};
+  unsigned sched = 0;
+  for (int a = 0; a < 8; ++a) {  // longest processing time first: the next slice to the least loaded wave
+    int m = 0;
+    for (int k = 1; k < 4; ++k)
+      if (load[k] < load[m]) m = k;
+    load[m] += w[a];
+    sched |= (unsigned)m << (2 * idx[a]);
+  }
+  wb_waves[b] = (uint16_t)sched;
+}
+
+// (block, column) keys of the slots of slices [s0, s1): key slot i - slot0
+__global__ __launch_bounds__(256) void k_win_entry_keys(const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ cols,
+                                                        const int32_t *__restrict__ blk_of_slice, int s0, int s1, int64_t slot0,
+                                                        uint64_t *__restrict__ keys) {
+  const int slice = s0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= s1) return;
+  const int64_t base = slice_ptr[slice], end = slice_ptr[slice + 1];
+  const uint64_t hi = (uint64_t)(uint32_t)blk_of_slice[slice] << 32;
+  for (int64_t e = base + lane; e < end; e += 64) keys[e - slot0] = hi | (uint32_t)cols[e];
+}
+
+__global__ __launch_bounds__(256) void k_win_flag_unique(const uint64_t *__restrict__ keys, int64_t n, int64_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_win_compact(const uint64_t *__restrict__ keys, const int64_t *__restrict__ pos, int64_t n,
+                                                     uint64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && (i == 0 || keys[i] != keys[i - 1])) out[pos[i]] = keys[i];
+}
+
+__global__ __launch_bounds__(256) void k_win_block_ptr(const uint64_t *__restrict__ ukey, int64_t n, int n_blocks,
+                                                       int64_t *__restrict__ wb_ptr, int32_t *__restrict__ wsize) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b > n_blocks) return;
+  auto lower = [&](uint64_t target) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (ukey[mid] < target) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t a = lower((uint64_t)(uint32_t)b << 32);
+  wb_ptr[b] = a;
+  if (b < n_blocks) wsize[b] = (int32_t)(lower((uint64_t)(uint32_t)(b + 1) << 32) - a);
+}
+__global__ __launch_bounds__(256) void k_win_list(const uint64_t *__restrict__ ukey, int64_t n, int32_t *__restrict__ wlist) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) wlist[i] = (int32_t)(uint32_t)(ukey[i] & 0xffffffffull);
+}
+
+__global__ __launch_bounds__(256) void k_win_ntiles(const int64_t *__restrict__ slice_ptr, int n_slices, int64_t *__restrict__ nt) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n_slices) nt[s] = (((slice_ptr[s + 1] - slice_ptr[s]) >> 7) + 1) >> 1;
+  if (s == n_slices) nt[s] = 0;
+}
+
+// window index of every entry, written in the tile layout
+__global__ __launch_bounds__(256) void k_win_codes(const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ cols, int n_slices,
+                                                   const int32_t *__restrict__ blk_of_slice, const int64_t *__restrict__ wb_ptr,
+                                                   const int32_t *__restrict__ wlist, const int64_t *__restrict__ wt_ptr,
+                                                   uint16_t *__restrict__ wcode, unsigned long long *__restrict__ n_over) {
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= n_slices) return;
+  const int64_t base = slice_ptr[slice];
+  const int npair = (int)((slice_ptr[slice + 1] - base) >> 7);
+  const int b = blk_of_slice[slice];
+  const int64_t w0 = wb_ptr[b];
+  const int W = (int)(wb_ptr[b + 1] - w0);
+  const int32_t *__restrict__ wl = wlist + w0;
+  const int64_t t0 = wt_ptr[slice];
+  const int ntile = (npair + 1) >> 1;
+  const bool big = W > 65535;  // a 16-bit index cannot address such a window: codes 0, the kernel multiplies from `cols`
+  if (big && lane == 0) atomicAdd(n_over, 1ull);
+  for (int t = 0; t < ntile; ++t)
+    for (int j = 0; j < 2; ++j) {
+      const int k = 2 * t + j;
+      uint16_t code[2] = {0, 0};
+      if (k < npair && !big) {
+        for (int i = 0; i < 2; ++i) {
+          const int32_t c = cols[base + (int64_t)k * 128 + lane * 2 + i];
+          int lo = 0, hi = W;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (wl[mid] < c) lo = mid + 1;
+            else hi = mid;
+          }
+          code[i] = (uint16_t)lo;
+        }
+      }
+      wcode[((t0 + t) * 64 + lane) * 4 + 2 * j] = code[0];
+      wcode[((t0 + t) * 64 + lane) * 4 + 2 * j + 1] = code[1];
+    }
+}
+
+int build_windows(ox_space *V, hipStream_t st) {
+  const ox_pattern_store &P = V->P;
+  const int ns = (int)P.n_slices;
+  if (ns == 0 || P.size == 0) {
+    V->windows_built = true;
+    return 0;
+  }
+  const int spw = std::max(1, V->window / SLICE);
+  const int bpw = (spw + 7) / 8;
+  const int nwin = (ns + spw - 1) / spw;
+  const int c_last = ns - (nwin - 1) * spw;
+  const int nb = (nwin - 1) * bpw + (c_last + 7) / 8;
+  auto nblk = [](int64_t n) { return (unsigned)((n + 255) / 256); };
+  const int64_t *slice_ptr = P.slice_ptr.as<int64_t>();
+  const int32_t *cols = P.cols.as<int32_t>();
+  // ---- blocks ---------------------------------------------------------------------------------------------------
+  DevBuf order, blk_of_slice;
+  OX_TRY(order.alloc(sizeof(int32_t) * (size_t)ns));
+  OX_TRY(blk_of_slice.alloc(sizeof(int32_t) * (size_t)ns));
+  {
+    DevBuf k_in, k_out, v_in;
+    OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)ns));
+    OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)ns));
+    OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)ns));
+    hipLaunchKernelGGL(k_win_slice_keys, dim3((ns + 3) / 4), dim3(256), 0, st, V->row_pos.as<int32_t>(), P.n_rows, ns, spw,
+                       k_in.as<uint64_t>(), v_in.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), order.as<int32_t>(), (size_t)ns,
+                      std::min(64, 40 + bits_for((uint64_t)nwin)), st));
+  }
+  OX_TRY(V->wb_slices.alloc(sizeof(int32_t) * (size_t)nb * 8));
+  OX_HIP(hipMemsetAsync(V->wb_slices.p, 0xff, sizeof(int32_t) * (size_t)nb * 8, st));
+  hipLaunchKernelGGL(k_win_blocks, dim3(nblk(ns)), dim3(256), 0, st, order.as<int32_t>(), ns, spw, bpw, V->wb_slices.as<int32_t>(),
+                     blk_of_slice.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(V->wb_waves.alloc(sizeof(uint16_t) * (size_t)nb));
+  hipLaunchKernelGGL(k_win_schedule, dim3(nblk(nb)), dim3(256), 0, st, V->wb_slices.as<int32_t>(), slice_ptr, nb,
+                     V->wb_waves.as<uint16_t>());
+  OX_LAUNCH_CHECK();
+  order.release();
+  // ---- window lists: distinct (block, column) keys, chunks of whole sort windows ------------------------------------
+  std::vector<int64_t> sp_h((size_t)ns + 1);
+  OX_HIP(hipMemcpyAsync(sp_h.data(), slice_ptr, sizeof(int64_t) * ((size_t)ns + 1), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  const int64_t chunk_slots = (int64_t)1 << 28;  // 2 GiB of keys per chunk (+ the sort's double buffer)
+  std::vector<std::unique_ptr<DevBuf>> parts;
+  std::vector<int64_t> part_n;
+  int64_t total = 0;
+  for (int w0 = 0; w0 < nwin;) {
+    int w1 = w0 + 1;
+    const int s0 = w0 * spw;
+    while (w1 < nwin && sp_h[(size_t)std::min(ns, (w1 + 1) * spw)] - sp_h[(size_t)s0] <= chunk_slots) ++w1;
+    const int s1 = std::min(ns, w1 * spw);
+    const int64_t slot0 = sp_h[(size_t)s0], m = sp_h[(size_t)s1] - slot0;
+    if (m > 0) {
+      DevBuf k_in, k_out, flag, pos;
+      OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)m));
+      OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)m));
+      hipLaunchKernelGGL(k_win_entry_keys, dim3((s1 - s0 + 3) / 4), dim3(256), 0, st, slice_ptr, cols, blk_of_slice.as<int32_t>(), s0,
+                         s1, slot0, k_in.as<uint64_t>());
+      OX_LAUNCH_CHECK();
+      {
+        size_t tb = 0;
+        const int end_bit = std::min(64, 32 + bits_for((uint64_t)nb));
+        OX_HIP(rocprim::radix_sort_keys(nullptr, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
+        DevBuf tmp;
+        OX_TRY(tmp.alloc(tb));
+        OX_HIP(rocprim::radix_sort_keys(tmp.p, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
+        OX_HIP(hipStreamSynchronize(st));
+      }
+      k_in.release();
+      OX_TRY(flag.alloc(sizeof(int64_t) * ((size_t)m + 1)));
+      OX_TRY(pos.alloc(sizeof(int64_t) * ((size_t)m + 1)));
+      hipLaunchKernelGGL(k_win_flag_unique, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), m, flag.as<int64_t>());
+      OX_LAUNCH_CHECK();
+      OX_HIP(hipMemsetAsync(flag.as<int64_t>() + m, 0, sizeof(int64_t), st));
+      OX_TRY(exclusive_scan_i64(flag.as<int64_t>(), pos.as<int64_t>(), (size_t)m + 1, st));
+      int64_t nu = 0;
+      OX_HIP(hipMemcpyAsync(&nu, pos.as<int64_t>() + m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      OX_HIP(hipStreamSynchronize(st));
+      flag.release();
+      parts.emplace_back(new DevBuf());
+      OX_TRY(parts.back()->alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(nu, 1)));
+      hipLaunchKernelGGL(k_win_compact, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), pos.as<int64_t>(), m,
+                         parts.back()->as<uint64_t>());
+      OX_LAUNCH_CHECK();
+      OX_HIP(hipStreamSynchronize(st));
+      part_n.push_back(nu);
+      total += nu;
+    }
+    w0 = w1;
+  }
+  DevBuf ukey;
+  OX_TRY(ukey.alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(total, 1)));
+  {
+    int64_t off = 0;
+    for (size_t i = 0; i < parts.size(); ++i) {  // chunks are in block order: the concatenation is sorted
+      OX_HIP(hipMemcpyAsync(ukey.as<uint64_t>() + off, parts[i]->p, sizeof(uint64_t) * (size_t)part_n[i], hipMemcpyDeviceToDevice, st));
+      off += part_n[i];
+    }
+    OX_HIP(hipStreamSynchronize(st));
+    parts.clear();
+  }
+  OX_TRY(V->wb_ptr.alloc(sizeof(int64_t) * ((size_t)nb + 1)));
+  DevBuf wsize;
+  OX_TRY(wsize.alloc(sizeof(int32_t) * (size_t)nb));
+  hipLaunchKernelGGL(k_win_block_ptr, dim3(nblk(nb + 1)), dim3(256), 0, st, ukey.as<uint64_t>(), total, nb, V->wb_ptr.as<int64_t>(),
+                     wsize.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(V->wlist.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
+  hipLaunchKernelGGL(k_win_list, dim3(nblk(total)), dim3(256), 0, st, ukey.as<uint64_t>(), total, V->wlist.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  int32_t wmax = 0;
+  OX_TRY(reduce_max_i32(wsize.as<int32_t>(), nb, &wmax, st));
+  ukey.release(), wsize.release();
+  // ---- tile offsets and the 16-bit window index of every entry ----------------------------------------------------------
+  DevBuf nt;
+  OX_TRY(nt.alloc(sizeof(int64_t) * ((size_t)ns + 1)));
+  OX_TRY(V->wt_ptr.alloc(sizeof(int64_t) * ((size_t)ns + 1)));
+  hipLaunchKernelGGL(k_win_ntiles, dim3(nblk(ns + 1)), dim3(256), 0, st, slice_ptr, ns, nt.as<int64_t>());
+  OX_LAUNCH_CHECK();
+  OX_TRY(exclusive_scan_i64(nt.as<int64_t>(), V->wt_ptr.as<int64_t>(), (size_t)ns + 1, st));
+  int64_t n_tiles = 0;
+  OX_HIP(hipMemcpyAsync(&n_tiles, V->wt_ptr.as<int64_t>() + ns, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  OX_TRY(V->wcode.alloc(sizeof(uint16_t) * (size_t)std::max<int64_t>(n_tiles, 1) * 256));
+  DevBuf n_over;
+  OX_TRY(n_over.alloc(sizeof(unsigned long long)));
+  OX_HIP(hipMemsetAsync(n_over.p, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_win_codes, dim3((ns + 3) / 4), dim3(256), 0, st, slice_ptr, cols, ns, blk_of_slice.as<int32_t>(),
+                     V->wb_ptr.as<int64_t>(), V->wlist.as<int32_t>(), V->wt_ptr.as<int64_t>(), V->wcode.as<uint16_t>(),
+                     n_over.as<unsigned long long>());
+  OX_LAUNCH_CHECK();
+  unsigned long long over = 0;
+  OX_HIP(hipMemcpyAsync(&over, n_over.p, sizeof(over), hipMemcpyDeviceToHost, st));
+  OX_HIP(hipStreamSynchronize(st));
+  V->n_wblocks = nb, V->w_max = wmax, V->n_list = total, V->n_tiles = n_tiles, V->n_over_16bit = (int64_t)over;
+  V->windows_built = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ox_space_windows(ox_space *V, ox_window_info *v) {
+  if (!V || !v) OX_FAIL("ox_space_windows: null argument");
+  if (!V->row_pos.p && V->n > 0) OX_FAIL("ox_space_windows: the space carries no locality positions");
+  if (!V->windows_built) OX_TRY(build_windows(V, nullptr));
+  memset(v, 0, sizeof(*v));
+  v->n_wblocks = V->n_wblocks, v->w_max = V->w_max;
+  v->n_list = V->n_list, v->n_tiles = V->n_tiles, v->n_over_16bit = V->n_over_16bit;
+  v->wb_slices = V->wb_slices.as<int32_t>(), v->wb_waves = V->wb_waves.as<uint16_t>();
+  v->wb_ptr = V->wb_ptr.as<int64_t>(), v->wlist = V->wlist.as<int32_t>();
+  v->wt_ptr = V->wt_ptr.as<int64_t>(), v->wcode = V->wcode.as<uint16_t>();
   return 0;
 }
 

@@ -635,6 +635,29 @@ class FunctionSpace:
         mesh = self.mesh
         if mesh.device.type != "cuda" or self.pattern.size == 0 or getattr(self.pattern, "wcode", None) is not None:
             return getattr(self.pattern, "wcode", None) is not None
+        if self.native is not None:  # the library builds and owns the stream (ox_space_windows, csrc/ox_setup.hip)
+            from . import native as N
+
+            P, own, dev = self.pattern, self.native.handle, mesh.device
+            w = _lib.ox_window_info()
+            _lib.check(_lib.load().ox_space_windows(own.ptr, C.byref(w)), "ox_space_windows")
+            nb = int(w.n_wblocks)
+            if nb == 0:
+                return False
+            P.wb_slices = N.dev_tensor(w.wb_slices, (nb, 8), torch.int32, own, dev)
+            P.wb_waves = N.dev_tensor(w.wb_waves, (nb,), torch.int16, own, dev)
+            P.wb_ptr = N.dev_tensor(w.wb_ptr, (nb + 1,), torch.int64, own, dev)
+            P.wlist = N.dev_tensor(w.wlist, (int(w.n_list),), torch.int32, own, dev)
+            P.wt_ptr = N.dev_tensor(w.wt_ptr, (P.n_slices + 1,), torch.int64, own, dev)
+            P.wcode = N.dev_tensor(w.wcode, (int(w.n_tiles) * 256,), torch.int16, own, dev)
+            P.n_wblocks, P.w_max = nb, int(w.w_max)
+            w_all = (P.wb_ptr[1:] - P.wb_ptr[:-1]).to(torch.float64)
+            wq = torch.quantile(w_all, torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev))
+            P.w_stats = {"blocks": nb, "w_mean": float(w_all.mean().item()), "w_max": P.w_max,
+                         "w_p50_p90_p99": [int(v) for v in wq.tolist()],
+                         "share_over_2176": float((w_all > 2176).to(torch.float64).mean().item()),
+                         "list_bytes": int(w.n_list) * 4, "over_16bit": int(w.n_over_16bit)}
+            return True
         lo = mesh.coords.min(dim=0).values
         span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
         tb = self.native.nmesh.tile_bits if self.native is not None else default_tile_bits(mesh)

@@ -123,11 +123,18 @@ class FractionalStep_AB_CN:
 
             part = MeshPartition(mesh, comm.rank, comm.size, comm)
         self._part = part
-        # options["spmv_windows"]: brick order of the velocity numbering + the LDS-window stream of its pattern
-        # (measured a wash on the whole step at 128^3 -- off unless asked for)
-        windows = bool((options or {}).get("spmv_windows", False)) and part is None
+        # options["spmv_windows"]: the LDS-window stream of the velocity pattern (k_spmv_win).  Default: ON for meshes
+        # that are not lattices (Z-order numbering as it is: the mat-vecs of a refined Delaunay mesh run 1.3-1.9 x
+        # faster), OFF on lattice meshes, where it needs the brick order of the numbering and was measured a wash on the
+        # whole step at 128^3 (profiles/r04_spmv_window_experiments.txt).  One GPU only.
+        from .fem import mesh_is_lattice
+
+        lattice = mesh_is_lattice(mesh)
+        windows = bool((options or {}).get("spmv_windows", not lattice)) and part is None and u_deg >= 2 \
+            and dev.type == "cuda"
+        self._spmv_windows = windows
         Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part,
-                                                                                  brick=windows)
+                                                                                  brick=windows and lattice)
         if isinstance(p_element, FunctionSpace):
             Q = p_element
         else:
@@ -243,7 +250,7 @@ class FractionalStep_AB_CN:
             self._grad_p_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "grad_p")
             self._divu_Mat = MultiSellMatrix(self._pat_qv, mesh.gdim, "divu")
         # LDS-window stream of the velocity pattern (M, K, A share it): single-GPU operators of a degree-2 space
-        if self._options.get("spmv_windows", False) and Vi.degree >= 2 and self._part is None and mesh.device.type == "cuda":
+        if self._spmv_windows and Vi.degree >= 2:
             Vi.build_windows()
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
         self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")

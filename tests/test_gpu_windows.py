@@ -10,9 +10,24 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _space(kind, dim, n, brick):
+def _space(kind, dim, n, brick, setup="native"):
+    import os
+
     from oasisx_amd import fem
     from oasisx_amd import mesh as M
+
+    old = os.environ.get("OX_SETUP")
+    os.environ["OX_SETUP"] = setup  # "torch": fem.py's twin of the library set-up (and of its window builder)
+    try:
+        return _space_impl(kind, dim, n, brick, fem, M)
+    finally:
+        if old is None:
+            del os.environ["OX_SETUP"]
+        else:
+            os.environ["OX_SETUP"] = old
+
+
+def _space_impl(kind, dim, n, brick, fem, M):
 
     if kind == "box":
         mesh = (M.create_rectangle(None, [[-1.0, -1.0], [1.0, 1.0]], [n, n]) if dim == 2 else
@@ -22,13 +37,15 @@ def _space(kind, dim, n, brick):
     return fem.FunctionSpace(mesh, 2, window=1024, brick=brick)
 
 
+@pytest.mark.parametrize("setup", ["native", "torch"])
 @pytest.mark.parametrize("kind,dim,n,brick", [("box", 3, 17, True), ("box", 3, 9, False), ("box", 2, 40, True),
                                              ("delaunay", 3, 6, False), ("delaunay", 2, 14, False)])
-def test_window_stream_reproduces_the_columns_and_the_matvec_bit_for_bit(hip, kind, dim, n, brick):
+def test_window_stream_reproduces_the_columns_and_the_matvec_bit_for_bit(hip, kind, dim, n, brick, setup):
     from oasisx_amd import _lib
     from oasisx_amd.la import SellMatrix
 
-    V = _space(kind, dim, n, brick)
+    V = _space(kind, dim, n, brick, setup)
+    assert (V.native is not None) == (setup == "native")
     assert V.build_windows()
     P = V.pattern
     # ---- structure: every slice in exactly one block, every slot's column recovered from its window ----------------
