@@ -364,7 +364,8 @@ def main():
 
     options = dict({"low_memory_version": args.matrix_free, "value_dictionary": not args.no_dictionary},
                    **({"sell_window": args.window} if args.window else {}),
-                   **({"spmv_windows": args.spmv_windows == "true"} if args.spmv_windows else {}))
+                   **({"spmv_windows": args.spmv_windows == "true"} if args.spmv_windows else {}),
+                   **({"spmv_windows_pressure": os.environ["OX_WIN_P"] == "1"} if os.environ.get("OX_WIN_P") else {}))
     mesh, S = build(N, args.udeg, options, args.zero_guess)
 
     def workload_leg(wname, steps=5, warmup=3, delaunay=None):

@@ -388,8 +388,7 @@ int ox_assemble_weights(int degree, const ox_cells *cells, const ox_adj *adj, in
  * Projector (function.py:75,110-113).  The caller tabulates: fq[cell][q] = f at the n_q quadrature points of every
  * cell (kernel cell order), wphi[q][i] = w_q phi_i(x_q) on the reference simplex (any rule, any of the n_d basis
  * functions of the space `adj` belongs to); the kernel forms, per row, sum over its (cell, i) pairs in adjacency
- * order of |det J_cell| * sum_q wphi[q][i] fq[cell][q] -- one lane per row, no atomics, fixed order.
- * n_q * n_d <= 4096. */
+ * order of |det J_cell| * sum_q wphi[q][i] fq[cell][q] -- one lane per row, no atomics, fixed order. */
 int ox_assemble_load_vector(const ox_cells *cells, const ox_adj *adj, int64_t n_rows, int n_d, int n_q,
                             const double *wphi, const double *fq, double *b, void *stream);
 

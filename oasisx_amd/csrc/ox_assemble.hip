@@ -606,12 +606,16 @@ extern "C" int ox_assemble_weights(int degree, const ox_cells *cells, const ox_a
 
 // b[row] = sum_(cell e, local i) |det J_e| sum_q wphi[q][i] fq[e][q]: the load vector of a tabulated source
 // (include/oasisx_hip.h).  The reference table sits in LDS; every lane walks its own row's cells.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_load_vector(ox_cells cells, ox_adj adj, int64_t n_rows, int n_d, int n_q,
                                                      const double *__restrict__ wphi, const double *__restrict__ fq,
                                                      double *__restrict__ b) {
-  extern __shared__ double tab[];  // [n_q][n_d]
-  for (int k = threadIdx.x; k < n_q * n_d; k += blockDim.x) tab[k] = wphi[k];
-  __syncthreads();
+  extern __shared__ double tab_lds[];  // [n_q][n_d] (STAGE); a table beyond 48 KB is read in place (set-up only)
+  const double *__restrict__ tab = STAGE ? tab_lds : wphi;
+  if (STAGE) {
+    for (int k = threadIdx.x; k < n_q * n_d; k += blockDim.x) tab_lds[k] = wphi[k];
+    __syncthreads();
+  }
   const int gs = cells.gdim == 2 ? 6 : 10, ia = cells.gdim * cells.gdim;
   double s = 0.0;
   OX_ADJ_WALK_BEGIN
@@ -627,11 +631,15 @@ extern "C" int ox_assemble_load_vector(const ox_cells *cells, const ox_adj *adj,
                                        const double *wphi, const double *fq, double *b, void *stream) {
   if (!cells || !adj || !wphi || !fq || !b) OX_FAIL("ox_assemble_load_vector: null argument");
   if (cells->gdim != 2 && cells->gdim != 3) OX_FAIL("ox_assemble_load_vector: gdim=%d", cells->gdim);
-  if (n_d < 1 || n_q < 1 || (int64_t)n_d * n_q > 4096) OX_FAIL("ox_assemble_load_vector: n_d=%d n_q=%d", n_d, n_q);
+  if (n_d < 1 || n_q < 1 || (int64_t)n_d * n_q > (1 << 20)) OX_FAIL("ox_assemble_load_vector: n_d=%d n_q=%d", n_d, n_q);
   const int nblk = (adj->n_slices + 3) / 4;
   if (nblk == 0) return 0;
-  hipLaunchKernelGGL(k_load_vector, dim3(nblk), dim3(256), (size_t)n_d * n_q * sizeof(double), ox_stream(stream), *cells,
-                     *adj, n_rows, n_d, n_q, wphi, fq, b);
+  if ((int64_t)n_d * n_q <= 6144)
+    hipLaunchKernelGGL(k_load_vector<true>, dim3(nblk), dim3(256), (size_t)n_d * n_q * sizeof(double), ox_stream(stream), *cells,
+                       *adj, n_rows, n_d, n_q, wphi, fq, b);
+  else
+    hipLaunchKernelGGL(k_load_vector<false>, dim3(nblk), dim3(256), 0, ox_stream(stream), *cells, *adj, n_rows, n_d, n_q, wphi,
+                       fq, b);
   OX_LAUNCH_CHECK();
   return 0;
 }

@@ -216,7 +216,7 @@ def load_vector(V: FunctionSpace, f, geom: torch.Tensor, n_points: int, chunk: i
         xq = torch.einsum("qa,mak->mqk", bary, xc)  # (m, NQ, d)
         X = torch.zeros((3, xq.shape[0] * xq.shape[1]), dtype=torch.float64, device=dev)
         X[:d] = xq.reshape(-1, d).T
-        v = f(X) if on_dev else torch.from_numpy(np.ascontiguousarray(np.broadcast_to(
+        v = f(X) if on_dev else torch.from_numpy(np.array(np.broadcast_to(
             np.asarray(f(X.cpu().numpy()), dtype=np.float64), (X.shape[1],)))).to(dev)
         fq[c0:c0 + chunk] = v.reshape(xq.shape[0], xq.shape[1])
     if out is None:
