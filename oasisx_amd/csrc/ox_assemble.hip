@@ -5,6 +5,7 @@
 // degree-5 rules: every integrand of the path is a polynomial of degree <= 5 on affine cells,
 // so the rule is exact, as FFCx's is in the reference).
 #include "fe_tables.h"
+#include "fe_tables_h.h"
 #include "ox_kernels.h"
 #include <stdlib.h>
 
@@ -12,21 +13,37 @@
 #define OX_KIND_STIFF 1
 #define OX_KIND_CONV 2
 
-template <int GDIM, int DEG>
+// RULE 0: the degree-5 rules (every form of a P1 / P2 velocity is integrated exactly); RULE 1 (triangles): the degree-9
+// rule a P3 velocity needs (convection: 3 + 2 + 3 = 8).  A kernel that couples two elements tabulates both on the rule
+// of the higher one (OX_RULE_OF).  P3 = Basix's gll_warped variant (reference fracstep.py:170,181), triangles only.
+#define OX_RULE_OF(DA, DB) (((DA) == 3 || (DB) == 3) ? 1 : 0)
+template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
 struct Elem {
+  static_assert(DEG >= 1 && DEG <= 3 && (DEG < 3 || GDIM == 2), "Lagrange degree 1, 2 (and 3 on triangles)");
+  static_assert(RULE == 0 || GDIM == 2, "the high-order rule is tabulated on triangles");
+  static_assert(DEG < 3 || RULE == 1, "P3 needs the degree-9 rule");
   static constexpr int NV = GDIM + 1;
-  static constexpr int ND = DEG == 1 ? GDIM + 1 : (GDIM == 2 ? 6 : 10);
-  static constexpr int NQ = GDIM == 2 ? OX_NQ2 : OX_NQ3;
+  static constexpr int ND = DEG == 1 ? GDIM + 1 : (DEG == 3 ? 10 : (GDIM == 2 ? 6 : 10));
+  static constexpr int NQ = RULE == 1 ? OX_NQ2H : (GDIM == 2 ? OX_NQ2 : OX_NQ3);
   static constexpr int GS = GDIM == 2 ? 6 : 10;
-  __host__ __device__ static constexpr double w(int q) { return GDIM == 2 ? OX_QW2[q] : OX_QW3[q]; }
+  __host__ __device__ static constexpr double w(int q) {
+    if constexpr (RULE == 1) return OX_QW2H[q];
+    else return GDIM == 2 ? OX_QW2[q] : OX_QW3[q];
+  }
   __host__ __device__ static constexpr double phi(int q, int k) {
-    if constexpr (GDIM == 2 && DEG == 1) return OX_PHI2_1[q][k];
+    if constexpr (RULE == 1 && DEG == 1) return OX_PHI2H_1[q][k];
+    else if constexpr (RULE == 1 && DEG == 2) return OX_PHI2H_2[q][k];
+    else if constexpr (RULE == 1) return OX_PHI2H_3[q][k];
+    else if constexpr (GDIM == 2 && DEG == 1) return OX_PHI2_1[q][k];
     else if constexpr (GDIM == 2 && DEG == 2) return OX_PHI2_2[q][k];
     else if constexpr (GDIM == 3 && DEG == 1) return OX_PHI3_1[q][k];
     else return OX_PHI3_2[q][k];
   }
   __host__ __device__ static constexpr double dphi(int q, int k, int b) {
-    if constexpr (GDIM == 2 && DEG == 1) return OX_DPHI2_1[q][k][b];
+    if constexpr (RULE == 1 && DEG == 1) return OX_DPHI2H_1[q][k][b];
+    else if constexpr (RULE == 1 && DEG == 2) return OX_DPHI2H_2[q][k][b];
+    else if constexpr (RULE == 1) return OX_DPHI2H_3[q][k][b];
+    else if constexpr (GDIM == 2 && DEG == 1) return OX_DPHI2_1[q][k][b];
     else if constexpr (GDIM == 2 && DEG == 2) return OX_DPHI2_2[q][k][b];
     else if constexpr (GDIM == 3 && DEG == 1) return OX_DPHI3_1[q][k][b];
     else return OX_DPHI3_2[q][k][b];
@@ -35,17 +52,17 @@ struct Elem {
 
 // Tables indexed by a RUNTIME local dof index (the lane's own row dof): device-resident
 // copies, w_q*phi_i(q) and dphi_i(q,b).
-template <int GDIM, int DEG>
+template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
 struct RtTab {
-  using E = Elem<GDIM, DEG>;
+  using E = Elem<GDIM, DEG, RULE>;
   double wphi[E::ND][E::NQ];
   double dphi[E::ND][E::NQ][GDIM + 1];
   double iphi[E::ND];  // int_ref phi_i
 };
-template <int GDIM, int DEG>
-constexpr RtTab<GDIM, DEG> make_rt() {
-  using E = Elem<GDIM, DEG>;
-  RtTab<GDIM, DEG> t{};
+template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
+constexpr RtTab<GDIM, DEG, RULE> make_rt() {
+  using E = Elem<GDIM, DEG, RULE>;
+  RtTab<GDIM, DEG, RULE> t{};
   for (int i = 0; i < E::ND; ++i) {
     double s = 0.0;
     for (int q = 0; q < E::NQ; ++q) {
@@ -61,9 +78,15 @@ __device__ const RtTab<2, 1> RT21 = make_rt<2, 1>();
 __device__ const RtTab<2, 2> RT22 = make_rt<2, 2>();
 __device__ const RtTab<3, 1> RT31 = make_rt<3, 1>();
 __device__ const RtTab<3, 2> RT32 = make_rt<3, 2>();
-template <int GDIM, int DEG>
-__device__ __forceinline__ const RtTab<GDIM, DEG> &rt() {
-  if constexpr (GDIM == 2 && DEG == 1) return RT21;
+__device__ const RtTab<2, 3, 1> RT23 = make_rt<2, 3, 1>();
+__device__ const RtTab<2, 2, 1> RT22H = make_rt<2, 2, 1>();  // P2 rows next to a P3 velocity (div(u) q, rows Q)
+template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
+__device__ __forceinline__ const RtTab<GDIM, DEG, RULE> &rt() {
+  if constexpr (RULE == 1 && DEG == 3) return RT23;
+  else if constexpr (RULE == 1) {
+    static_assert(DEG == 2, "row tables on the high-order rule: P2 and P3");
+    return RT22H;
+  } else if constexpr (GDIM == 2 && DEG == 1) return RT21;
   else if constexpr (GDIM == 2 && DEG == 2) return RT22;
   else if constexpr (GDIM == 3 && DEG == 1) return RT31;
   else return RT32;
@@ -127,9 +150,11 @@ __device__ const ConvTab<2, 1> CT21 = make_conv<2, 1>();
 __device__ const ConvTab<2, 2> CT22 = make_conv<2, 2>();
 __device__ const ConvTab<3, 1> CT31 = make_conv<3, 1>();
 __device__ const ConvTab<3, 2> CT32 = make_conv<3, 2>();
+__device__ const ConvTab<2, 3> CT23 = make_conv<2, 3>();
 template <int GDIM, int DEG>
 __device__ __forceinline__ const ConvTab<GDIM, DEG> &ct() {
-  if constexpr (GDIM == 2 && DEG == 1) return CT21;
+  if constexpr (DEG == 3) return CT23;
+  else if constexpr (GDIM == 2 && DEG == 1) return CT21;
   else if constexpr (GDIM == 2 && DEG == 2) return CT22;
   else if constexpr (GDIM == 3 && DEG == 1) return CT31;
   else return CT32;
@@ -498,7 +523,7 @@ static int launch_rows(int degree, const ox_cells *cells, const int32_t *cell_do
     return launch_rows_t<GD, DG, KIND, P>(cells, cell_dofs, adj, adj_pos, A, F, n_bins, bin_ptr, \
                                           bin_slices, bin_width, st);                         \
   }
-  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16)
+  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16)
 #undef OX_ROWS_CASE
   OX_FAIL("assemble: unsupported gdim=%d degree=%d", g, degree);
 }
@@ -599,7 +624,7 @@ extern "C" int ox_assemble_weights(int degree, const ox_cells *cells, const ox_a
     OX_LAUNCH_CHECK();                                                                             \
     return 0;                                                                                      \
   }
-  OX_W_CASE(2, 1) OX_W_CASE(2, 2) OX_W_CASE(3, 1) OX_W_CASE(3, 2)
+  OX_W_CASE(2, 1) OX_W_CASE(2, 2) OX_W_CASE(3, 1) OX_W_CASE(3, 2) OX_W_CASE(2, 3)
 #undef OX_W_CASE
   OX_FAIL("ox_assemble_weights: unsupported gdim=%d degree=%d", g, degree);
 }
@@ -761,9 +786,10 @@ __global__ __launch_bounds__(256) void k_grad_vector(ox_cells cells, const int32
                                                      const double *__restrict__ p,
                                                      const double *__restrict__ base_v, double scale,
                                                      double *__restrict__ out) {
-  using ER = Elem<GDIM, RDEG>;
-  using EP = Elem<GDIM, PDEG>;
-  const auto &R = rt<GDIM, RDEG>();
+  constexpr int RULE = OX_RULE_OF(RDEG, PDEG);
+  using ER = Elem<GDIM, RDEG, RULE>;
+  using EP = Elem<GDIM, PDEG, RULE>;
+  const auto &R = rt<GDIM, RDEG, RULE>();
   double o[GDIM];
 #pragma unroll
   for (int d = 0; d < GDIM; ++d) o[d] = 0.0;
@@ -834,7 +860,7 @@ extern "C" int ox_assemble_grad_vector(int kind, int row_degree, int p_degree, c
   }
 #define OX_GV_ALL(GD) \
   OX_GV_CASE(GD, 1, 1, 0) OX_GV_CASE(GD, 1, 1, 1) OX_GV_CASE(GD, 2, 1, 0) OX_GV_CASE(GD, 2, 1, 1)
-  OX_GV_ALL(2) OX_GV_ALL(3)
+  OX_GV_ALL(2) OX_GV_ALL(3) OX_GV_CASE(2, 3, 2, 0) OX_GV_CASE(2, 3, 2, 1)
 #undef OX_GV_ALL
 #undef OX_GV_CASE
   OX_FAIL("ox_assemble_grad_vector: unsupported gdim=%d row_degree=%d p_degree=%d kind=%d", g,
@@ -847,9 +873,10 @@ __global__ __launch_bounds__(256) void k_div_vector(ox_cells cells, const int32_
                                                     ox_adj adj, int64_t n_rows,
                                                     const double *__restrict__ u, double scale,
                                                     double *__restrict__ out) {
-  using ER = Elem<GDIM, RDEG>;
-  using EU = Elem<GDIM, UDEG>;
-  const auto &R = rt<GDIM, RDEG>();
+  constexpr int RULE = OX_RULE_OF(RDEG, UDEG);
+  using ER = Elem<GDIM, RDEG, RULE>;
+  using EU = Elem<GDIM, UDEG, RULE>;
+  const auto &R = rt<GDIM, RDEG, RULE>();
   double o = 0.0;
   OX_ADJ_WALK_BEGIN
   double G[GDIM + 1][GDIM], adet;
@@ -904,7 +931,7 @@ extern "C" int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cel
     OX_LAUNCH_CHECK();                                                                             \
     return 0;                                                                                      \
   }
-  OX_DV_CASE(2, 1, 1) OX_DV_CASE(2, 1, 2) OX_DV_CASE(3, 1, 1) OX_DV_CASE(3, 1, 2)
+  OX_DV_CASE(2, 1, 1) OX_DV_CASE(2, 1, 2) OX_DV_CASE(3, 1, 1) OX_DV_CASE(3, 1, 2) OX_DV_CASE(2, 2, 3)
 #undef OX_DV_CASE
   OX_FAIL("ox_assemble_div_vector: unsupported gdim=%d row_degree=%d u_degree=%d", g, row_degree,
           u_degree);
@@ -921,9 +948,10 @@ extern "C" int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cel
 template <int GDIM, int RDEG, int CDEG, int FAM, int PW>
 __global__ __launch_bounds__(256) void k_assemble_rect(ox_cells cells, ox_adj adj,
                                                        const uint8_t *__restrict__ adj_pos, ox_sell A) {
-  using ER = Elem<GDIM, RDEG>;
-  using EC = Elem<GDIM, CDEG>;
-  const auto &R = rt<GDIM, RDEG>();
+  constexpr int RULE = OX_RULE_OF(RDEG, CDEG);
+  using ER = Elem<GDIM, RDEG, RULE>;
+  using EC = Elem<GDIM, CDEG, RULE>;
+  const auto &R = rt<GDIM, RDEG, RULE>();
   // blocks that share an XCD take one contiguous eighth of the slices (as k_assemble_rows): neighbouring rows,
   // which share their cells, then meet in ONE L2 (r02 PMC: 31-52 GB moved to write 3.3 GB with blocks dealt
   // round-robin over the XCDs)
@@ -1004,6 +1032,7 @@ extern "C" int ox_assemble_rect(int family, int row_degree, int col_degree, cons
   OX_RECT_CASE(GD, 1, 1, 0, 4) OX_RECT_CASE(GD, 1, 1, 1, 4) OX_RECT_CASE(GD, 1, 1, 2, 4) \
   OX_RECT_CASE(GD, 2, 1, 0, 4) OX_RECT_CASE(GD, 2, 1, 1, 4) OX_RECT_CASE(GD, 1, 2, 2, PV2)
   OX_RECT_DIM(2, 8) OX_RECT_DIM(3, 16)
+  OX_RECT_CASE(2, 3, 2, 0, 8) OX_RECT_CASE(2, 3, 2, 1, 8) OX_RECT_CASE(2, 2, 3, 2, 16)  // P3-P2 on triangles
 #undef OX_RECT_DIM
 #undef OX_RECT_CASE
   OX_FAIL("ox_assemble_rect: unsupported gdim=%d row_degree=%d col_degree=%d family=%d", g, row_degree,

@@ -267,20 +267,54 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *__restrict
 }
 
 __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, const int32_t *__restrict__ cell_edges,
-                                             int64_t nc, int d, int degree, int64_t nverts, int32_t *__restrict__ cd0) {
+                                             int64_t nc, int d, int degree, int64_t nverts, int64_t n_edges,
+                                             int32_t *__restrict__ cd0) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= nc) return;
-  const int nv = d + 1, ne = degree == 2 ? (d == 2 ? 3 : 6) : 0, nd = nv + ne;
+  const int nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0;
+  if (degree == 3) {
+    // triangles, 10 dofs: vertices; per local edge (a, b) the node nearer a, then the node nearer b -- an edge's two
+    // dofs are numbered from its LOWER global vertex to its higher one: nverts + 2 e + {0, 1}; the cell's own dof
+    const int nd = 10;
+    for (int a = 0; a < nv; ++a) cd0[c * nd + a] = cells[c * nv + a];
+    for (int e = 0; e < ne; ++e) {
+      const int flip = cells[c * nv + EDGE2[e][0]] > cells[c * nv + EDGE2[e][1]] ? 1 : 0;
+      const int64_t first = nverts + 2 * (int64_t)cell_edges[c * ne + e];
+      cd0[c * nd + nv + 2 * e] = (int32_t)(first + flip);
+      cd0[c * nd + nv + 2 * e + 1] = (int32_t)(first + 1 - flip);
+    }
+    cd0[c * nd + 9] = (int32_t)(nverts + 2 * n_edges + c);
+    return;
+  }
+  const int nd = nv + ne;
   for (int a = 0; a < nv; ++a) cd0[c * nd + a] = cells[c * nv + a];
   for (int e = 0; e < ne; ++e) cd0[c * nd + nv + e] = (int32_t)(nverts + cell_edges[c * ne + e]);
 }
 
 __global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ coords, const uint64_t *__restrict__ edge_keys,
-                                                    int64_t nverts, int64_t n, int d, double *__restrict__ x) {
+                                                    int64_t nverts, int64_t n, int d, double *__restrict__ x, int degree = 2,
+                                                    int64_t n_edges = 0, const int32_t *__restrict__ cells = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (i < nverts) {
     for (int k = 0; k < d; ++k) x[i * d + k] = coords[i * d + k];
+  } else if (degree == 3) {
+    // gll_warped P3 (reference fracstep.py:170,181): the edge nodes at the Gauss-Lobatto-Legendre points of the edge,
+    // counted from its lower global vertex; the cell's node at its centroid
+    if (i < nverts + 2 * n_edges) {
+      const int64_t e = (i - nverts) >> 1;
+      const double t = ((i - nverts) & 1) ? 0.5 + 0.5 / sqrt(5.0) : 0.5 - 0.5 / sqrt(5.0);
+      const uint64_t key = edge_keys[e];
+      const int64_t a = (int64_t)(key / (uint64_t)nverts), b = (int64_t)(key % (uint64_t)nverts);
+      for (int k = 0; k < d; ++k) x[i * d + k] = (1.0 - t) * coords[a * d + k] + t * coords[b * d + k];
+    } else {
+      const int64_t c = i - nverts - 2 * n_edges;
+      for (int k = 0; k < d; ++k) {
+        double v = 0.0;
+        for (int a = 0; a <= d; ++a) v += coords[(int64_t)cells[c * (d + 1) + a] * d + k];
+        x[i * d + k] = v / (double)(d + 1);
+      }
+    }
   } else {
     const uint64_t key = edge_keys[i - nverts];
     const int64_t a = (int64_t)(key / (uint64_t)nverts), b = (int64_t)(key % (uint64_t)nverts);
@@ -932,7 +966,9 @@ __global__ __launch_bounds__(256) void k_window_keys_part(const int32_t *__restr
 static int space_create_impl(const ox_mesh *M, int degree, int window, const int32_t *owner, int rank, int64_t n_initial,
                              int64_t n_dofs_whole, ox_space **out, int brick = 0) {
   if (!M || !out) OX_FAIL("ox_space_create: null argument");
-  if (degree != 1 && degree != 2) OX_FAIL("ox_space_create: Lagrange degree %d (1 and 2 are built)", degree);
+  if (degree < 1 || degree > 3) OX_FAIL("ox_space_create: Lagrange degree %d (1, 2 and -- on triangles -- 3 are built)", degree);
+  if (degree == 3 && (M->gdim != 2 || owner))
+    OX_FAIL("ox_space_create: Lagrange degree 3 is built on triangles, one GPU (gdim %d)", M->gdim);
   if (window < SLICE) window = 4096;
   hipStream_t st = nullptr;
   ox_space *V = new ox_space();
@@ -940,7 +976,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
     ox_space *v;
     ~Guard() { delete v; }
   } guard{V};
-  const int d = M->gdim, nv = d + 1, ne = degree == 2 ? (d == 2 ? 3 : 6) : 0, nd = nv + ne;
+  const int d = M->gdim, nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0, nd = degree == 3 ? 10 : nv + ne;
   const int64_t nc = M->nc;
   V->mesh = M, V->degree = degree, V->nd = nd, V->window = window;
   V->pw = nd <= 4 ? 4 : (nd <= 8 ? 8 : 16);
@@ -949,7 +985,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
   OX_TRY(cd0.alloc(sizeof(int32_t) * (size_t)nc * nd));
   {
     DevBuf cell_edges;
-    if (degree == 2) {
+    if (degree >= 2) {
       const int64_t nk = nc * ne;
       DevBuf k_in, k_out, v_in, v_out, head, excl;
       OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)nk));
@@ -980,11 +1016,11 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
       OX_HIP(hipStreamSynchronize(st));
     }
     hipLaunchKernelGGL(k_cd0, dim3(nblk(nc)), dim3(256), 0, st, M->cells.as<int32_t>(), cell_edges.as<int32_t>(), nc, d, degree,
-                       M->nv, cd0.as<int32_t>());
+                       M->nv, V->n_edges, cd0.as<int32_t>());
     OX_LAUNCH_CHECK();
     OX_HIP(hipStreamSynchronize(st));
   }
-  const int64_t n = M->nv + V->n_edges;
+  const int64_t n = degree == 3 ? M->nv + 2 * V->n_edges + nc : M->nv + V->n_edges;
   if (n >= ((int64_t)1 << 31) - 64) OX_FAIL("ox_space_create: %lld dofs exceed int32", (long long)n);
   V->n = n;
   if (owner && n != n_initial)
@@ -1003,7 +1039,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
   DevBuf xL, rank1;
   OX_TRY(xL.alloc(sizeof(double) * (size_t)n * d));
   hipLaunchKernelGGL(k_dof_coords, dim3(nblk(n)), dim3(256), 0, st, M->coords.as<double>(), V->edge_keys.as<uint64_t>(), M->nv, n,
-                     d, xL.as<double>());
+                     d, xL.as<double>(), degree, V->n_edges, M->cells.as<int32_t>());
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {

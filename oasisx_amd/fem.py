@@ -451,8 +451,10 @@ class FunctionSpace:
 
     def __init__(self, mesh: Mesh, degree: int, window: int = 4096, part=None,
                  block_pairs: int = 1 << 24, block_nnz: int = 1 << 27, brick: bool | None = None):
-        if degree not in (1, 2):
-            raise ValueError("oasisx_amd supports Lagrange degree 1 and 2")
+        if degree not in (1, 2, 3):
+            raise ValueError("oasisx_amd supports Lagrange degree 1, 2 and (on triangles) 3")
+        if degree == 3 and (mesh.gdim != 2 or part is not None):
+            raise NotImplementedError("Lagrange degree 3: triangles on one GPU")
         # brick order of the numbering (lattice meshes, one GPU): what the LDS-window SpMV needs, a loss for the
         # lane = row kernels -- only together with ``build_windows`` (FractionalStep_AB_CN options["spmv_windows"]);
         # OX_BRICK=1 forces it for tuning runs
@@ -474,6 +476,9 @@ class FunctionSpace:
             # (ox_mesh_create_sub / ox_space_create_part); the halo plan is then read off the partition.
             self._init_native(window, part)
             return
+        if degree == 3:
+            raise NotImplementedError("Lagrange degree 3 spaces are built by the library (GPU hosts); the torch twin "
+                                      "of the set-up covers degree 1 and 2")
         d = mesh.gdim
         nverts = mesh.num_vertices
         rank = 0 if part is None else part.rank
@@ -701,7 +706,7 @@ class FunctionSpace:
             self.num_dofs_global = self.n_owned = self.n_local = self.num_dofs = n
             self._gl = None
             self._edge_keys = (N.dev_tensor(v.edge_keys, (int(v.n_edges),), torch.int64, own, dev)
-                               if self.degree == 2 else None)
+                               if self.degree >= 2 else None)
         else:
             self.local_cells = sub.cells_global[ns.nmesh.cell_perm.to(torch.int64)]  # global cell ids, kernel order
             self.n_owned, self.n_local = int(v.pattern.sell.n_rows), n
@@ -916,7 +921,7 @@ class FunctionSpace:
         ev, _ = mesh._entities(dim)
         verts = ev[np.asarray(entities, dtype=np.int64)].reshape(len(entities), -1)
         gids = [torch.from_numpy(verts.ravel().astype(np.int64)).to(dev)]
-        if self.degree == 2 and verts.shape[1] >= 2:
+        if self.degree >= 2 and verts.shape[1] >= 2:
             ek = self._edge_keys
             nv = mesh.num_vertices
             for a, b in itertools.combinations(range(verts.shape[1]), 2):
@@ -925,7 +930,14 @@ class FunctionSpace:
                 key = lo * nv + hi
                 pos = torch.searchsorted(ek, key).clamp_max(max(int(ek.shape[0]) - 1, 0))
                 hit = ek[pos] == key  # (a partitioned space knows the edges of its window only)
-                gids.append((nv + pos)[hit])
+                if self.degree == 2:
+                    gids.append((nv + pos)[hit])
+                else:  # degree 3: two dofs per edge
+                    gids.append((nv + 2 * pos)[hit])
+                    gids.append((nv + 2 * pos + 1)[hit])
+        if self.degree == 3 and dim == mesh.gdim:  # the cells' own dofs: initial id = nv + 2 n_edges + kernel cell index
+            kc = torch.from_numpy(self.kernel_cell_index(np.asarray(entities, dtype=np.int64)).astype(np.int64)).to(dev)
+            gids.append(mesh.num_vertices + 2 * int(self._edge_keys.shape[0]) + kc)
         loc = self.global_to_local(torch.cat(gids))
         loc = loc[loc >= 0]
         return np.unique(loc.cpu().numpy()).astype(np.int32)
@@ -1416,6 +1428,42 @@ def _simplex_rule(d: int, n: int):
     return bary, W.ravel()
 
 
+GLL3 = (0.5 - 0.5 / np.sqrt(5.0), 0.5 + 0.5 / np.sqrt(5.0))  # interior edge nodes of the gll_warped P3 element
+_P3_COEF = None
+
+
+def lagrange_basis(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
+    """phi (npts, nd) of the Lagrange element the solver's spaces use, at barycentric points: P1, P2, and on triangles
+    the ``gll_warped`` P3 element (reference fracstep.py:170,181; the same node layout as csrc/fe_tables_h.h: vertices,
+    per local edge the node nearer its first vertex then the one nearer its second, the centroid)."""
+    nv = d + 1
+    if degree == 1:
+        return bary
+    if degree == 2:
+        cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
+        cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
+        return np.stack(cols, axis=1)
+    if degree == 3 and d == 2:
+        global _P3_COEF
+        ex = [(i, j) for i in range(4) for j in range(4 - i)]
+
+        def mono(x, y):
+            return np.stack([x ** i * y ** j for i, j in ex], axis=1)
+
+        if _P3_COEF is None:
+            nodes = [np.eye(3)[a] for a in range(3)]
+            for a, b in local_edges(2):
+                for t in GLL3:
+                    v = np.zeros(3)
+                    v[a], v[b] = 1.0 - t, t
+                    nodes.append(v)
+            nodes.append(np.full(3, 1.0 / 3.0))
+            nodes = np.array(nodes)
+            _P3_COEF = np.linalg.inv(mono(nodes[:, 1], nodes[:, 2]))
+        return mono(bary[:, 1], bary[:, 2]) @ _P3_COEF
+    raise NotImplementedError(f"Lagrange degree {degree} on a {d}-simplex")
+
+
 def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
     """int (u_h - exact)^2 dx over the local cells (``assemble_scalar`` of the demo's error form).
     ``exact`` maps x:(3, npts) -> (npts,).  Host numpy; a harness functional, not the hot path."""
@@ -1423,13 +1471,7 @@ def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
     mesh = V.mesh
     d = mesh.gdim
     bary, w = _simplex_rule(d, V.degree + degree_raise)
-    nv = d + 1
-    if V.degree == 1:
-        phi = bary
-    else:
-        cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
-        cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
-        phi = np.stack(cols, axis=1)
+    phi = lagrange_basis(d, V.degree, bary)
     lc = V.local_cells
     cd = V.cell_dofs
     if V.part is not None:  # integrate over the cells this rank owns (the ghost layer belongs to others)

@@ -196,15 +196,9 @@ def load_vector(V: FunctionSpace, f, geom: torch.Tensor, n_points: int, chunk: i
     mesh = V.mesh
     d, dev = mesh.gdim, mesh.device
     bary_np, w_np = _simplex_rule(d, n_points)
-    nv = d + 1
-    if V.degree == 1:
-        phi_np = bary_np
-    elif V.degree == 2:
-        cols = [bary_np[:, a] * (2 * bary_np[:, a] - 1) for a in range(nv)]
-        cols += [4 * bary_np[:, a] * bary_np[:, b] for a, b in local_edges(d)]
-        phi_np = np.stack(cols, axis=1)
-    else:
-        raise NotImplementedError("load_vector: Lagrange degree 1 and 2")
+    from .fem import lagrange_basis
+
+    phi_np = lagrange_basis(d, V.degree, bary_np)
     bary = torch.from_numpy(bary_np).to(dev)
     wphi = torch.from_numpy(np.ascontiguousarray(w_np[:, None] * phi_np)).to(dev)  # (NQ, nd)
     cells = mesh.cells[V.local_cells]

@@ -99,7 +99,52 @@ def local_edges(d: int):
 
 
 def num_cell_dofs(d: int, degree: int) -> int:
+    if degree == 3:
+        if d != 2:
+            raise ValueError("Lagrange degree 3 is restated on triangles only")
+        return 10
     return d + 1 if degree == 1 else (d + 1) + len(local_edges(d))
+
+
+# Lagrange degree 3 on triangles, ``lagrange_variant=gll_warped`` (reference fracstep.py:170,181): the two interior
+# nodes of an edge sit at the Gauss-Lobatto-Legendre points of the edge, (1 -+ 1/sqrt 5)/2, instead of 1/3 and 2/3;
+# the interior node stays at the centroid (Basix warps the equispaced lattice by the 1-D GLL displacement along every
+# barycentric direction: documented in its "variants" demo; for degree <= 2 the variant coincides with equispaced).
+GLL3 = (0.5 - 0.5 / math.sqrt(5.0), 0.5 + 0.5 / math.sqrt(5.0))
+
+
+def p3_nodes_2d() -> np.ndarray:
+    """Barycentric coordinates (10, 3) of the P3 nodes: vertices, then per local edge (a, b) the node nearer a and
+    the node nearer b, then the centroid."""
+    nodes = [np.eye(3)[a] for a in range(3)]
+    for a, b in local_edges(2):
+        for t in GLL3:
+            v = np.zeros(3)
+            v[a], v[b] = 1.0 - t, t
+            nodes.append(v)
+    nodes.append(np.full(3, 1.0 / 3.0))
+    return np.array(nodes)
+
+
+def _p3_monomials(x, y):
+    """The 10 monomials of degree <= 3 and their x / y derivatives at points (x, y)."""
+    ex = [(i, j) for i in range(4) for j in range(4 - i)]
+    m = np.stack([x ** i * y ** j for i, j in ex], axis=1)
+    mx = np.stack([i * x ** max(i - 1, 0) * y ** j if i > 0 else np.zeros_like(x) for i, j in ex], axis=1)
+    my = np.stack([j * x ** i * y ** max(j - 1, 0) if j > 0 else np.zeros_like(x) for i, j in ex], axis=1)
+    return m, mx, my
+
+
+_P3_COEF = None
+
+
+def _p3_coefficients():
+    global _P3_COEF
+    if _P3_COEF is None:
+        n = p3_nodes_2d()
+        V, _, _ = _p3_monomials(n[:, 1], n[:, 2])  # reference coordinates (x, y) = (lambda_1, lambda_2)
+        _P3_COEF = np.linalg.inv(V)  # column i: monomial coefficients of phi_i
+    return _P3_COEF
 
 
 def tabulate(d: int, degree: int, bary: np.ndarray):
@@ -127,7 +172,17 @@ def tabulate(d: int, degree: int, bary: np.ndarray):
             dphi[:, nv + e, a] = 4 * bary[:, b]
             dphi[:, nv + e, b] = 4 * bary[:, a]
         return phi, dphi
-    raise ValueError("only Lagrange degree 1 and 2 are restated")
+    if degree == 3 and d == 2:
+        # phi as a polynomial of (lambda_1, lambda_2) alone (lambda_0 = 1 - lambda_1 - lambda_2 eliminated): its
+        # derivative with respect to lambda_0 is then 0 and grad phi = phi_x grad lambda_1 + phi_y grad lambda_2
+        Cf = _p3_coefficients()
+        m, mx, my = _p3_monomials(bary[:, 1], bary[:, 2])
+        phi = m @ Cf
+        dphi = np.zeros((Q, 10, 3))
+        dphi[:, :, 1] = mx @ Cf
+        dphi[:, :, 2] = my @ Cf
+        return phi, dphi
+    raise ValueError("Lagrange degree 1 and 2 (and 3 on triangles) are restated")
 
 
 # ----------------------------------------------------------------------------
@@ -215,14 +270,32 @@ def build_dofmap(cells: np.ndarray, nverts: int, degree: int):
     key = pairs[:, :, 0] * np.int64(nverts) + pairs[:, :, 1]
     uniq, inv = np.unique(key.ravel(), return_inverse=True)
     edge_ids = inv.reshape(key.shape)
-    cell_dofs = np.concatenate([cells, nverts + edge_ids], axis=1)
     edge_verts = np.stack([uniq // nverts, uniq % nverts], axis=1)
+    if degree == 3:
+        # two dofs per edge, numbered from its lower global vertex to its higher one: nverts + 2 e + {0, 1}; the
+        # cell lists, per local edge (a, b), the node nearer a first; then one interior dof per cell
+        if d != 2:
+            raise ValueError("Lagrange degree 3 is restated on triangles only")
+        ne, nc = uniq.shape[0], cells.shape[0]
+        ed = np.empty((nc, 3, 2), dtype=np.int64)
+        for k, (a, b) in enumerate(edges):
+            flip = (cells[:, a] > cells[:, b]).astype(np.int64)  # the node nearer a is the edge's SECOND dof
+            ed[:, k, 0] = nverts + 2 * edge_ids[:, k] + flip
+            ed[:, k, 1] = nverts + 2 * edge_ids[:, k] + 1 - flip
+        interior = nverts + 2 * ne + np.arange(nc, dtype=np.int64)
+        cell_dofs = np.concatenate([cells, ed.reshape(nc, 6), interior[:, None]], axis=1)
+        return cell_dofs, nverts + 2 * ne + nc, edge_verts
+    cell_dofs = np.concatenate([cells, nverts + edge_ids], axis=1)
     return cell_dofs, nverts + uniq.shape[0], edge_verts
 
 
-def dof_coordinates(coords, degree, edge_verts):
+def dof_coordinates(coords, degree, edge_verts, cells=None):
     if degree == 1:
         return coords.copy()
+    if degree == 3:
+        lo, hi = coords[edge_verts[:, 0]], coords[edge_verts[:, 1]]
+        on_edges = np.stack([(1.0 - t) * lo + t * hi for t in GLL3], axis=1).reshape(-1, coords.shape[1])
+        return np.concatenate([coords, on_edges, coords[cells].mean(axis=1)], axis=0)
     mid = 0.5 * (coords[edge_verts[:, 0]] + coords[edge_verts[:, 1]])
     return np.concatenate([coords, mid], axis=0)
 
@@ -247,16 +320,16 @@ class Forms:
         nverts = self.coords.shape[0]
         if vd is None:
             vd, nv_dofs, ev = build_dofmap(self.cells, nverts, u_deg)
-            self.x_v = dof_coordinates(self.coords, u_deg, ev)
+            self.x_v = dof_coordinates(self.coords, u_deg, ev, self.cells)
         if qd is None:
             qd, nq_dofs, eq = build_dofmap(self.cells, nverts, p_deg)
-            self.x_q = dof_coordinates(self.coords, p_deg, eq)
+            self.x_q = dof_coordinates(self.coords, p_deg, eq, self.cells)
         self.vd = np.asarray(vd, dtype=np.int64)
         self.qd = np.asarray(qd, dtype=np.int64)
         self.nv, self.nq = int(nv_dofs), int(nq_dofs)
         self.G, self.adet = cell_geometry(self.coords, self.cells)
-        # rule exact to degree 2*4-1 = 7 >= 5 (P2 convection: 2+1+2)
-        self.bary, self.w = simplex_quadrature(self.d, 4)
+        # rule exact to degree 2*4-1 = 7 >= 5 (P2 convection: 2+1+2); degree 9 >= 8 for P3 (3+2+3)
+        self.bary, self.w = simplex_quadrature(self.d, 4 if max(u_deg, p_deg) <= 2 else 5)
         self.phi_v, self.dphi_v = tabulate(self.d, u_deg, self.bary)
         self.phi_q, self.dphi_q = tabulate(self.d, p_deg, self.bary)
         # physical gradients at quadrature points: (nc, Q, nd, d)
