@@ -45,7 +45,8 @@ class TaylorGreen2D:
         return lambda x: -0.25 * (np.cos(2 * np.pi * x[0]) + np.cos(2 * np.pi * x[1])) * self.decay(4, t)
 
 
-def build_solver(N: int, field: TaylorGreen2D, degree_u: int, solver_options, low_memory: bool, rotational: bool):
+def build_solver(N: int, field: TaylorGreen2D, degree_u: int, solver_options, low_memory: bool, rotational: bool,
+                 degree_p: int = 1):
     import oasisx_amd as ox
     from oasisx_amd import mesh as M
 
@@ -55,7 +56,8 @@ def build_solver(N: int, field: TaylorGreen2D, degree_u: int, solver_options, lo
     boundary = np.sort(M.exterior_facet_indices(mesh.topology))
     tags = M.meshtags(mesh, fdim, boundary, np.full(boundary.shape, 1, dtype=np.int32))
     bcs = [[ox.DirichletBC(field.velocity(c), ox.LocatorMethod.TOPOLOGICAL, (tags, 1))] for c in range(2)]
-    solver = ox.FractionalStep_AB_CN(mesh, ("Lagrange", degree_u), ("Lagrange", 1), bcs_u=bcs, bcs_p=[],
+    assert degree_u > degree_p  # reference demo/taylor_green.py:111
+    solver = ox.FractionalStep_AB_CN(mesh, ("Lagrange", degree_u), ("Lagrange", degree_p), bcs_u=bcs, bcs_p=[],
                                      rotational=rotational, solver_options=solver_options,
                                      options={"low_memory_version": low_memory})
     return mesh, solver
@@ -63,13 +65,13 @@ def build_solver(N: int, field: TaylorGreen2D, degree_u: int, solver_options, lo
 
 def run_taylor_green(N: int, dt: float = 0.005, T: float = 1.0, nu: float = 0.01, degree_u: int = 2,
                      solver_options=None, low_memory: bool = False, rotational: bool = False,
-                     out_dir: str | None = None) -> dict:
+                     out_dir: str | None = None, degree_p: int = 1) -> dict:
     """March from t = 0 to T on the N x N mesh; returns h, the space-time L2 errors
     sqrt(dt sum_n ||e^n||^2) of u and p and the Krylov iteration counts of the last step."""
     from oasisx_amd import fem
 
     field = TaylorGreen2D(nu)
-    mesh, solver = build_solver(N, field, degree_u, solver_options or DIRECT, low_memory, rotational)
+    mesh, solver = build_solver(N, field, degree_u, solver_options or DIRECT, low_memory, rotational, degree_p)
     for c in range(2):  # two velocity levels and the staggered pressure (t = -dt, 0, -dt/2)
         solver._u2[c].interpolate(field.velocity(c, -dt))
         solver._u1[c].interpolate(field.velocity(c, 0.0))
@@ -108,7 +110,8 @@ def main(argv=None):
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--T", type=float, default=1.0)
     ap.add_argument("--nu", type=float, default=0.01)
-    ap.add_argument("--degree-u", type=int, default=2)
+    ap.add_argument("-u", "--degree-u", type=int, default=2, help="velocity degree (reference demo: -u)")
+    ap.add_argument("-p", "--degree-p", type=int, default=1, help="pressure degree (reference demo: -p); built pairs: 2-1, 3-2")
     ap.add_argument("--krylov", action="store_true", help="Jacobi-BiCGStab / Jacobi-CG at 1e-10 instead of 'preonly lu'")
     ap.add_argument("--low-memory", action="store_true")
     ap.add_argument("--rotational", action="store_true")
@@ -117,7 +120,7 @@ def main(argv=None):
     results = []
     for N in a.N:
         r = run_taylor_green(N, a.dt, a.T, a.nu, a.degree_u, KRYLOV if a.krylov else DIRECT, a.low_memory,
-                             a.rotational, a.out)
+                             a.rotational, a.out, a.degree_p)
         results.append(r)
         print(f"N = {N:4d}  h = {r['h']:.5f}  ||e_u|| = {r['error_u']:.4e}  ||e_p|| = {r['error_p']:.4e}  "
               f"iterations {r['iterations']}")

@@ -29,3 +29,16 @@ def test_assembly_bcs_fused_rhs_equals_the_matvec_rhs(hip, degree):
     # b_first from the fused kernel == (M/dt - C/2 - nu K/2) u_1 rebuilt from the stored operators
     assert r["rhs_rel_diff"] < 1e-11, r
     assert r["fused_lhs_rhs_ms"] > 0 and r["separate_rhs_matvecs_ms"] > 0
+
+
+def test_taylor_green_demo_with_the_reference_demo_degrees_3_and_2(hip):
+    """``demo/taylor_green.py -u 3 -p 2`` of the reference (:82-83,111) on the device harness: topological Dirichlet
+    conditions on a degree-3 space (two dofs per tagged edge), direct-solver options, rotational update with a P2
+    pressure; the errors against the analytic solution undercut the P2-P1 run's."""
+    from demo.taylor_green_hip import run_taylor_green
+
+    e32 = run_taylor_green(8, dt=0.002, T=0.02, nu=0.01, degree_u=3, degree_p=2)
+    e21 = run_taylor_green(8, dt=0.002, T=0.02, nu=0.01, degree_u=2, degree_p=1)
+    assert e32["error_u"] < 0.5 * e21["error_u"] and e32["error_p"] < 0.5 * e21["error_p"], (e32, e21)
+    rot = run_taylor_green(8, dt=0.002, T=0.02, nu=0.01, degree_u=3, degree_p=2, rotational=True, low_memory=True)
+    assert rot["error_u"] < 2.0 * e32["error_u"], (rot, e32)
