@@ -103,7 +103,10 @@ typedef struct {
    * boundary slices (DOLFINx/PETSc do the same inside MatMult; reference fracstep.py:453,497,632). */
   const int32_t *ib_slices;  /* device [n_slices] or NULL                                   */
   int32_t n_interior;        /* leading entries of ib_slices that are interior              */
-  int32_t reserved2;
+  int32_t n_wb_interior;     /* LDS-window stream of a mesh-partitioned operator: its window blocks are listed with the
+                                INTERIOR ones (no ghost column in any row of any of their slices) first; this many.
+                                The overlapped mat-vec multiplies blocks [0, n_wb_interior) while the halo exchange is in
+                                flight and the others after it (0 with ib_slices set: no interior block)  */
   /* optional pair-slot stream of a value-dictionary matrix (ox_pair_stream_size / _fill; all NULL =
    * not built).  A slot multiplies TWO adjacent columns: y += vdict[a] * x[col] + vdict[b] * x[col+1],
    * one 16-byte gather instead of two 8-byte ones -- the SpMV on these matrices is bound by the number

@@ -36,7 +36,7 @@ class ox_sell(C.Structure):
         ("vdict", C.c_void_p),
         ("ib_slices", C.c_void_p),
         ("n_interior", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("n_wb_interior", C.c_int32),
         ("ps_ptr", C.c_void_p),
         ("ps_code", C.c_void_p),
         ("ps_base", C.c_void_p),

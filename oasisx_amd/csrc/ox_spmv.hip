@@ -403,7 +403,7 @@ template <int NC, int EPI, int VAR>
 __global__ __launch_bounds__(256) void k_spmv_win(ox_sell A, const double *__restrict__ x, double *__restrict__ y,
                                                   const double *__restrict__ dinv, const double *__restrict__ aux,
                                                   double *__restrict__ partial, const int *__restrict__ done_flag,
-                                                  int w_cap, OxEpiDinv ED) {
+                                                  int w_cap, OxEpiDinv ED, int wb0, int wbn) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
   extern __shared__ double xw[];  // [NC][w_cap]: one plane per right-hand side -- the 64 lanes of a wave mostly read
                                   // consecutive window entries: consecutive 8-byte words, no bank conflicts (the
@@ -414,12 +414,15 @@ __global__ __launch_bounds__(256) void k_spmv_win(ox_sell A, const double *__res
   if (VAR & 4) {
     if ((int)threadIdx.x < A.n_dict) dict[threadIdx.x] = A.vdict[threadIdx.x];
   }
-  const int b = ox_xcd_remap(blockIdx.x, gridDim.x);  // blocks of one XCD: a contiguous eighth of the window blocks
+  // blocks of one XCD: a contiguous eighth of the launch's window blocks [wb0, wb0 + wbn) -- all of them, or the
+  // interior / the boundary ones of a mesh-partitioned operator (ox_sell.n_wb_interior)
+  const int bl = ox_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wb0 + bl;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double s[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) s[i] = 0.0;
-  const bool live = b < A.n_wblocks;
+  const bool live = bl < wbn;
   int64_t w0 = 0;
   int W = 0;
   if (live) {
@@ -618,7 +621,9 @@ static int spmv_variant() {
 // resident blocks per CU with three columns); OX_WIN_CAP overrides (tuning).  0: the matrix has no window stream, or
 // the launch cannot use it (slice lists of a partitioned operator).
 static int spmv_window_cap(const ox_sell *A, int ncomp, const int32_t *list) {
-  if (list || !(spmv_variant() & 16) || !A->wcode || !A->wt_ptr || !A->wlist || !A->wb_ptr || !A->wb_slices ||
+  // slice lists: only the interior / boundary halves of a partitioned operator whose window blocks are split alike
+  if (list && !(A->ib_slices && (list == A->ib_slices || list == A->ib_slices + A->n_interior))) return 0;
+  if (!(spmv_variant() & 16) || !A->wcode || !A->wt_ptr || !A->wlist || !A->wb_ptr || !A->wb_slices ||
       !A->wb_waves || A->n_wblocks <= 0 || ncomp < 1 || ncomp > 3)
     return 0;
   static int env = -1;
@@ -630,7 +635,13 @@ static int spmv_window_cap(const ox_sell *A, int ncomp, const int32_t *list) {
   const int cap = env > 0 ? env : dflt;
   return A->w_max < cap ? A->w_max : cap;
 }
-static inline int spmv_window_grid(const ox_sell *A) { return (A->n_wblocks + 7) & ~7; }
+static inline int spmv_window_grid_n(int nblocks) { return (nblocks + 7) & ~7; }
+// window blocks [first, first + count) of a launch over `list`: all, the interior or the boundary ones
+static inline void spmv_window_range(const ox_sell *A, const int32_t *list, int n_list, int *first, int *count) {
+  if (!list) *first = 0, *count = A->n_wblocks;
+  else if (list == A->ib_slices && n_list == A->n_interior) *first = 0, *count = A->n_wb_interior;
+  else *first = A->n_wb_interior, *count = A->n_wblocks - A->n_wb_interior;
+}
 
 // the Jacobi diagonal of the OX_EPI_CG_M2 epilogue through its value dictionary (ox_ksp.hip sets it around its mat-vecs;
 // one call at a time per process: include/oasisx_hip.h)
@@ -652,7 +663,10 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
   const int w_cap = pairs ? 0 : spmv_window_cap(A, ncomp, list);
   if (w_cap > 0) {
     const bool codes = var == 7 && A->wvcode;  // a dictionary matrix without tiled value codes multiplies its f64 values
-    const int wgrid = spmv_window_grid(A);
+    int wb0 = 0, wbn = 0;
+    spmv_window_range(A, list, n_list, &wb0, &wbn);
+    if (wbn == 0) return 0;
+    const int wgrid = spmv_window_grid_n(wbn);
     const size_t lds = (size_t)w_cap * ncomp * sizeof(double);
 #define OX_WIN_CASE(NC, E)                                                                                          \
   if (ncomp == NC && epi == E) {                                                                                    \
@@ -661,7 +675,7 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
         OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)lds));                                                                      \
       if (ox_prof_on) ox_prof_start(OX_TAG_SPMV(NC, E), st, A->n_rows);                                             \
-      hipLaunchKernelGGL(kern, dim3(wgrid), dim3(256), lds, st, *A, x, y, dinv, aux, partial, done, w_cap, g_epi_dinv); \
+      hipLaunchKernelGGL(kern, dim3(wgrid), dim3(256), lds, st, *A, x, y, dinv, aux, partial, done, w_cap, g_epi_dinv, wb0, wbn); \
       if (ox_prof_on) ox_prof_stop(st);                                                                             \
       OX_LAUNCH_CHECK();                                                                                            \
       return 0;                                                                                                     \
@@ -729,13 +743,21 @@ static bool ox_overlap_on(const ox_sell *A, const ox_dist *dist) {
   return !(dist->comm && !dist->p2p && !dist->halo_cb);  // RCCL plan: off by default
 }
 
-int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist, int ncomp) {
-  if (!ox_overlap_on(A, dist)) {
-    const bool pairs = (spmv_variant() & 8) && A->ps_ptr && A->ps_code && A->ps_base;
-    if (!pairs && spmv_window_cap(A, ncomp, nullptr) > 0) return spmv_window_grid(A);
-    return ox_spmv_blocks(A);
+// partial-sum rows (= grid blocks) of the launch over `list` (nullptr: the whole operator)
+static int spmv_parts_of(const ox_sell *A, int ncomp, const int32_t *list, int n_list) {
+  const bool pairs = (spmv_variant() & 8) && A->ps_ptr && A->ps_code && A->ps_base;
+  if (!pairs && spmv_window_cap(A, ncomp, list) > 0) {
+    int wb0 = 0, wbn = 0;
+    spmv_window_range(A, list, n_list, &wb0, &wbn);
+    return wbn == 0 ? 0 : spmv_window_grid_n(wbn);
   }
-  return ox_spmv_blocks_n(A->n_interior) + ox_spmv_blocks_n(A->n_slices - A->n_interior);
+  return list ? ox_spmv_blocks_n(n_list) : ox_spmv_blocks(A);
+}
+
+int ox_spmv_dist_nparts(const ox_sell *A, const ox_dist *dist, int ncomp) {
+  if (!ox_overlap_on(A, dist)) return spmv_parts_of(A, ncomp, nullptr, 0);
+  return spmv_parts_of(A, ncomp, A->ib_slices, A->n_interior) +
+         spmv_parts_of(A, ncomp, A->ib_slices + A->n_interior, A->n_slices - A->n_interior);
 }
 
 // y = A x with the ghost block of x refreshed: halo exchange started, interior slices multiplied
@@ -750,7 +772,7 @@ int ox_spmv_dist(const ox_sell *A, double *x, double *y, int ncomp, int epi, con
   if (ox_halo_begin_impl(dist, x, ncomp, st)) return -1;
   if (ox_prof_on) ox_prof_stop(st);
   const int nv = ox_epi_nv(epi, ncomp);
-  const int nb_int = ox_spmv_blocks_n(A->n_interior);
+  const int nb_int = spmv_parts_of(A, ncomp, A->ib_slices, A->n_interior);
   if (spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, A->ib_slices, A->n_interior)) return -1;
   if (ox_halo_end_impl(dist, x, ncomp, st)) return -1;
   return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial ? partial + (size_t)nb_int * nv : nullptr, done, st,

@@ -234,6 +234,29 @@ class SellPattern:
         boundary = torch.nonzero(ghost > 0).reshape(-1)
         self.ib_slices = torch.cat([interior, boundary]).to(torch.int32).contiguous()
         self.n_interior = int(interior.shape[0])
+        self._slice_has_ghost = ghost > 0
+        self.order_window_blocks()
+
+    def order_window_blocks(self):
+        """LDS-window stream of a mesh-partitioned operator: list the window blocks with the interior ones (no slice
+        with a ghost column) first -- the overlapped mat-vec multiplies those while the halo exchange is in flight
+        (``ox_sell.n_wb_interior``).  The library-owned arrays are copied in the new order."""
+        if getattr(self, "wcode", None) is None or getattr(self, "_slice_has_ghost", None) is None \
+                or getattr(self, "n_wb_interior", None) is not None:
+            return
+        dev = self.device
+        sl = self.wb_slices.to(torch.int64)
+        flag = (self._slice_has_ghost[sl.clamp_min(0)] & (sl >= 0)).any(dim=1)
+        perm = torch.argsort(flag.to(torch.int8), stable=True)
+        w = (self.wb_ptr[1:] - self.wb_ptr[:-1])[perm]
+        new_ptr = torch.zeros_like(self.wb_ptr)
+        new_ptr[1:] = torch.cumsum(w, 0)
+        src = torch.repeat_interleave(self.wb_ptr[:-1][perm] - new_ptr[:-1], w) + torch.arange(int(new_ptr[-1].item()), device=dev)
+        self.wlist = self.wlist[src].contiguous()
+        self.wb_ptr = new_ptr
+        self.wb_slices = self.wb_slices[perm].contiguous()
+        self.wb_waves = self.wb_waves[perm].contiguous()
+        self.n_wb_interior = int((~flag).sum().item())
 
     def new_values(self) -> torch.Tensor:
         return torch.zeros(self.size, dtype=torch.float64, device=self.device)
@@ -368,6 +391,7 @@ class SellPattern:
             S.wb_slices, S.wb_waves, S.wb_ptr = self.wb_slices.data_ptr(), self.wb_waves.data_ptr(), self.wb_ptr.data_ptr()
             S.wlist, S.wcode, S.n_wblocks, S.w_max = self.wlist.data_ptr(), self.wcode.data_ptr(), self.n_wblocks, self.w_max
             S.wt_ptr = self.wt_ptr.data_ptr()
+            S.n_wb_interior = int(getattr(self, "n_wb_interior", None) or 0)
         return S
 
     def bins_args(self):
@@ -662,6 +686,7 @@ class FunctionSpace:
                          "w_p50_p90_p99": [int(v) for v in wq.tolist()],
                          "share_over_2176": float((w_all > 2176).to(torch.float64).mean().item()),
                          "list_bytes": int(w.n_list) * 4, "over_16bit": int(w.n_over_16bit)}
+            P.order_window_blocks()  # (a mesh-partitioned operator whose interior / boundary split is known already)
             return True
         lo = mesh.coords.min(dim=0).values
         span = (mesh.coords.max(dim=0).values - lo).clamp_min(1e-300)
@@ -673,7 +698,9 @@ class FunctionSpace:
         order = torch.argsort(key, stable=True)
         row_pos = torch.empty_like(order)
         row_pos[order] = torch.arange(order.shape[0], device=order.device)
-        return self.pattern.build_windows(row_pos, self.window)
+        ok = self.pattern.build_windows(row_pos, self.window)
+        self.pattern.order_window_blocks()
+        return ok
 
     def _init_native(self, window: int, part=None):
         from . import native as N

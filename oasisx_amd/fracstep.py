@@ -134,8 +134,10 @@ class FractionalStep_AB_CN:
         from .fem import mesh_is_lattice
 
         lattice = mesh_is_lattice(mesh)
-        windows = bool((options or {}).get("spmv_windows", not lattice)) and part is None and dev.type == "cuda" \
-            and (u_deg >= 2 or not lattice)
+        # (mesh-partitioned operators too, in the Z-order numbering: their window blocks are listed interior-first and
+        # the overlapped mat-vec multiplies the two halves around the halo exchange; the brick order is one-GPU only)
+        windows = bool((options or {}).get("spmv_windows", not lattice)) and dev.type == "cuda" \
+            and (not lattice or (part is None and u_deg >= 2))
         self._spmv_windows = windows
         self._lattice = lattice
         Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part,
@@ -259,8 +261,7 @@ class FractionalStep_AB_CN:
             Vi.build_windows()
         # the pressure matrix too where it has no pair-slot stream to lose (meshes that are not lattices carry no
         # value dictionary): refined Delaunay mesh, 2.4 M P1 rows: 120 -> 86 us per mat-vec, 0.73 of the HBM peak
-        if self._options.get("spmv_windows_pressure", self._spmv_windows and not self._lattice) and self._part is None \
-                and mesh.device.type == "cuda":
+        if self._options.get("spmv_windows_pressure", self._spmv_windows and not self._lattice) and mesh.device.type == "cuda":
             Q.build_windows()
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
         self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")

@@ -38,8 +38,11 @@ def _run(dim, N, deg, comm, steps, low_memory=True):
     from tests.helpers import KRYLOV, on_boundary, on_boundary3
 
     nu, dt = 0.01, 0.005
-    mesh = (M.create_rectangle(comm, [[-1.0, -1.0], [1.0, 1.0]], [N, N]) if dim == 2
-            else M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N]))
+    if N < 0:  # an UNSTRUCTURED mesh (Delaunay, refined once): Z-order numbering, the mat-vecs on the LDS-window stream
+        mesh = M.create_delaunay_box(comm, [[-1.0] * dim, [1.0] * dim], -N, refine=1)
+    else:
+        mesh = (M.create_rectangle(comm, [[-1.0, -1.0], [1.0, 1.0]], [N, N]) if dim == 2
+                else M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [N, N, N]))
     clock = {"t": 0.0}
     fns = [O.tg_u, O.tg_v, O.tg_w][:dim]
     marker = on_boundary if dim == 2 else on_boundary3
@@ -77,6 +80,10 @@ def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
         Vi, Q = S._Vi[0][0], S._Q
         assert Vi.dist is not None and Vi.n_local > Vi.n_owned
         assert comm.active == {deg: transport, 1: transport}, comm.active
+        if N < 0:  # the partitioned operators really run on window blocks, split interior / boundary
+            for Pn in (S._A.pattern, S._Ap.pattern):
+                assert Pn.wcode is not None and Pn.n_wb_interior is not None and 0 <= Pn.n_wb_interior <= Pn.n_wblocks
+            assert S._A._struct.n_wblocks == S._A.pattern.n_wblocks and S._A._struct.n_wb_interior == S._A.pattern.n_wb_interior
         kg = _key(G._Vi[0][0].x.cpu().numpy())
         og = np.argsort(kg)
         iu = og[np.searchsorted(kg[og], _key(Vi.x.cpu().numpy()))]
@@ -100,7 +107,7 @@ def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
 
 @pytest.mark.parametrize("transport", ["p2p", "host"])
 @pytest.mark.parametrize("dim,N,deg,world,low_memory", [(3, 6, 2, 2, True), (2, 12, 2, 3, True), (3, 6, 1, 2, True),
-                                                        (3, 6, 2, 2, False)])
+                                                        (3, 6, 2, 2, False), (3, -5, 2, 2, True), (2, -14, 2, 3, False)])
 def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory, transport):
     import torch.multiprocessing as mp
 
