@@ -214,25 +214,21 @@ class PressureBC:
         # weights sum to 1/(d-1)!;  int_F g n_i ds = -|detJ| (grad lambda_opp)_i sum_q w_q g(x_q)
         nq_ = bf.shape[0]
         nvl = d + 1
-        bary = np.zeros((nf, nq_, nvl))
-        for f in range(nvl):  # facets grouped by opposite vertex
-            sel = fopp == f
+        # pressure basis and velocity-basis derivatives at the facet points (any built pair: P1-P1, P2-P1, P3-P2);
+        # the points of a facet depend on its opposite vertex only: one tabulation per local facet
+        from .fem import lagrange_basis, lagrange_basis_derivs
+
+        psi = torch.zeros((nf, nq_, Q.nd), dtype=torch.float64, device=dev)
+        dphi = torch.zeros((nf, nq_, V.nd, nvl), dtype=torch.float64, device=dev)
+        for f in range(nvl):
+            sel = torch.from_numpy(fopp == f).to(dev)
+            if not bool(sel.any()):
+                continue
             others = [b_ for b_ in range(nvl) if b_ != f]
             tmp = np.zeros((nq_, nvl))
             tmp[:, others] = bf
-            bary[sel] = tmp
-        lam = torch.from_numpy(bary).to(dev)  # (nf, q, d+1)
-        psi = lam  # P1 pressure basis
-        if V.degree == 1:
-            dphi = torch.eye(nvl, dtype=torch.float64, device=dev).expand(nf, nq_, nvl, nvl)
-        else:
-            nd = V.nd
-            dphi = torch.zeros((nf, nq_, nd, nvl), dtype=torch.float64, device=dev)
-            for a in range(nvl):
-                dphi[:, :, a, a] = 4 * lam[:, :, a] - 1
-            for e, (a, b_) in enumerate(local_edges(d)):
-                dphi[:, :, nvl + e, a] = 4 * lam[:, :, b_]
-                dphi[:, :, nvl + e, b_] = 4 * lam[:, :, a]
+            psi[sel] = torch.from_numpy(lagrange_basis(d, Q.degree, tmp)).to(dev)
+            dphi[sel] = torch.from_numpy(lagrange_basis_derivs(d, V.degree, tmp)).to(dev)
         grad = torch.einsum("fqrb,fbk->fqrk", dphi, G)  # (nf, q, nd_v, d)
         ia = torch.from_numpy(fopp).to(dev)
         Ga = G[torch.arange(nf, device=dev), ia]  # (nf, d) = grad lambda_opp;  n |F| = -|detJ| Ga
@@ -241,8 +237,8 @@ class PressureBC:
         vals = torch.einsum("q,fqc,fqrk->fkrc", w, psi, grad) * (-(adet.unsqueeze(1) * Ga)).unsqueeze(2).unsqueeze(3)
         tl = torch.from_numpy(floc).to(dev)
         rows = V.cell_dofs[tl].to(torch.int64)  # (nf, nd_v)
-        cols = Q.cell_dofs[tl].to(torch.int64)  # (nf, d+1)
-        R = rows.unsqueeze(2).expand(-1, -1, nvl).reshape(-1)
+        cols = Q.cell_dofs[tl].to(torch.int64)  # (nf, nd_q)
+        R = rows.unsqueeze(2).expand(-1, -1, cols.shape[1]).reshape(-1)
         Cc = cols.unsqueeze(1).expand(-1, rows.shape[1], -1).reshape(-1)
         keep = R < V.n_owned
         R, Cc = R[keep], Cc[keep]

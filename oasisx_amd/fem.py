@@ -1491,6 +1491,36 @@ def lagrange_basis(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
     raise NotImplementedError(f"Lagrange degree {degree} on a {d}-simplex")
 
 
+def lagrange_basis_derivs(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
+    """dphi (npts, nd, d+1) = d(phi_i)/d(lambda_b) with the barycentric coordinates treated as independent variables
+    (grad phi_i = sum_b dphi[:, i, b] grad lambda_b).  The degree-3 element is written as a polynomial of (lambda_1,
+    lambda_2) alone: its column b = 0 is zero (the convention of csrc/fe_tables_h.h)."""
+    nv = d + 1
+    n = bary.shape[0]
+    if degree == 1:
+        return np.broadcast_to(np.eye(nv), (n, nv, nv)).copy()
+    if degree == 2:
+        edges = local_edges(d)
+        out = np.zeros((n, nv + len(edges), nv))
+        for a in range(nv):
+            out[:, a, a] = 4 * bary[:, a] - 1
+        for e, (a, b) in enumerate(edges):
+            out[:, nv + e, a] = 4 * bary[:, b]
+            out[:, nv + e, b] = 4 * bary[:, a]
+        return out
+    if degree == 3 and d == 2:
+        lagrange_basis(2, 3, bary[:1])  # (fills the coefficient cache)
+        ex = [(i, j) for i in range(4) for j in range(4 - i)]
+        x, y = bary[:, 1], bary[:, 2]
+        mx = np.stack([i * x ** max(i - 1, 0) * y ** j if i > 0 else np.zeros_like(x) for i, j in ex], axis=1)
+        my = np.stack([j * x ** i * y ** max(j - 1, 0) if j > 0 else np.zeros_like(x) for i, j in ex], axis=1)
+        out = np.zeros((n, 10, 3))
+        out[:, :, 1] = mx @ _P3_COEF
+        out[:, :, 2] = my @ _P3_COEF
+        return out
+    raise NotImplementedError(f"Lagrange degree {degree} on a {d}-simplex")
+
+
 def assemble_l2_error_sq(u: Function, exact, degree_raise: int = 3) -> float:
     """int (u_h - exact)^2 dx over the local cells (``assemble_scalar`` of the demo's error form).
     ``exact`` maps x:(3, npts) -> (npts,).  Host numpy; a harness functional, not the hot path."""

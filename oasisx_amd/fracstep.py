@@ -114,8 +114,6 @@ class FractionalStep_AB_CN:
         # demo/taylor_green.py:82-83,111); equal order P1-P1 (BASELINE configs[1])
         if (u_deg, p_deg) not in ((1, 1), (2, 1), (3, 2)):
             raise NotImplementedError(f"Lagrange P{u_deg}-P{p_deg}: the built pairs are P1-P1, P2-P1 and (triangles) P3-P2")
-        if p_deg == 2 and bcs_p:
-            raise NotImplementedError("PressureBC with a degree-2 pressure space")
         window = int((options or {}).get("sell_window", 4096))
 
         # ---- spaces (reference fracstep.py:186-216) ----------------------------------------

@@ -703,7 +703,10 @@ class PressureData:
         d = F.d
         dofs = []
         for c, a in zip(self.fc, self.fa):
-            dofs.extend(F.qd[c][[b for b in range(d + 1) if b != a]])
+            loc = [b for b in range(d + 1) if b != a]
+            if F.p_deg == 2:  # the facet's edge dofs too: local edges whose two vertices lie on the facet
+                loc += [d + 1 + e for e, (va, vb) in enumerate(local_edges(d)) if va != a and vb != a]
+            dofs.extend(F.qd[c][loc])
         self.dofs = np.unique(np.asarray(dofs, dtype=np.int64))
         self.update(x_q)
 

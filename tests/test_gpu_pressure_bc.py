@@ -19,23 +19,25 @@ def _facet_pairs(F, mesh, facets):
     return fcell, opp[fslot]
 
 
-@pytest.mark.parametrize("dim,P", [(2, 1), (2, 2), (3, 1), (3, 2)])
+@pytest.mark.parametrize("dim,P", [(2, 1), (2, 2), (3, 1), (3, 2), (2, 3)])
 @pytest.mark.parametrize("kind", ["const", "callable"])
 def test_pressure_condition(hip, dim, P, kind):
-    """PressureBC.rhs(i) assembles int h n_i dv/dx_i ds; .bc holds the tagged pressure dofs."""
+    """PressureBC.rhs(i) assembles int h n_i dv/dx_i ds; .bc holds the tagged pressure dofs.  (2, 3): the reference's
+    own parametrisation P = 3 with Q of degree P - 1 = 2 (test/test_bcs.py:166,189-190)."""
     from oasisx_amd import PressureBC, fem
     from oasisx_amd import mesh as M
     from oracle import ipcs_oracle as O
 
     mesh = (M.create_unit_square(None, 6, 5) if dim == 2 else M.create_unit_cube(None, 3, 3, 2))
-    V, Q = fem.FunctionSpace(mesh, P, window=64), fem.FunctionSpace(mesh, 1, window=64)
+    pq = 2 if P == 3 else 1
+    V, Q = fem.FunctionSpace(mesh, P, window=64), fem.FunctionSpace(mesh, pq, window=64)
     fd = dim - 1
     facets = M.locate_entities_boundary(mesh, fd, lambda x: np.isclose(x[0], 1.0))
     tags = M.meshtags(mesh, fd, facets, np.full(facets.shape, 2, dtype=np.int32))
     hfun = (lambda x: 1.0 + 2 * x[1] - x[dim - 1] ** 1) if kind == "callable" else None
     bc = PressureBC(hfun if hfun else 4.0, (tags, 2))
     bc.create_bcs(V, Q)
-    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), P, 1, vd=V.cell_dofs.cpu().numpy(),
+    F = O.Forms(mesh.coords.cpu().numpy(), V.cells_in_kernel_order(), P, pq, vd=V.cell_dofs.cpu().numpy(),
                 qd=Q.cell_dofs.cpu().numpy(), nv_dofs=V.num_dofs, nq_dofs=Q.num_dofs)
     fc, fa = _facet_pairs(F, mesh, facets)
     fc = V.kernel_cell_index(fc)
@@ -54,7 +56,7 @@ def test_pressure_condition(hip, dim, P, kind):
 
 @pytest.mark.parametrize("low_memory", [True, False])
 @pytest.mark.parametrize("body_force", [True, False])
-@pytest.mark.parametrize("u_deg", [1, 2])
+@pytest.mark.parametrize("u_deg", [1, 2, 3])
 def test_tentative_with_outlet(hip, low_memory, body_force, u_deg):
     """The reference's test_tentative set-up (10x10 unit square, dt 0.1, nu 0.5, sin inlet,
     no-slip walls, PressureBC(4.0) outlet), then a full solve() to cover the pressure Dirichlet
@@ -80,11 +82,12 @@ def test_tentative_with_outlet(hip, low_memory, body_force, u_deg):
     bc_in_x = ox.DirichletBC(inlet, ox.LocatorMethod.TOPOLOGICAL, (tags, 1))
     bc_in_y = ox.DirichletBC(0.0, ox.LocatorMethod.TOPOLOGICAL, (tags, 1))
     f = (0.3, -0.1) if body_force else None
-    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", u_deg), ("Lagrange", 1), bcs_u=[[bc_in_x, bc_tb], [bc_in_y, bc_tb]],
+    p_deg = 2 if u_deg == 3 else 1
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", u_deg), ("Lagrange", p_deg), bcs_u=[[bc_in_x, bc_tb], [bc_in_y, bc_tb]],
                                 bcs_p=[ox.PressureBC(4.0, (tags, 3))], solver_options=KRYLOV, body_force=f,
                                 options={"low_memory_version": low_memory, "sell_window": 128})
     Vi, Q = S._Vi[0][0], S._Q
-    F = O.Forms(mesh.coords.cpu().numpy(), Vi.cells_in_kernel_order(), u_deg, 1, vd=Vi.cell_dofs.cpu().numpy(),
+    F = O.Forms(mesh.coords.cpu().numpy(), Vi.cells_in_kernel_order(), u_deg, p_deg, vd=Vi.cell_dofs.cpu().numpy(),
                 qd=Q.cell_dofs.cpu().numpy(), nv_dofs=Vi.num_dofs, nq_dofs=Q.num_dofs)
     xv = Vi.x.cpu().numpy()
     ld = np.nonzero(np.isclose(xv[:, 0], 0))[0]
