@@ -104,8 +104,9 @@ class IPCS:
     """FractionalStep_AB_CN for Dirichlet velocity data on the whole boundary, no pressure condition,
     low_memory_version=True, Jacobi-BiCGStab / Jacobi-CG -- every operation a C-ABI call."""
 
-    def __init__(self, coords, cells, u_deg, rtol=1e-11, compress=False, cg_merged=False):
+    def __init__(self, coords, cells, u_deg, rtol=1e-11, compress=False, cg_merged=False, windows=False):
         self.L, self.lib = L, lib = load_binding()
+        self.windows = windows  # brick order of the velocity numbering + the LDS-window stream of its pattern
         self.cg_pressure = L.KSP_CG_MERGED if cg_merged else L.KSP_CG  # OX_KSP_CG_MERGED: one synchronisation point per iteration
         self.dev = dev = Device(L, lib)
         self.gdim = d = coords.shape[1]
@@ -118,8 +119,12 @@ class IPCS:
         self.mesh = mesh
         self.mv = L.ox_mesh_info()
         ck(lib.ox_mesh_view(mesh, C.byref(self.mv)), "ox_mesh_view")
-        self.V, self.vv = self._space(u_deg)
+        self.V, self.vv = self._space(u_deg, brick=windows)
         self.Q, self.qv = (self.V, self.vv) if u_deg == 1 else self._space(1)
+        self.window_info = None
+        if windows:  # ox_space_windows: built once per space, the arrays belong to it
+            self.window_info = w = L.ox_window_info()
+            ck(lib.ox_space_windows(self.V, C.byref(w)), "ox_space_windows")
         self.n_u, self.n_q = int(self.vv.n_dofs), int(self.qv.n_dofs)
         self.x_v = dev.download(self.vv.x, (self.n_u, d))
         self.x_q = dev.download(self.qv.x, (self.n_q, d))
@@ -157,9 +162,10 @@ class IPCS:
         self.work = dev.zeros(wb, np.uint8)
         self.its = {}
 
-    def _space(self, degree):
+    def _space(self, degree, brick=False):
         s = C.c_void_p()
-        self.L.check(self.lib.ox_space_create(self.mesh, degree, 0, C.byref(s)), "ox_space_create")
+        self.L.check(self.lib.ox_space_create_ordered(self.mesh, degree, 0, 1 if brick else 0, C.byref(s)),
+                     "ox_space_create_ordered")
         v = self.L.ox_space_info()
         self.L.check(self.lib.ox_space_view(s, C.byref(v)), "ox_space_view")
         return s, v
@@ -168,6 +174,10 @@ class IPCS:
         A = self.L.ox_sell()
         C.memmove(C.byref(A), C.byref(pat.sell), C.sizeof(A))
         A.vals = self.dev.zeros(int(pat.size)).value
+        w = getattr(self, "window_info", None)
+        if w is not None and pat is self.vv.pattern and w.n_wblocks > 0:  # the velocity matrices run on the window stream
+            for f in ("wb_slices", "wb_waves", "wb_ptr", "wlist", "wt_ptr", "wcode", "n_wblocks", "w_max"):
+                setattr(A, f, getattr(w, f))
         return A
 
     def _compress(self, A, pat, pairs):
@@ -180,6 +190,11 @@ class IPCS:
             return {"n_dict": 0, "pair_codes": 0}
         A.vcode, A.vdict, A.n_dict = codes.value, vdict.value, nd.value
         built = {"n_dict": int(nd.value), "pair_codes": 0}
+        if A.n_wblocks > 0:  # a dictionary matrix on the window stream: its value codes in the tile layout
+            tiled = dev.zeros(int(self.window_info.n_tiles) * 256, np.uint8)
+            ck(lib.ox_window_retile(C.byref(A), A.wt_ptr, codes, 1, tiled, None), "ox_window_retile")
+            A.wvcode = tiled.value
+            built["tiled_codes"] = int(self.window_info.n_tiles) * 256
         if pairs:
             ps_ptr, ncodes = dev.zeros(int(A.n_slices) + 1, np.int64), C.c_int64(0)
             ck(lib.ox_pair_stream_size(C.byref(A), pat.row_len, ps_ptr, C.byref(ncodes), None), "ox_pair_stream_size")
@@ -266,9 +281,9 @@ def tg(dim, nu):
     return [u, v, w][:dim], p
 
 
-def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=False, cg_merged=False):
+def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=False, cg_merged=False, windows=False):
     coords, cells = box_mesh(dim, N)
-    S = IPCS(coords, cells, u_deg, rtol, compress, cg_merged)
+    S = IPCS(coords, cells, u_deg, rtol, compress, cg_merged, windows)
     fns, pf = tg(dim, nu)
     X, Xq = S.x_v.T, S.x_q.T
     S.set_field(S.U2, np.stack([f(X, -dt) for f in fns], axis=1))
@@ -282,7 +297,9 @@ def run(dim=2, N=8, u_deg=2, steps=2, nu=0.01, dt=0.005, rtol=1e-11, compress=Fa
     out = {"coords": coords, "cells": cells, "x_v": S.x_v, "x_q": S.x_q, "u": S.dev.download(S.U1, (S.n_u, dim)),
            "p": S.dev.download(S.P, (S.n_q,)), "its_pressure": np.asarray(S.its["pressure"]), "t": t,
            "imported_package": np.asarray("oasisx_amd" in sys.modules), "imported_torch": np.asarray("torch" in sys.modules),
-           "compressed": np.asarray(repr(S.compressed))}
+           "compressed": np.asarray(repr(S.compressed)),
+           "window_blocks": np.asarray(0 if S.window_info is None else int(S.window_info.n_wblocks)),
+           "window_max": np.asarray(0 if S.window_info is None else int(S.window_info.w_max))}
     S.close()
     return out
 
@@ -296,8 +313,11 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=None)
     ap.add_argument("--compress", action="store_true", help="value dictionaries and the pair-slot stream for M, K, Ap")
     ap.add_argument("--cg-merged", action="store_true", help="OX_KSP_CG_MERGED for the pressure solve")
+    ap.add_argument("--windows", action="store_true",
+                    help="brick order of the velocity numbering (ox_space_create_ordered) and the LDS-window stream of its "
+                         "pattern (ox_space_windows, ox_window_retile): M, K, A multiply through k_spmv_win")
     a = ap.parse_args()
-    r = run(a.dim, a.N, a.udeg, a.steps, compress=a.compress, cg_merged=a.cg_merged)
+    r = run(a.dim, a.N, a.udeg, a.steps, compress=a.compress, cg_merged=a.cg_merged, windows=a.windows)
     ex = [f(r["x_v"].T, r["t"]) for f in tg(a.dim, 0.01)[0]]
     print("C-ABI step: n_u", r["x_v"].shape[0], "n_p", r["x_q"].shape[0], "max |u - u_exact| =",
           float(max(np.abs(r["u"][:, i] - ex[i]).max() for i in range(a.dim))), "pressure iterations", r["its_pressure"])

@@ -1242,14 +1242,14 @@ __global__ __launch_bounds__(256) void k_win_slice_keys(const int32_t *__restric
   }
 }
 
-__global__ __launch_bounds__(256) void k_win_blocks(const int32_t *__restrict__ order, int n_slices, int spw, int bpw,
+__global__ __launch_bounds__(256) void k_win_blocks(const int32_t *__restrict__ order, int n_slices, int spw, int bpw, int spb,
                                                     int32_t *__restrict__ wb_slices, int32_t *__restrict__ blk_of_slice) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_slices) return;
   const int slice = order[i];
   const int w = i / spw, j = i - w * spw;  // the windows are contiguous runs of spw slices, in the sorted order too
-  const int b = w * bpw + (j >> 3);
-  wb_slices[(size_t)b * 8 + (j & 7)] = slice;
+  const int b = w * bpw + j / spb;
+  wb_slices[(size_t)b * 8 + j % spb] = slice;
   blk_of_slice[slice] = b;
 }
 
@@ -1379,10 +1379,12 @@ int build_windows(ox_space *V, hipStream_t st) {
     return 0;
   }
   const int spw = std::max(1, V->window / SLICE);
-  const int bpw = (spw + 7) / 8;
+  int spb = 8;  // slices per window block (OX_WIN_SPB: tuning)
+  if (const char *e = getenv("OX_WIN_SPB")) spb = std::min(8, std::max(1, atoi(e)));
+  const int bpw = (spw + spb - 1) / spb;
   const int nwin = (ns + spw - 1) / spw;
   const int c_last = ns - (nwin - 1) * spw;
-  const int nb = (nwin - 1) * bpw + (c_last + 7) / 8;
+  const int nb = (nwin - 1) * bpw + (c_last + spb - 1) / spb;
   auto nblk = [](int64_t n) { return (unsigned)((n + 255) / 256); };
   const int64_t *slice_ptr = P.slice_ptr.as<int64_t>();
   const int32_t *cols = P.cols.as<int32_t>();
@@ -1403,7 +1405,7 @@ int build_windows(ox_space *V, hipStream_t st) {
   }
   OX_TRY(V->wb_slices.alloc(sizeof(int32_t) * (size_t)nb * 8));
   OX_HIP(hipMemsetAsync(V->wb_slices.p, 0xff, sizeof(int32_t) * (size_t)nb * 8, st));
-  hipLaunchKernelGGL(k_win_blocks, dim3(nblk(ns)), dim3(256), 0, st, order.as<int32_t>(), ns, spw, bpw, V->wb_slices.as<int32_t>(),
+  hipLaunchKernelGGL(k_win_blocks, dim3(nblk(ns)), dim3(256), 0, st, order.as<int32_t>(), ns, spw, bpw, spb, V->wb_slices.as<int32_t>(),
                      blk_of_slice.as<int32_t>());
   OX_LAUNCH_CHECK();
   OX_TRY(V->wb_waves.alloc(sizeof(uint16_t) * (size_t)nb));

@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dim,N,udeg,compress,merged", [(2, 12, 2, False, False), (3, 5, 2, False, True), (3, 6, 1, False, False),
-                                                        (3, 6, 2, True, True), (2, 16, 1, True, False)])
-def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, merged):
+@pytest.mark.parametrize("dim,N,udeg,compress,merged,windows", [
+    (2, 12, 2, False, False, False), (3, 5, 2, False, True, False), (3, 6, 1, False, False, False), (3, 6, 2, True, True, False),
+    (2, 16, 1, True, False, False), (3, 8, 2, True, False, True), (2, 24, 2, False, False, True)])
+def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, merged, windows):
     from oracle import ipcs_oracle as O
     from oracle.cpu_baseline import match_by_coordinates
     from tests.helpers import KRYLOV
@@ -24,7 +25,8 @@ def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, me
     out = str(tmp_path / "step.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "cabi_ipcs_step.py"), "--dim", str(dim), "-N", str(N),
                         "--udeg", str(udeg), "--steps", "2", "--out", out] + (["--compress"] if compress else [])
-                       + (["--cg-merged"] if merged else []),  # (OX_KSP_CG_MERGED for the pressure solve)
+                       + (["--cg-merged"] if merged else [])  # (OX_KSP_CG_MERGED for the pressure solve)
+                       + (["--windows"] if windows else []),  # brick order + ox_space_windows / ox_window_retile
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     g = np.load(out)
@@ -33,6 +35,8 @@ def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, me
         # (the P2 matrices of this two-shape mesh have more than 256 distinct values: declined, as designed)
         assert built["Ap"]["n_dict"] > 0 and built["Ap"]["pair_codes"] > 0 and set(built) == {"M", "K", "Ap"}, built
     assert not bool(g["imported_package"]) and not bool(g["imported_torch"])  # the C ABI was all it used
+    if windows:  # the velocity matrices really carried window blocks
+        assert int(g["window_blocks"]) > 0 and int(g["window_max"]) > 0
     nu, dt = 0.01, 0.005
     R, clock = O.taylor_green_problem(0, dim, u_deg=udeg, p_deg=1, nu=nu, dt=dt, solver_options=KRYLOV,
                                       mesh=(g["coords"], g["cells"].astype(np.int64)))
