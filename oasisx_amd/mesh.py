@@ -239,9 +239,137 @@ def _read_plain(path):
     return pts, cells
 
 
+# Gmsh element types of the simplices: number of nodes
+_GMSH_NODES = {15: 1, 1: 2, 2: 3, 4: 4}
+
+
+def _read_gmsh(path):
+    """Gmsh ``.msh`` ASCII, format 2.2 or 4.1 (what ``gmsh -format msh2 / msh4`` writes and
+    ``dolfinx.io.gmshio.read_from_msh`` reads for the reference's users): first-order points, lines, triangles and
+    tetrahedra.  Returns (points (n, 3), {element type: (node ids 0-based (m, k), physical tag (m,))})."""
+    lines = open(path).read().split("\n")
+    sec, i = {}, 0
+    while i < len(lines):
+        ln = lines[i].strip()
+        if ln.startswith("$") and not ln.startswith("$End"):
+            j = i + 1
+            while j < len(lines) and lines[j].strip() != "$End" + ln[1:]:
+                j += 1
+            sec[ln[1:]] = lines[i + 1:j]
+            i = j
+        i += 1
+    if "MeshFormat" not in sec:
+        raise ValueError(f"{path}: not a Gmsh .msh file")
+    fmt = sec["MeshFormat"][0].split()
+    version, binary = float(fmt[0]), int(fmt[1])
+    if binary:
+        raise ValueError(f"{path}: binary .msh files are not read (write ASCII: gmsh -format msh4 / Mesh.Binary = 0)")
+    elems = {}
+
+    def add(etype, nodes, tag):
+        if etype in _GMSH_NODES:
+            elems.setdefault(etype, ([], []))
+            elems[etype][0].append(nodes)
+            elems[etype][1].append(tag)
+
+    if version < 3.0:
+        body = sec["Nodes"]
+        n = int(body[0])
+        tab = np.asarray([ln.split() for ln in body[1:1 + n]], dtype=np.float64)
+        ids, pts = tab[:, 0].astype(np.int64), tab[:, 1:4]
+        body = sec["Elements"]
+        for ln in body[1:1 + int(body[0])]:
+            t = [int(v) for v in ln.split()]
+            etype, ntags = t[1], t[2]
+            add(etype, t[3 + ntags:3 + ntags + _GMSH_NODES.get(etype, 0)], t[3] if ntags > 0 else 0)
+    else:
+        phys = {}  # (entity dim, entity tag) -> first physical tag
+        if "Entities" in sec:
+            body = sec["Entities"]
+            counts = [int(v) for v in body[0].split()]
+            k = 1
+            for dim, cnt in enumerate(counts):
+                for _ in range(cnt):
+                    t = body[k].split()
+                    k += 1
+                    off = 4 if dim == 0 else 7  # tag + a point, or tag + a bounding box
+                    nph = int(t[off])
+                    phys[(dim, int(t[0]))] = int(t[off + 1]) if nph > 0 else 0
+        body = sec["Nodes"]
+        nblocks = int(body[0].split()[0])
+        k, ids, pts = 1, [], []
+        for _ in range(nblocks):
+            h = [int(v) for v in body[k].split()]
+            nn = h[3]
+            ids += [int(v) for v in body[k + 1:k + 1 + nn]]
+            pts += [[float(v) for v in ln.split()[:3]] for ln in body[k + 1 + nn:k + 1 + 2 * nn]]
+            k += 1 + 2 * nn
+        ids, pts = np.asarray(ids, dtype=np.int64), np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+        body = sec["Elements"]
+        nblocks = int(body[0].split()[0])
+        k = 1
+        for _ in range(nblocks):
+            edim, etag, etype, ne = (int(v) for v in body[k].split())
+            tag = phys.get((edim, etag), 0)
+            for ln in body[k + 1:k + 1 + ne]:
+                add(etype, [int(v) for v in ln.split()[1:1 + _GMSH_NODES.get(etype, 0)]], tag)
+            k += 1 + ne
+    lookup = np.full(int(ids.max()) + 1, -1, dtype=np.int64)
+    lookup[ids] = np.arange(ids.shape[0])
+    out = {}
+    for etype, (nodes, tags) in elems.items():
+        out[etype] = (lookup[np.asarray(nodes, dtype=np.int64)], np.asarray(tags, dtype=np.int32))
+    return pts, out
+
+
+def read_gmsh(filename: str, comm=None, device=None, gdim: int | None = None):
+    """``dolfinx.io.gmshio.read_from_msh`` for first-order simplicial meshes: (mesh, cell_tags, facet_tags) from a Gmsh
+    ASCII ``.msh`` file (2.2 or 4.1).  The tags are the physical groups of the cells and of the facet elements (lines
+    in 2-D, triangles in 3-D) the file lists -- ``MeshTags`` ready for ``DirichletBC(..., LocatorMethod.TOPOLOGICAL,
+    (facet_tags, id))`` and ``PressureBC(value, (facet_tags, id))``.  ``gdim``: 2 drops the z coordinate (default: 2
+    when the file holds no tetrahedron and z is constant)."""
+    pts, el = _read_gmsh(filename)
+    if gdim is None:
+        gdim = 3 if 4 in el else (2 if np.ptp(pts[:, 2]) == 0.0 else 3)
+    ctype, ftype = (4, 2) if gdim == 3 and 4 in el else (2, 1)
+    if ctype not in el:
+        raise ValueError(f"{filename}: no {'tetrahedra' if ctype == 4 else 'triangles'} found")
+    cells, ctag = el[ctype]
+    used = np.zeros(pts.shape[0], dtype=bool)
+    used[cells.ravel()] = True
+    new = np.cumsum(used) - 1
+    mesh = from_arrays(pts[used][:, :gdim], new[cells], comm=comm, device=device)
+    cell_tags = MeshTags(mesh, gdim, np.arange(cells.shape[0], dtype=np.int32), ctag)
+    fidx, fval = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    if ftype in el:
+        fn, ft = el[ftype]
+        keep = used[fn].all(axis=1)
+        fn, ft = np.sort(new[fn[keep]], axis=1), ft[keep]
+        ev, _ = mesh._entities(gdim - 1)  # facet -> sorted vertices
+        nv = mesh.num_vertices
+
+        def key(a):
+            k = np.zeros(a.shape[0], dtype=np.int64)
+            for c in range(a.shape[1]):
+                k = k * np.int64(nv) + a[:, c]
+            return k
+        ka, kf = key(ev), key(fn)
+        order = np.argsort(ka)
+        pos = np.searchsorted(ka[order], kf)
+        ok = (pos < ka.shape[0]) & (ka[order][np.minimum(pos, ka.shape[0] - 1)] == kf)
+        idx = order[pos[ok]]
+        srt = np.argsort(idx)
+        fidx, fval = idx[srt].astype(np.int32), ft[ok][srt]
+        first = np.ones(fidx.shape[0], dtype=bool)
+        first[1:] = fidx[1:] != fidx[:-1]
+        fidx, fval = fidx[first], fval[first]
+    return mesh, cell_tags, MeshTags(mesh, gdim - 1, fidx, fval)
+
+
 def read_mesh(filename: str, comm=None, device=None) -> Mesh:
-    """Simplicial mesh from a file: ``.npz`` (arrays ``points``/``coords`` and ``cells``), Medit ASCII ``.mesh``
-    or the plain text format of :func:`write_mesh`.  Cells may come in any order and orientation; unused
+    """Simplicial mesh from a file: ``.npz`` (arrays ``points``/``coords`` and ``cells``), Medit ASCII ``.mesh``,
+    Gmsh ASCII ``.msh`` (2.2 / 4.1; with its physical groups: :func:`read_gmsh`) or the plain text format of
+    :func:`write_mesh`.  Cells may come in any order and orientation; unused
     vertices are dropped.  No gmsh / XDMF / ADIOS2 dependency."""
     ext = filename.rsplit(".", 1)[-1].lower()
     if ext == "npz":
@@ -250,6 +378,8 @@ def read_mesh(filename: str, comm=None, device=None) -> Mesh:
         cells = np.asarray(z["cells"], dtype=np.int64)
     elif ext == "mesh":
         pts, cells = _read_medit(filename)
+    elif ext == "msh":  # Gmsh ASCII 2.2 / 4.1 (the physical groups: read_gmsh)
+        return read_gmsh(filename, comm=comm, device=device)[0]
     else:
         pts, cells = _read_plain(filename)
     if cells.ndim != 2 or cells.shape[1] != pts.shape[1] + 1:

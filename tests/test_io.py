@@ -59,3 +59,102 @@ def test_functions_on_different_spaces_are_refused(tmp_path):
     V1, V2 = fem.functionspace(mesh, ("Lagrange", 1)), fem.functionspace(mesh, ("Lagrange", 2))
     with pytest.raises(RuntimeError):
         io.VTXWriter(mesh.comm, str(tmp_path / "x.bp"), [fem.Function(V1), fem.Function(V2)])
+
+
+MSH22 = """$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$PhysicalNames
+2
+1 7 "inlet"
+2 9 "fluid"
+$EndPhysicalNames
+$Nodes
+5
+1 0 0 0
+2 1 0 0
+4 1 1 0
+7 0 1 0
+9 5 5 0
+$EndNodes
+$Elements
+5
+1 1 2 7 1 1 7
+2 1 2 8 2 2 4
+3 2 2 9 1 1 2 4
+4 2 2 9 1 1 4 7
+5 15 2 3 1 1
+$EndElements
+"""
+
+MSH41 = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$Entities
+4 4 1 0
+1 0 0 0 0
+2 1 0 0 0
+3 1 1 0 0
+4 0 1 0 0
+1 0 0 0 1 0 0 0 2 1 -2
+2 1 0 0 1 1 0 1 8 2 2 -3
+3 0 1 0 1 1 0 0 2 3 -4
+4 0 0 0 0 1 0 1 7 2 4 -1
+1 0 0 0 1 1 0 1 9 4 1 2 3 4
+$EndEntities
+$Nodes
+1 4 1 4
+2 1 0 4
+1
+2
+3
+4
+0 0 0
+1 0 0
+1 1 0
+0 1 0
+$EndNodes
+$Elements
+3 4 1 4
+1 2 1 1
+1 2 3
+1 4 1 1
+2 4 1
+2 1 2 2
+3 1 2 3
+4 1 3 4
+$EndElements
+"""
+
+
+@pytest.mark.parametrize("text", [MSH22, MSH41])
+def test_gmsh_reader_with_physical_groups(tmp_path, text):
+    """Gmsh ASCII .msh (2.2 and 4.1), the route the reference's users take into DOLFINx (gmshio): mesh, cell tags and
+    facet tags; node ids with gaps and unused nodes; the tagged lines land on the right mesh facets."""
+    from oasisx_amd import mesh as M
+
+    path = str(tmp_path / "square.msh")
+    open(path, "w").write(text)
+    mesh, ct, ft = M.read_gmsh(path, device="cpu")
+    assert mesh.gdim == 2 and mesh.num_vertices == 4 and mesh.num_cells == 2
+    assert (ct.values == 9).all() and ct.dim == 2
+    x = mesh.coords.numpy()
+    ev, _ = mesh._entities(1)
+    assert ft.dim == 1 and sorted(ft.values.tolist()) == [7, 8]
+    for tag, xval in ((7, 0.0), (8, 1.0)):
+        f = ft.find(tag)
+        assert f.shape[0] == 1 and np.allclose(x[ev[f[0]], 0], xval)  # inlet on x = 0, the other line on x = 1
+    assert (np.diff(ft.indices) > 0).all()
+    # the area, and the same mesh through read_mesh / import_mesh
+    J = x[mesh.cells.numpy()[:, 1:]] - x[mesh.cells.numpy()[:, :1]]
+    assert abs(np.abs(np.linalg.det(J)).sum() / 2 - 1.0) < 1e-14
+    assert M.read_mesh(path, device="cpu").num_cells == 2
+
+
+def test_gmsh_reader_refuses_binary_files(tmp_path):
+    from oasisx_amd import mesh as M
+
+    path = str(tmp_path / "b.msh")
+    open(path, "w").write("$MeshFormat\n4.1 1 8\n$EndMeshFormat\n")
+    with pytest.raises(ValueError, match="binary"):
+        M.read_gmsh(path)
