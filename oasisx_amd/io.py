@@ -6,8 +6,8 @@ ADIOS2/BP4 is not available here; the writer produces the open VTK XML format in
 ``<stem>_<step>.vtu`` (UnstructuredGrid, base64 "binary" arrays, float64) per ``write(t)`` and a
 ``<stem>.pvd`` collection that maps the files to their time values -- ParaView opens the ``.pvd``
 as the time series it would get from the ``.bp`` directory.  P2 fields are written on quadratic
-cells (VTK_QUADRATIC_TRIANGLE = 22, VTK_QUADRATIC_TETRA = 24) with the P2 nodes as points, so no
-interpolation to P1 happens, as with VTX.  In mesh-partitioned runs every rank writes the cells
+cells (VTK_QUADRATIC_TRIANGLE = 22, VTK_QUADRATIC_TETRA = 24) with the P2 nodes as points, P3 fields on triangles on
+VTK_LAGRANGE_TRIANGLE = 69 cells with the (gll_warped) P3 nodes as points, so no interpolation to P1 happens, as with VTX.  In mesh-partitioned runs every rank writes the cells
 of its own partition as a separate piece (``<stem>_p<rank>_<step>.vtu``), all listed in the .pvd
 written by rank 0.
 
@@ -25,8 +25,10 @@ from .fem import Function, VectorFunctionSpace
 # my local dof order (vertices, then fem.local_edges) -> VTK node order
 _VTK_PERM = {(2, 1): [0, 1, 2], (3, 1): [0, 1, 2, 3],
              (2, 2): [0, 1, 2, 5, 3, 4],  # e01, e12, e20
-             (3, 2): [0, 1, 2, 3, 9, 6, 8, 7, 5, 4]}  # e01, e12, e02, e03, e13, e23
-_VTK_TYPE = {(2, 1): 5, (3, 1): 10, (2, 2): 22, (3, 2): 24}
+             (3, 2): [0, 1, 2, 3, 9, 6, 8, 7, 5, 4],  # e01, e12, e02, e03, e13, e23
+             # P3 triangle -> VTK_LAGRANGE_TRIANGLE: e01 (from 0 to 1), e12 (1 to 2), e20 (2 to 0), interior
+             (2, 3): [0, 1, 2, 7, 8, 3, 4, 6, 5, 9]}
+_VTK_TYPE = {(2, 1): 5, (3, 1): 10, (2, 2): 22, (3, 2): 24, (2, 3): 69}
 
 
 def _b64(a: np.ndarray) -> str:

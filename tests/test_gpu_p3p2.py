@@ -130,3 +130,30 @@ def test_p3p2_taylor_green_errors_against_the_analytic_solution(hip):
     assert e16[0] < e8[0] < e4[0] and e16[1] < e8[1] < e4[1], errs
     assert np.log2(e8[0] / e16[0]) > 1.8 and np.log2(e8[1] / e16[1]) > 2.0, errs
     assert e16[0] < 0.5 * errs[((2, 1), 16)][0] and e16[1] < 0.5 * errs[((2, 1), 16)][1], errs
+
+
+def test_p3_fields_written_on_vtk_lagrange_triangles(hip, tmp_path):
+    """VTXWriter on a degree-3 field (the demo's output with -u 3): VTK_LAGRANGE_TRIANGLE cells whose node order is
+    VTK's -- corners, then the two nodes of edge 01 from 0 to 1, of 12 from 1 to 2, of 20 from 2 to 0, then the centroid."""
+    from oasisx_amd import fem, io
+    from tests.helpers import tg_mesh
+
+    mesh = tg_mesh(2, 5)
+    V = fem.FunctionSpace(mesh, 3, window=128)
+    W = fem.VectorFunctionSpace(V, 2)
+    u = fem.Function(W, name="u")
+    u.interpolate(lambda x: np.stack([x[0] ** 3 - x[1], 2.0 * x[0] * x[1]]))
+    w = io.VTXWriter(mesh.comm, str(tmp_path / "u.bp"), [u], engine="BP4")
+    w.write(0.25)
+    w.close()
+    d = io.read_vtu(str(tmp_path / "u_000000.vtu"))
+    assert int(d["types"][0]) == 69
+    conn = d["connectivity"].reshape(-1, 10)
+    assert conn.shape[0] == mesh.num_cells and np.unique(conn).shape[0] == V.num_dofs
+    P = d["points"][:, :2]
+    t0, t1 = fem.GLL3
+    for j, (a, b) in enumerate(((0, 1), (1, 2), (2, 0))):
+        for k, t in enumerate((t0, t1)):
+            np.testing.assert_allclose(P[conn[:, 3 + 2 * j + k]], (1 - t) * P[conn[:, a]] + t * P[conn[:, b]], atol=1e-14)
+    np.testing.assert_allclose(P[conn[:, 9]], P[conn[:, :3]].mean(axis=1), atol=1e-14)
+    np.testing.assert_allclose(d["point_data"]["u"][:, 0], P[:, 0] ** 3 - P[:, 1], atol=1e-13)
