@@ -484,7 +484,7 @@ class FunctionSpace:
         # OX_BRICK=1 forces it for tuning runs
         if brick is None:
             brick = _os.environ.get("OX_BRICK", "0") == "1"
-        self.brick = bool(brick) and part is None and degree >= 2
+        self.brick = bool(brick) and part is None
         self.mesh = mesh
         self.degree = degree
         self.element = _Element(degree, mesh.gdim)

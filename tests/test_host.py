@@ -254,3 +254,45 @@ def test_high_order_lagrange_space_3d():
         bct.create_bc(V)
         assert (np.sort(bct._dofs) == np.sort(bc._dofs)).all()
         assert np.allclose(bc.values_host(), X[bc._dofs, 0] + 2 * X[bc._dofs, 1])
+
+
+def test_p3_basis_matches_the_oracle_and_is_nodal():
+    """fem.lagrange_basis / lagrange_basis_derivs (host plumbing of load vectors, PressureBC and error functionals) against
+    the oracle's tabulation, for every built element; P3 (gll_warped) is nodal at its own nodes."""
+    for d, deg in ((2, 1), (2, 2), (2, 3), (3, 1), (3, 2)):
+        bary, _ = O.simplex_quadrature(d, 4)
+        phi, dphi = O.tabulate(d, deg, bary)
+        assert np.abs(fem.lagrange_basis(d, deg, bary) - phi).max() < 1e-13
+        assert np.abs(fem.lagrange_basis_derivs(d, deg, bary) - dphi).max() < 1e-12
+    nodes = O.p3_nodes_2d()
+    assert np.abs(fem.lagrange_basis(2, 3, nodes) - np.eye(10)).max() < 1e-13
+    assert abs(fem.GLL3[0] - O.GLL3[0]) < 1e-16 and abs(fem.GLL3[0] + fem.GLL3[1] - 1.0) < 1e-16
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_uniform_refinement_is_conforming(dim):
+    """mesh.refine_uniform: 2^dim children per cell, the same volume, every interior facet shared by exactly two cells,
+    the old vertices first; twice on a Delaunay mesh (what bench.py's unstructured leg is built from)."""
+    import itertools
+
+    X, T = M.refine_uniform(*_delaunay_arrays(dim))
+    X0, T0 = _delaunay_arrays(dim)
+    assert T.shape[0] == T0.shape[0] * 2 ** dim and np.array_equal(X[: X0.shape[0]], X0)
+    X, T = M.refine_uniform(X, T)
+
+    def vol(P, C):
+        J = np.stack([P[C[:, a]] - P[C[:, 0]] for a in range(1, dim + 1)], axis=2)
+        return np.abs(np.linalg.det(J)).sum()
+    assert abs(vol(X, T) - vol(X0, T0)) < 1e-12 * vol(X0, T0) and np.abs(np.linalg.det(
+        np.stack([X[T[:, a]] - X[T[:, 0]] for a in range(1, dim + 1)], axis=2))).min() > 0
+    f = np.concatenate([np.sort(T[:, list(c)], axis=1) for c in itertools.combinations(range(dim + 1), dim)])
+    _, cnt = np.unique(f, axis=0, return_counts=True)
+    assert set(np.unique(cnt).tolist()) <= {1, 2}
+    f0 = np.concatenate([np.sort(T0[:, list(c)], axis=1) for c in itertools.combinations(range(dim + 1), dim)])
+    _, cnt0 = np.unique(f0, axis=0, return_counts=True)
+    assert (cnt == 1).sum() == (cnt0 == 1).sum() * 2 ** (2 * (dim - 1))  # every boundary facet became 4^... children
+
+
+def _delaunay_arrays(dim):
+    m = M.create_delaunay_box(None, [[-1.0] * dim, [1.0] * dim], 4, device="cpu")
+    return m.coords.numpy().copy(), m.cells.numpy().astype(np.int64)

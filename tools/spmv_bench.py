@@ -11,7 +11,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 which = sys.argv[2] if len(sys.argv) > 2 else "p"
 mesh = M.create_box(None, [[-1.,-1.,-1.],[1.,1.,1.]], [N,N,N])
 deg, nc = {"p": (1, 1), "u": (2, 3), "u1": (2, 1)}[which]  # u1: one column on the velocity matrix (narrowed solves)
-V = fem.FunctionSpace(mesh, deg, window=int(os.environ.get("WINDOW", "4096")))
+V = fem.FunctionSpace(mesh, deg, window=int(os.environ.get("WINDOW", "4096")), brick=os.environ.get("BRICK") == "1")
+if os.environ.get("WIN") == "1":  # LDS-window stream of the pattern (variant bit 4): VARIANTS=15,31 compares
+    print("windows:", V.build_windows(), getattr(V.pattern, "w_stats", None))
 A = SellMatrix(V.pattern); A.vals.uniform_(0.5, 1.5)
 real = os.environ.get("REAL", "")  # "stiff" / "mass": the mesh's real stiffness / mass matrix, frozen
 if real:
