@@ -80,7 +80,7 @@ def _p(a):
 
 def reference_tensors(d, u_deg, p_deg):
     """Reference-element tensors the C kernels contract with (collapsed Gauss-Jacobi, exact)."""
-    bary, w = O.simplex_quadrature(d, 4)
+    bary, w = O.simplex_quadrature(d, 4 if max(u_deg, p_deg) <= 2 else 5)  # degree 7; 9 for P3 (convection: 3 + 2 + 3)
     phi, dphi = O.tabulate(d, u_deg, bary)
     psi, dpsi = O.tabulate(d, p_deg, bary)
     Tc = np.einsum("q,qk,qja,qi->kaji", w, phi, dphi, phi)
@@ -212,7 +212,7 @@ class CpuIPCS:
 
 def reference_setup_tensors(d, deg):
     """Reference-simplex tensors of the port's own mass / stiffness / weight assembly."""
-    bary, w = O.simplex_quadrature(d, 4)
+    bary, w = O.simplex_quadrature(d, 4 if deg <= 2 else 5)
     phi, dphi = O.tabulate(d, deg, bary)
     Tm = np.einsum("q,qi,qj->ij", w, phi, phi)
     Tk = np.einsum("q,qia,qjb->ijab", w, dphi, dphi)
@@ -251,12 +251,12 @@ def from_mesh(coords, cells, u_deg, p_deg, ksp, body_force=None):
     d = coords.shape[1]
     nverts = coords.shape[0]
     vd, nv_dofs, ev = O.build_dofmap(cells, nverts, u_deg)
-    x_v = O.dof_coordinates(coords, u_deg, ev)
+    x_v = O.dof_coordinates(coords, u_deg, ev, cells)
     if p_deg == u_deg:
         qd, nq_dofs, x_q = vd, nv_dofs, x_v
     else:
         qd, nq_dofs, eq = O.build_dofmap(cells, nverts, p_deg)
-        x_q = O.dof_coordinates(coords, p_deg, eq)
+        x_q = O.dof_coordinates(coords, p_deg, eq, cells)
     del ev
     G, adet = O.cell_geometry(coords, cells)
     geom = pack_geometry(G, adet)

@@ -157,3 +157,42 @@ def test_p3_fields_written_on_vtk_lagrange_triangles(hip, tmp_path):
             np.testing.assert_allclose(P[conn[:, 3 + 2 * j + k]], (1 - t) * P[conn[:, a]] + t * P[conn[:, b]], atol=1e-14)
     np.testing.assert_allclose(P[conn[:, 9]], P[conn[:, :3]].mean(axis=1), atol=1e-14)
     np.testing.assert_allclose(d["point_data"]["u"][:, 0], P[:, 0] ** 3 - P[:, 1], atol=1e-13)
+
+
+def test_p3p2_steps_against_the_c_port_on_its_own_mesh(hip):
+    """The second witness: oracle/ipcs_cpu.c (generic in the element tensors) set up from the mesh definition alone --
+    its own P3 / P2 numbering, patterns and operators, Jacobi-BiCGStab / Jacobi-CG like the device -- against the device's
+    P3-P2 steps through the dof coordinates."""
+    from oracle import cpu_baseline as CB
+    from oracle import ipcs_oracle as O
+    from oracle.cpu_baseline import match_by_coordinates
+
+    N, nu, dt, steps = 20, 0.01, 0.004, 3
+    ksp = {"ksp_rtol": 1e-11, "ksp_atol": 1e-30, "pc_type": "jacobi"}
+    opts = {"tentative": dict(ksp, ksp_type="bcgs"), "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")}
+    S, clock, mesh = _problem(N, True, opts, nu, dt)
+    coords, cells = O.create_rectangle_mesh([-1, -1], [1, 1], [N, N])
+    cpu, x_v, x_q = CB.from_mesh(coords, cells, 3, 2, {"rtol": 1e-11, "atol": 1e-30, "max_it": 10000, "guess": False})
+    lo, hi = np.array([-1.0, -1.0]), np.array([1.0, 1.0])
+    pv = match_by_coordinates(S._Vi[0][0].x.cpu().numpy(), x_v, lo, hi)
+    pq = match_by_coordinates(S._Q.x.cpu().numpy(), x_q, lo, hi)
+    assert cpu.nu_ == S._n_u == (N + 1) ** 2 + 2 * (3 * N * N + 2 * N) + 2 * N * N and cpu.nq == S._n_q
+    X = np.zeros((3, x_v.shape[0]))
+    X[:2] = x_v.T
+    Xq = np.zeros((3, x_q.shape[0]))
+    Xq[:2] = x_q.T
+    for i, f in enumerate((O.tg_u, O.tg_v)):
+        cpu.u2[i] = f(X, -dt, nu)
+        cpu.u1[i] = f(X, 0.0, nu)
+    cpu.p[:] = O.tg_p(Xq, -dt / 2.0, nu)
+    Xb = X[:, cpu.bc_dofs]
+    t = 0.0
+    for _ in range(steps):
+        t += dt
+        clock["t"] = t
+        S.solve(dt, nu, max_iter=1)
+        cpu.step(dt, nu, np.stack([f(Xb, t, nu) for f in (O.tg_u, O.tg_v)]))
+    u = S.u.x.array.reshape(-1, 2)
+    assert np.abs(u[pv] - cpu.u1.T).max() < 1e-8 and np.abs(S._p.x.array[pq] - cpu.p).max() < 1e-7
+    its_h, its_c = S.iteration_counts(), cpu.its
+    assert abs(max(its_h["pressure"]) - its_c["pressure"][0]) <= 2, (its_h, its_c)
