@@ -32,7 +32,6 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
-import time
 import typing
 
 import torch
@@ -62,7 +61,6 @@ class KSPSolver:
         self.last_result = None
         self.check_every = None  # override of the automatic check interval (see solve_block)
         self._every = {}
-        self._every_seen = {}
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -119,7 +117,6 @@ class KSPSolver:
         self._A = A
         self._dinv_version = -1
         self._every = {}
-        self._every_seen = {}
         self._merged_auto = None  # decided at the first one-column CG solve on this operator (see _cg_merged)
 
     def solve(self, b, x: Function) -> int:
@@ -239,8 +236,11 @@ class KSPSolver:
         # so check every iteration unless iterations are shorter than two reads.
         key = (nc, meth)
         if key not in self._every:
-            # first solve of this shape: an estimate from the matrix size (bytes per iteration at ~4 TB/s + launch
-            # latencies); replaced after the solve by what an iteration really took (below)
+            # from the matrix size alone (bytes per iteration at ~4 TB/s + launch latencies), NOT from a measured time:
+            # with several columns the interval decides at which iteration a solve narrows to its last live column,
+            # the 1-column kernels sum their dot products in another order than the NC-column ones, and a schedule
+            # that followed timing noise made the last bits of a step differ from run to run (round 4: seen as 1e-15
+            # differences between identical runs at sizes where an iteration takes about the 60 us of the threshold)
             t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6
             self._every[key] = self._check_interval(nc, t_iter)
         every = self.check_every or self._every[key]
@@ -248,7 +248,6 @@ class KSPSolver:
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
         dcode = getattr(self, "_dcode", None)
-        t_start = time.perf_counter()
         _lib.check(lib.ox_ksp_solve_dc(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
                                        max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
                                        int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
@@ -259,21 +258,6 @@ class KSPSolver:
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
             _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")
         self.last_result = res
-        # The call blocks until the state is back on the host: wall time = solve time.  The FIRST solve of a shape also
-        # pays one-time costs (code-object load of the kernel templates, pinned-memory and event creation, first touch
-        # of the workspace) and keeps the analytic estimate; the interval is set from the fastest of the next two
-        # solves with at least four iterations, then stays fixed (a launch schedule must not follow timing noise).
-        # Iteration counts are global quantities: on partitioned operators every rank takes the same branch.
-        seen = self._every_seen.setdefault(key, [0, None])
-        if seen[0] < 3:
-            its = max(int(res.its[c]) for c in range(nc))
-            if its >= 4:
-                seen[0] += 1
-                if seen[0] > 1:
-                    t_it = (time.perf_counter() - t_start) / its
-                    seen[1] = t_it if seen[1] is None else min(seen[1], t_it)
-                if seen[0] == 3:
-                    self._every[key] = self._check_interval(nc, seen[1])
         reasons = [int(res.reason[c]) for c in range(nc)]
         if direct:
             reasons = [_lib.CONVERGED_ITS if r > 0 else r for r in reasons]

@@ -17,6 +17,7 @@ from . import ipcs_oracle as O
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LAST_SETUP = None  # (key, (CpuIPCS, x_v, x_q)) of the last box-mesh set-up of run_cpu_baseline
 
 
 PORTABLE_FLAGS = ["-O3", "-fopenmp", "-fPIC", "-shared", "-Wall"]
@@ -362,15 +363,30 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     d = mesh.gdim
     load(native=True)  # built for this host's cores (falls back to the portable in-tree build)
     t0 = time.perf_counter()
+    global _LAST_SETUP
+    key = None
     if isinstance(mesh_def, dict):  # an unstructured mesh is DEFINED by its vertex and cell arrays
         coords = np.ascontiguousarray(mesh_def["coords"], dtype=np.float64)
         cells = np.ascontiguousarray(mesh_def["cells"], dtype=np.int64)
         p0, p1 = mesh_def["lo"], mesh_def["hi"]
     else:
         p0, p1, nn = mesh_def
-        coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
-    cpu, x_v, x_q = from_mesh(coords, cells, Vi.degree, Q.degree, ksp, body_force=S._body_force)
-    del coords, cells
+        key = (tuple(float(v) for v in p0), tuple(float(v) for v in p1), tuple(int(v) for v in nn), Vi.degree, Q.degree,
+               tuple(sorted(ksp.items())), tuple(S._body_force))
+    if key is not None and _LAST_SETUP is not None and _LAST_SETUP[0] == key:
+        # the same mesh definition, spaces and settings as the previous call (bench.py: the headline and the Beltrami leg
+        # share the box): the port's operators are those of that set-up; only the state vectors are new
+        cpu, x_v, x_q = _LAST_SETUP[1]
+        reused = True
+    else:
+        _LAST_SETUP = None  # (release the previous 20 GB before the next set-up)
+        if key is not None:
+            coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
+        cpu, x_v, x_q = from_mesh(coords, cells, Vi.degree, Q.degree, ksp, body_force=S._body_force)
+        del coords, cells
+        reused = False
+        if key is not None:
+            _LAST_SETUP = (key, (cpu, x_v, x_q))
     n, nq = Vi.num_dofs, Q.num_dofs
     lo, hi = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)
     pv = match_by_coordinates(Vi.x[:n].cpu().numpy(), x_v, lo, hi)  # product index of the port's dof k
@@ -394,7 +410,8 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
            "sample": f"1 time step of the same workload (same mesh definition, state, Krylov settings) on the host: "
                      f"oracle/ipcs_cpu.c, OpenMP x{cpu.threads}, CSR, per-component solves as the reference; own "
                      f"dof numbering, patterns and M/K/Ap assembly",
-           "seconds": t_step, "setup_seconds": t_setup, "krylov_iterations": cpu.its, "build_flags": BUILD["flags"]}
+           "seconds": t_step, "setup_seconds": t_setup, "setup_reused": reused, "krylov_iterations": cpu.its,
+           "build_flags": BUILD["flags"]}
     if gpu_step is not None:
         clock["t"] -= dt
         gpu_step()
