@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--cg-merged", default=None, choices=["true", "false"],
                     help="force the merged-reduction CG (OX_KSP_CG_MERGED: one synchronisation point, three kernels per "
                          "iteration) for the one-column pressure solve")
+    ap.add_argument("--cg-fold-blocks", type=int, default=None,
+                    help="blocks of the folded one-column CG update kernels (ox_ksp_set_fold_blocks: 0 = the five-kernel "
+                         "iteration, default one block per compute unit)")
     ap.add_argument("--cg-single-reduction", default=None, choices=["true", "false"],
                     help="force -ksp_cg_single_reduction for the CG solves (default: true on partitioned operators only)")
     ap.add_argument("--bcgs-merged", default=None, choices=["true", "false"],
@@ -358,6 +361,8 @@ def main():
             so["tentative"]["ksp_bcgs_merged_reduction"] = args.bcgs_merged == "true"
         if args.cg_merged is not None:
             so["pressure"]["ksp_cg_merged_reduction"] = args.cg_merged == "true"
+        if args.cg_fold_blocks is not None:
+            _lib.load().ox_ksp_set_fold_blocks(int(args.cg_fold_blocks))
         S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                      solver_options=so, options=opts)
         return mesh, S_
@@ -622,11 +627,14 @@ def main():
         spmv = stored_bytes(S._Ap)
         return {"us": us, "bytes_moved": int(spmv + vec), "spmv_bytes": int(spmv), "vector_bytes": int(vec),
                 "gbs": (spmv + vec) / (1e3 * us), "frac_of_hbm_peak": (spmv + vec) / (1e3 * us) / HBM_PEAK_GBS,
-                "kernels_per_iteration": 3 if cg_merged else 5,
-                "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else "standard CG"}
+                "kernels_per_iteration": 3 if (cg_merged or cg_folded) else 5,
+                "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else
+                ("standard CG, both synchronisation points folded into the update kernels (k_cg_update1f / 2f)"
+                 if cg_folded else "standard CG")}
 
     S_main = S
     cg_merged = cg_merged_main = bool(S._solver_p._cg_merged())  # the one-column pressure solve runs OX_KSP_CG_MERGED
+    cg_folded = bool(S._solver_p._cg_folded())
     # (computed now: the variant legs below drop the dictionaries of this solver)
     piter_line = (pressure_iteration_line(phase_ms["pressure_solve"], mean_iterations(its)["pressure"])
                   if phase_ms.get("pressure_solve") else None)

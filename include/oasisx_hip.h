@@ -489,6 +489,12 @@ int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, doubl
  * 110/111 grad vectors, 120 div vector. */
 int ox_set_spmv_variant(int v); /* A/B switch of the SpMV micro-benchmark (tools/spmv_bench.py):
                                    1 = nontemporal matrix loads (default), 0 = plain loads */
+/* One-column CG on one GPU: blocks (of 1024 threads) of the two update kernels that fold the iteration's synchronisation
+ * points into themselves (3 kernels per iteration instead of 5; replaces nothing in the reference: its PETSc KSPCG has the
+ * same two reductions, ksp.py:71-78).  v = 0: the five-kernel form; v = -1: the default (one block per compute unit;
+ * environment OX_CG_FOLD_BLOCKS overrides); v < -1: query only; returns the value in force.  Partitioned operators never fold (their points
+ * carry an all-reduce). */
+int ox_ksp_set_fold_blocks(int v);
 int ox_profile_begin(int max_records, int sample_every); /* time every sample_every-th launch per tag */
 int ox_profile_end(void);
 int ox_profile_get(int tag, long long key, long long *count, double *total_ms); /* key: the matrix's

@@ -225,6 +225,7 @@ SIGNATURES = {
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_window_retile": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
+    "ox_ksp_set_fold_blocks": (_I, [_I]),
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),

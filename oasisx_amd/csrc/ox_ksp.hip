@@ -413,6 +413,206 @@ __global__ __launch_bounds__(256) void k_cg_update2(int64_t n, const KspState *S
   });
 }
 
+// ---------------------------------------------------------------------------------------
+// One-column CG on one GPU with the two synchronisation points FOLDED into the update kernels (round 4).
+// A pressure-CG iteration at 128^3 was five kernels -- mat-vec 31 us, k_ksp_scalar 4.7, k_cg_update1 10.8,
+// k_ksp_scalar 4.7, k_cg_update2 12.9 --: a third of the two scalar kernels' time is the kernel boundary, the rest two
+// dependent round trips of ONE block while 255 CUs idle.  Here every block of the consuming update kernel sums the
+// producer's partial sums itself (same per-thread rows, same block tree as k_ksp_scalar with 1024 threads: the same bits
+// in every block), runs the point's scalar logic on an LDS copy of the state, and goes on to its rows; block 0 stores the
+// new state.  Few large blocks (<= OX_CG_FOLD_BLOCKS x 1024 threads) keep the redundant reads small (8 392 sums x 512
+// blocks = 34 MB of L2 hits; with 2 048 blocks of 256 threads -- the first attempt of the round, profiles/
+// r04_krylov_consumer_fold_experiment.txt -- they cost more than they saved).  The state ping-pongs between two blocks
+// (a block that starts late must not read what block 0 has already written): S -> S2 at the first point, S2 -> S at the
+// second, so that between iterations it is where every other kernel and the host expect it.
+// ---------------------------------------------------------------------------------------
+#define OX_FOLD_T 1024
+#define OX_FOLD_NP 5  // pairs of rows per thread whose operands are requested BEFORE the point's reduction
+// LDS-only barrier: waits for this wave's LDS traffic, not for its outstanding global loads (__syncthreads() fences
+// both, which would park the prefetched operands' latency in front of the reduction instead of behind it)
+__device__ __forceinline__ void ox_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The point itself.  Loads are issued in this order: state, partial sums, dictionary -- and only then (by the caller's
+// `prefetch`) the operands of the thread's rows, so that waiting for the former does not wait for the latter (vector
+// loads return in order).  Every load of the prologue is unconditional (clamped address + select): a load inside a
+// branch makes the compiler wait for ALL outstanding loads where the branches join.
+template <int NVIN, int U, int PH, bool CODE, class Prefetch>
+__device__ __forceinline__ bool ksp_fold_point(const KspState *Sin, KspState *Sout, const double *__restrict__ pin, int npin,
+                                               const KspParams &P, const KspDinv &D, KspState *sh, double *red /* [32] */,
+                                               double *sums /* [2] */, double *dd /* [256] */, Prefetch &&prefetch) {
+  const int T = OX_FOLD_T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const unsigned long long sw = reinterpret_cast<const unsigned long long *>(Sin)[min(tid, KSP_STATE_WORDS - 1)];
+  double t[U][NVIN];  // thread t takes rows t, t + T, ...: the order k_ksp_scalar sums in
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int p = tid + u * T;
+    const int pc = min(p, npin - 1);
+#pragma unroll
+    for (int i = 0; i < NVIN; ++i) {
+      const double val = pin[(size_t)pc * NVIN + i];
+      t[u][i] = p < npin ? val : 0.0;
+    }
+  }
+  double dv = 0.0;
+  if constexpr (CODE) dv = D.dict[min(tid, D.n - 1)];
+  prefetch();
+  // (unconditional: a load used only inside a branch is sunk into it, behind the prefetch; the surplus threads rewrite
+  // the last word with its own value)
+  reinterpret_cast<unsigned long long *>(sh)[min(tid, KSP_STATE_WORDS - 1)] = sw;
+  if constexpr (CODE) dd[min(tid, D.n - 1)] = dv;  // (same reason)
+  double v[2] = {0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int i = 0; i < NVIN; ++i) v[i] += t[u][i];
+  if (npin > U * T) {  // (more than U x 1024 sums: not on this path's sizes)
+    for (int p = tid + U * T; p < npin; p += T)
+#pragma unroll
+      for (int i = 0; i < NVIN; ++i) v[i] += pin[(size_t)p * NVIN + i];
+  }
+#pragma unroll
+  for (int i = 0; i < NVIN; ++i) {
+    const double s = ox_wave_sum(v[i]);
+    if (lane == 0) red[i * 16 + wave] = s;
+  }
+  ox_lds_barrier();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NVIN; ++i) {
+      double s = lane < nw ? red[i * 16 + lane] : 0.0;
+      s += __shfl_down(s, 8, 64);
+      s += __shfl_down(s, 4, 64);
+      s += __shfl_down(s, 2, 64);
+      s += __shfl_down(s, 1, 64);
+      v[i] = s;
+    }
+    if (tid == 0 && !sh->done) {
+      sums[0] = v[0];
+      sums[1] = v[1];
+      for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(sh, sums, c, P);
+      ksp_finish(sh, P.nc_total);
+    }
+  }
+  ox_lds_barrier();
+  // (a state that arrived `done` is handed on unchanged -- the logic above did not run --; the host's copy is still due)
+  if (blockIdx.x == 0) {
+    ksp_state_store(Sout, sh);
+    if (P.mirror) ksp_state_store(P.mirror, sh);
+  }
+  return !sh->done;
+}
+
+// first point {p.q} -> alpha;  r -= alpha q;  z = D^-1 r (not stored);  partial = {r.z, z.z}   (k_cg_update1<1>)
+// (n >= 2: the prefetch reads clamped addresses)
+template <bool CODE>
+__global__ __launch_bounds__(OX_FOLD_T) void k_cg_update1f(int64_t n, const KspState *Sin, KspState *Sout,
+                                                           const double *__restrict__ pin, int npin, KspParams P,
+                                                           double *vr, const double *__restrict__ vq, KspDinv D,
+                                                           double *pout) {
+  __shared__ double red[32], sums[2], dd[256];
+  __shared__ KspState sh;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * OX_FOLD_T, i0 = (int64_t)blockIdx.x * OX_FOLD_T + threadIdx.x;
+  double2 qq[OX_FOLD_NP], rr[OX_FOLD_NP], dq[OX_FOLD_NP];
+  unsigned short cq[OX_FOLD_NP];
+  const bool live = ksp_fold_point<1, 10, PH_CG_A, CODE>(Sin, Sout, pin, npin, P, D, &sh, red, sums, dd, [&]() {
+#pragma unroll
+    for (int j = 0; j < OX_FOLD_NP; ++j) {
+      const int64_t iw = i0 + j * stride;
+      const int64_t i = iw < n2 ? iw : min(i0, n2 - 1);  // (surplus: the thread's own first pair again, not ONE hot address)
+      qq[j] = *reinterpret_cast<const double2 *>(vq + 2 * i);
+      rr[j] = *reinterpret_cast<const double2 *>(vr + 2 * i);
+      if constexpr (CODE) cq[j] = *reinterpret_cast<const unsigned short *>(D.code + 2 * i);
+      else dq[j] = *reinterpret_cast<const double2 *>(D.v + 2 * i);
+    }
+  });
+  if (!live) return;  // (uniform)
+  const double alpha = sh.alpha[P.c0];
+  double s[2] = {0.0, 0.0};
+  auto rows = [&](int64_t e, const double2 q2, double2 r, const double d0, const double d1) {
+    r.x = fma(-alpha, q2.x, r.x);
+    r.y = fma(-alpha, q2.y, r.y);
+    const double z0 = d0 * r.x, z1 = d1 * r.y;
+    *reinterpret_cast<double2 *>(vr + e) = r;
+    s[0] = fma(r.x, z0, s[0]);
+    s[1] = fma(z0, z0, s[1]);
+    s[0] = fma(r.y, z1, s[0]);
+    s[1] = fma(z1, z1, s[1]);
+  };
+#pragma unroll
+  for (int j = 0; j < OX_FOLD_NP; ++j) {
+    const int64_t i = i0 + j * stride;
+    if (i < n2) rows(2 * i, qq[j], rr[j], CODE ? dd[cq[j] & 0xff] : dq[j].x, CODE ? dd[cq[j] >> 8] : dq[j].y);
+  }
+  for (int64_t i = i0 + OX_FOLD_NP * stride; i < n2; i += stride) {
+    const int64_t e = 2 * i;
+    rows(e, *reinterpret_cast<const double2 *>(vq + e), *reinterpret_cast<const double2 *>(vr + e), KSP_DINV(e), KSP_DINV(e + 1));
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t e = n - 1;
+    const double r = fma(-alpha, vq[e], vr[e]), z = KSP_DINV(e) * r;
+    vr[e] = r;
+    s[0] = fma(r, z, s[0]);
+    s[1] = fma(z, z, s[1]);
+  }
+  __syncthreads();  // (red is reused)
+  ksp_block_sum_t<2>(s, 2, red);
+  if (threadIdx.x == 0) {
+    pout[(size_t)blockIdx.x * 2] = s[0];
+    pout[(size_t)blockIdx.x * 2 + 1] = s[1];
+  }
+}
+
+// second point {r.z, z.z} -> convergence test, beta;  x += alpha p;  p = D^-1 r + beta p   (k_cg_update2<1>; when the
+// test ends the solve the rows are left alone and the host runs k_cg_update2<1> with `finish` set, as in the unfolded form)
+template <bool CODE>
+__global__ __launch_bounds__(OX_FOLD_T) void k_cg_update2f(int64_t n, const KspState *Sin, KspState *Sout,
+                                                           const double *__restrict__ pin, int npin, KspParams P,
+                                                           double *x, const double *__restrict__ vr, KspDinv D, double *vp) {
+  __shared__ double red[32], sums[2], dd[256];
+  __shared__ KspState sh;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * OX_FOLD_T, i0 = (int64_t)blockIdx.x * OX_FOLD_T + threadIdx.x;
+  double2 rr[OX_FOLD_NP], pp[OX_FOLD_NP], xx[OX_FOLD_NP], dq[OX_FOLD_NP];
+  unsigned short cq[OX_FOLD_NP];
+  const bool live = ksp_fold_point<2, 1, PH_CG_B, CODE>(Sin, Sout, pin, npin, P, D, &sh, red, sums, dd, [&]() {
+#pragma unroll
+    for (int j = 0; j < OX_FOLD_NP; ++j) {
+      const int64_t iw = i0 + j * stride;
+      const int64_t i = iw < n2 ? iw : min(i0, n2 - 1);  // (surplus: the thread's own first pair again, not ONE hot address)
+      rr[j] = *reinterpret_cast<const double2 *>(vr + 2 * i);
+      pp[j] = *reinterpret_cast<const double2 *>(vp + 2 * i);
+      xx[j] = *reinterpret_cast<const double2 *>(x + 2 * i);
+      if constexpr (CODE) cq[j] = *reinterpret_cast<const unsigned short *>(D.code + 2 * i);
+      else dq[j] = *reinterpret_cast<const double2 *>(D.v + 2 * i);
+    }
+  });
+  if (!live) return;
+  const double alpha = sh.alpha[P.c0], beta = sh.beta[P.c0];
+  auto rows = [&](int64_t e, const double2 r, double2 p, double2 xv, const double d0, const double d1) {
+    xv.x = fma(alpha, p.x, xv.x);
+    xv.y = fma(alpha, p.y, xv.y);
+    p.x = fma(beta, p.x, d0 * r.x);
+    p.y = fma(beta, p.y, d1 * r.y);
+    *reinterpret_cast<double2 *>(x + e) = xv;
+    *reinterpret_cast<double2 *>(vp + e) = p;
+  };
+#pragma unroll
+  for (int j = 0; j < OX_FOLD_NP; ++j) {
+    const int64_t i = i0 + j * stride;
+    if (i < n2) rows(2 * i, rr[j], pp[j], xx[j], CODE ? dd[cq[j] & 0xff] : dq[j].x, CODE ? dd[cq[j] >> 8] : dq[j].y);
+  }
+  for (int64_t i = i0 + OX_FOLD_NP * stride; i < n2; i += stride) {
+    const int64_t e = 2 * i;
+    rows(e, *reinterpret_cast<const double2 *>(vr + e), *reinterpret_cast<const double2 *>(vp + e),
+         *reinterpret_cast<const double2 *>(x + e), KSP_DINV(e), KSP_DINV(e + 1));
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t e = n - 1;
+    const double pe = vp[e];
+    x[e] = fma(alpha, pe, x[e]);
+    vp[e] = fma(beta, pe, KSP_DINV(e) * vr[e]);
+  }
+}
+
 // Merged-reduction CG, the ONE vector kernel of an iteration (alpha and beta are both known behind the mat-vec's
 // synchronisation point, PH_CGM_IT):  x += alpha p;  r -= alpha q;  z = D^-1 r (not stored);  p = z + beta p;
 // partial = {r.z, z.z, p.q} -- the true sums, which replace the carried r.z / serve the convergence test at the next
@@ -748,7 +948,7 @@ __global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ pa
 static inline int ksp_prered_rows(int nparts) { return (nparts + OX_PRERED_CHUNK - 1) / OX_PRERED_CHUNK; }
 
 struct KspLayout {
-  size_t state, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
+  size_t state, state2, sums, partial, partial2, vec0, vec_stride, narrow0, narrow_stride, total;
   int nvec, nparts_max;
 };
 
@@ -760,7 +960,8 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
   L.nvec = (ksp_type == OX_KSP_CG || ksp_type == OX_KSP_CG_MERGED) ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);  // (both BiCGStab variants: 6)
   L.state = 0;
-  L.sums = ox_align(sizeof(KspState));
+  L.state2 = ox_align(sizeof(KspState));  // (folded CG: the state ping-pongs between the two points of an iteration)
+  L.sums = 2 * ox_align(sizeof(KspState));
   // sums, then the pre-reduction scratch of both partial arrays of a synchronisation point
   L.partial = L.sums + ox_align(sizeof(double) * (OX_PRERED_OFFSET + 2 * (size_t)(ksp_prered_rows(L.nparts_max) + 1) * OX_MAX_NV));
   L.partial2 = L.partial + ox_align(sizeof(double) * (size_t)L.nparts_max * 5 * OX_MAXC);
@@ -858,7 +1059,7 @@ struct KspCtx {
   const ox_sell *A;
   const double *dinv;
   KspDinv D;  // dinv again, with its value dictionary where the caller has one (CG update kernels)
-  KspState *S;
+  KspState *S, *S2;
   double *sums, *partial, *partial2;
   const ox_dist *dist;
   hipStream_t st;
@@ -870,10 +1071,64 @@ struct KspCtx {
     if (ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st)) return -1;       \
   } while (0)
 
+// blocks of the folded CG update kernels (0: the five-kernel form); OX_CG_FOLD_BLOCKS overrides (tuning)
+static int g_fold_blocks = -1;
+static int ksp_fold_blocks() {
+  if (g_fold_blocks < 0) {
+    // ONE block per compute unit: a CU that receives a second 1024-thread block takes twice as long as the others
+    // (128^3 pressure: 256 blocks 59.1 us per iteration, 262 blocks 66.0, 512 blocks 65.8, 128 blocks 62.5)
+    hipDeviceProp_t prop;
+    int dev = 0;
+    int ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    const char *e = getenv("OX_CG_FOLD_BLOCKS");
+    int v = e ? atoi(e) : ncu;
+    if (v > OX_FOLD_T) v = OX_FOLD_T;  // (the second point reads one partial row per thread)
+    if (v < 0) v = 0;
+    g_fold_blocks = v;
+  }
+  return g_fold_blocks;
+}
+extern "C" int ox_ksp_set_fold_blocks(int v) {
+  if (v >= -1) g_fold_blocks = v < 0 ? -1 : (v > OX_FOLD_T ? OX_FOLD_T : v);  // (v < -1: query only)
+  return ksp_fold_blocks();
+}
 template <int NC>
 static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
+  if (NC == 1 && !C.dist && n >= 2 && ksp_fold_blocks() > 0) {  // one column, one GPU: both points folded into the update kernels
+    int64_t want = ((n >> 1) + OX_FOLD_T - 1) / OX_FOLD_T;
+    if (want < 1) want = 1;
+    const int nbf = (int)(want < ksp_fold_blocks() ? want : ksp_fold_blocks());
+    const int nbs1 = ox_spmv_dist_nparts(C.A, nullptr, 1);  // (block sums of the ONE-column mat-vec)
+    for (int k = 0; k < count; ++k) {
+      if (ox_spmv_dist(C.A, V.p, V.q, 1, OX_EPI_DOT, nullptr, nullptr, C.partial, done, nullptr, C.st)) return -1;
+      const double *pin = C.partial;
+      int npin = nbs1;
+      if (npin >= OX_PRERED_MIN) {  // (a 17 M-row mass matrix: 66 K block sums)
+        double *scr = C.sums + OX_PRERED_OFFSET;
+        const int g = ksp_prered_rows(npin);
+        hipLaunchKernelGGL(k_prereduce, dim3(g), dim3(256), 0, C.st, pin, npin, 1, scr);
+        pin = scr;
+        npin = g;
+      }
+      if (C.D.code) {
+        hipLaunchKernelGGL(k_cg_update1f<true>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, C.S, C.S2, pin, npin, P, V.r, V.q,
+                           C.D, C.partial2);
+        hipLaunchKernelGGL(k_cg_update2f<true>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, C.S2, C.S, C.partial2, nbf,
+                           ksp_last_point(P, k, count), V.x, V.r, C.D, V.p);
+      } else {
+        hipLaunchKernelGGL(k_cg_update1f<false>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, C.S, C.S2, pin, npin, P, V.r, V.q,
+                           C.D, C.partial2);
+        hipLaunchKernelGGL(k_cg_update2f<false>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, C.S2, C.S, C.partial2, nbf,
+                           ksp_last_point(P, k, count), V.x, V.r, C.D, V.p);
+      }
+      OX_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   for (int k = 0; k < count; ++k) {
     if (ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_DOT, nullptr, nullptr, C.partial, done, C.dist, C.st)) return -1;
     KSP_SYNC(PH_CG_A, C.partial, C.nbs, NC);
@@ -1041,6 +1296,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.dinv = dinv;
   C.D = Dc;
   C.S = reinterpret_cast<KspState *>(work + L.state);
+  C.S2 = reinterpret_cast<KspState *>(work + L.state2);
   C.sums = reinterpret_cast<double *>(work + L.sums);
   C.partial = reinterpret_cast<double *>(work + L.partial);
   C.partial2 = reinterpret_cast<double *>(work + L.partial2);

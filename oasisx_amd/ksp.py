@@ -187,6 +187,15 @@ class KSPSolver:
             self._merged_auto = rows <= CG_MERGED_MAX_ROWS
         return self._merged_auto
 
+    def _cg_folded(self) -> bool:
+        """One-column standard CG on one GPU: the iteration's two synchronisation points are folded into the update
+        kernels (3 kernels per iteration: csrc/ox_ksp.hip k_cg_update1f / k_cg_update2f; ``ox_ksp_set_fold_blocks``).
+        Partitioned operators never fold: their points carry an all-reduce."""
+        if self._A is None or self._A.pattern.dist is not None:
+            return False
+        return (self._method()[0] == _lib.KSP_CG and not self._cg_merged()
+                and int(_lib.load().ox_ksp_set_fold_blocks(-2)) > 0)
+
     def solve_block(self, B: FieldStorage, X: FieldStorage, ax0: FieldStorage | None = None):
         """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
         Returns the list of per-component converged reasons.  ``ax0``: the product A X of the initial

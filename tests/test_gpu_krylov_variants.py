@@ -333,3 +333,70 @@ def test_identical_runs_give_identical_bits_and_the_launch_schedule_does_not_fol
             ref = got
         else:
             assert got[2] == ref[2] and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), run
+
+
+@pytest.mark.parametrize("dim,N,deg,nc,dictionary", [(2, 24, 2, 1, False), (2, 25, 1, 1, False), (3, 16, 1, 1, True),
+                                                     (3, 8, 2, 3, False), (2, 1, 1, 1, False), (3, 12, 1, 2, True)])
+def test_folded_cg_matches_the_five_kernel_iteration_and_oracle(hip, dim, N, deg, nc, dictionary):
+    """Round 4: one-column CG on one GPU runs its two synchronisation points inside the update kernels
+    (k_cg_update1f / k_cg_update2f, 3 kernels per iteration; ``ox_ksp_set_fold_blocks``).  Against the five-kernel form
+    (fold off) and the oracle's PETSc-convention CG: same converged reasons, iteration counts within 1, solutions to
+    solver tolerance; odd and even row counts (the pair loop's tail), a 4-row system, a value dictionary of the diagonal
+    (1-byte codes in the update kernels), several columns (the folded kernels serve the narrowed tail of the lock-step
+    solve), a right-hand side that needs no iteration, a solve cut by max_it, and block counts from 1 to many."""
+    from oasisx_amd import _lib
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oracle import ipcs_oracle as O
+
+    lib = _lib.load()
+    V, A, Acsr = _system(dim, N, deg, mass=3.0)
+    if dictionary:
+        A.freeze()
+    n = V.num_dofs
+    x = V.x.cpu().numpy()
+    cols = [np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1]), 1e-3 * np.sin(5.0 * x[:, 0] * x[:, -1]), np.exp(x[:, 1])][:nc]
+    B = FieldStorage(n, nc, "cuda")
+    B.dev()[:] = torch.from_numpy(np.stack(cols, axis=1)).cuda()
+    default_blocks = lib.ox_ksp_set_fold_blocks(-1)
+    assert default_blocks > 0 and lib.ox_ksp_set_fold_blocks(-2) == default_blocks
+    out = {}
+    try:
+        for blocks in (0, 1, 7, default_blocks, 1024):
+            assert lib.ox_ksp_set_fold_blocks(blocks) == blocks
+            ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
+                                   "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False})
+            ksp.setOperators(A)
+            assert ksp._cg_folded() == (blocks > 0)
+            X = FieldStorage(n, nc, "cuda")
+            reasons = ksp.solve_block(B, X)
+            sol = X.dev().cpu().numpy().copy()
+            its = list(ksp.iterations[:nc])
+            # the solution as the right-hand side's answer: a second solve from it needs no iteration
+            ksp2 = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-6, "ksp_atol": 1e-50,
+                                    "ksp_initial_guess_nonzero": True, "ksp_cg_single_reduction": False,
+                                    "ksp_cg_merged_reduction": False})
+            ksp2.setOperators(A)
+            r2 = ksp2.solve_block(B, X)
+            assert all(r == 2 for r in r2) and list(ksp2.iterations[:nc]) == [0] * nc
+            assert np.array_equal(X.dev().cpu().numpy(), sol)  # untouched
+            # cut by max_it: reason -3 after exactly that many iterations
+            ksp3 = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-30, "ksp_atol": 1e-300,
+                                    "ksp_max_it": 3, "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False})
+            ksp3.setOperators(A)
+            X3 = FieldStorage(n, nc, "cuda")
+            r3 = ksp3.solve_block(B, X3)
+            out[blocks] = (sol, its, reasons, X3.dev().cpu().numpy().copy(), list(r3), list(ksp3.iterations[:nc]))
+    finally:
+        lib.ox_ksp_set_fold_blocks(-1)
+    ref = out[0]
+    for c in range(nc):
+        sol, reason, its, _ = O.jacobi_cg(Acsr, cols[c], rtol=1e-10, atol=1e-50)
+        for blocks, (xs, it, rs, x3, r3, it3) in out.items():
+            assert rs[c] == reason == 2, (blocks, rs)
+            assert abs(it[c] - its) <= 1 and abs(it[c] - ref[1][c]) <= 1, (blocks, it, its, ref[1])
+            assert np.abs(xs[:, c] - sol).max() < 1e-8 * max(np.abs(sol).max(), 1.0)
+            if n > 4:  # (a 4-row system is solved exactly within 3 iterations)
+                assert r3[c] == -3 and it3[c] == 3, (blocks, r3, it3)
+            # three iterations of the same recurrences: the same iterate up to the rounding of the dot products
+            assert np.abs(x3[:, c] - ref[3][:, c]).max() <= 1e-12 * max(np.abs(ref[3][:, c]).max(), 1e-300)
