@@ -465,10 +465,10 @@ def main():
                     lambda X, t: np.stack([np.asarray(f(X, t), dtype=np.float64) for f in W2["fns"]]), gpu_step=one,
                     mesh_def=((q0, q1, [N, N, N]) if delaunay is None else
                               {"coords": m2.coords.cpu().numpy(), "cells": m2.cells.cpu().numpy(), "lo": q0, "hi": q1}),
-                    threads_1=False, scipy_check=False)
+                    threads_1=False, scipy_check=False, reuse_setup=True)
                 res["cpu_cross_check"] = {k: chk[k] for k in (
                     "gpu_vs_cpu_rel_l2_u", "gpu_vs_cpu_rel_l2_p", "gpu_vs_cpu_max_abs_u", "gpu_vs_cpu_shared", "value", "cores",
-                    "seconds", "setup_seconds", "krylov_iterations", "gpu_krylov_iterations") if k in chk}
+                    "seconds", "setup_seconds", "setup_reused", "krylov_iterations", "gpu_krylov_iterations") if k in chk}
                 res["cpu_cross_check"]["step"] = warmup + steps + 1
             except Exception as e:
                 res["cpu_cross_check"] = {"error": repr(e)}
@@ -905,7 +905,7 @@ def main():
                     gpu_step=step,
                     mesh_def=((p0, p1, [N, N, N]) if args.mesh == "box" else
                               {"coords": mesh.coords.cpu().numpy(), "cells": mesh.cells.cpu().numpy(), "lo": p0, "hi": p1}),
-                    threads_1=not args.no_cpu_one_core)
+                    threads_1=not args.no_cpu_one_core, reuse_setup=True)
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}

@@ -346,7 +346,7 @@ def sell_to_csr_host(pattern, vals_list):
 
 
 def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_def=None, threads_1=True,
-                     scipy_check=True):
+                     scipy_check=True, reuse_setup=False):
     """Time ONE step of the same workload on the host cores with the C/OpenMP port and compare it
     with the GPU's step from the same state.
 
@@ -357,6 +357,8 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     (u, u1, u2, p, dp), which are carried over through the dof COORDINATES.  The relative L2
     difference of the two results after the step is therefore a full-size check of assembly, step
     algebra and solvers with no shared dof map.  ``bc_values_at(X, t)`` -> (d, npts) Dirichlet values.
+    ``reuse_setup``: keep the port's set-up (20 GB of host memory at 128^3) for a following call with the same box mesh,
+    spaces and settings.
     """
     Vi, Q = S._Vi[0][0], S._Q
     mesh = S._mesh
@@ -373,6 +375,8 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
         p0, p1, nn = mesh_def
         key = (tuple(float(v) for v in p0), tuple(float(v) for v in p1), tuple(int(v) for v in nn), Vi.degree, Q.degree,
                tuple(sorted(ksp.items())), tuple(S._body_force))
+    if not reuse_setup:  # (bench.py opts in: its legs follow one another on the same box; nothing is kept otherwise)
+        key, _LAST_SETUP = None, None
     if key is not None and _LAST_SETUP is not None and _LAST_SETUP[0] == key:
         # the same mesh definition, spaces and settings as the previous call (bench.py: the headline and the Beltrami leg
         # share the box): the port's operators are those of that set-up; only the state vectors are new
