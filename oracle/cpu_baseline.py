@@ -384,7 +384,7 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
         reused = True
     else:
         _LAST_SETUP = None  # (release the previous 20 GB before the next set-up)
-        if key is not None:
+        if not isinstance(mesh_def, dict):
             coords, cells = (O.create_box_mesh(p0, p1, nn) if d == 3 else O.create_rectangle_mesh(p0, p1, nn))
         cpu, x_v, x_q = from_mesh(coords, cells, Vi.degree, Q.degree, ksp, body_force=S._body_force)
         del coords, cells
