@@ -627,7 +627,7 @@ def main():
         spmv = stored_bytes(S._Ap)
         return {"us": us, "bytes_moved": int(spmv + vec), "spmv_bytes": int(spmv), "vector_bytes": int(vec),
                 "gbs": (spmv + vec) / (1e3 * us), "frac_of_hbm_peak": (spmv + vec) / (1e3 * us) / HBM_PEAK_GBS,
-                "kernels_per_iteration": 3 if (cg_merged or cg_folded) else 5,
+                "kernels_per_iteration": int(S._solver_p._cg_kernels_per_iteration()),
                 "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else
                 ("standard CG, both synchronisation points folded into the update kernels (k_cg_update1f / 2f)"
                  if cg_folded else "standard CG")}

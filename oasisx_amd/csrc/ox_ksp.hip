@@ -1143,10 +1143,203 @@ static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, 
 
 // Merged-reduction CG: mat-vec with the three-sum epilogue, ONE synchronisation point (one all-reduce of
 // {p.q, q.D^-1 q, r.z, z.z, p.q_old} in a partitioned run), one update kernel -- 3 kernels per iteration instead of 5.
+// ---------------------------------------------------------------------------------------
+// Merged-reduction CG with its ONE synchronisation point folded into the update kernel: 2 kernels per iteration
+// (mat-vec with the two-sum epilogue, k_cgm_updatef).  Same construction as k_cg_update1f / 2f above: every block sums
+// the mat-vec's partial sums {p.q, q.D^-1 q} and the previous update's {r.z, z.z, p.q_old}, thread 0 runs PH_CGM_IT on
+// an LDS copy of the state, block 0 stores it -- into the OTHER state block: the state alternates S / S2 from one
+// iteration to the next, so batches are even; the update's own partial sums alternate between two arrays likewise
+// (a block reads the previous iteration's while others already write this one's).
+// ---------------------------------------------------------------------------------------
+#define OX_FOLDM_NP 2  // (the merged form is the default up to 2^20 rows: at most two pairs per thread)
+template <bool CODE>
+__global__ __launch_bounds__(OX_FOLD_T) void k_cgm_updatef(int64_t n, const KspState *Sin, KspState *Sout,
+                                                           const double *__restrict__ pinA, int npinA,
+                                                           const double *__restrict__ pinB, int npinB, KspParams P,
+                                                           double *x, double *vr, const double *__restrict__ vq, KspDinv D,
+                                                           double *vp, double *pout) {
+  __shared__ double red[16 * 5], sums[5], dd[256];
+  __shared__ KspState sh;
+  const int T = OX_FOLD_T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * OX_FOLD_T, i0 = (int64_t)blockIdx.x * OX_FOLD_T + tid;
+  // ---- the point: state, partial sums, dictionary requested first (unconditional, clamped), then the rows' operands
+  const unsigned long long sw = reinterpret_cast<const unsigned long long *>(Sin)[min(tid, KSP_STATE_WORDS - 1)];
+  double2 tA[10];
+#pragma unroll
+  for (int u = 0; u < 10; ++u) tA[u] = *reinterpret_cast<const double2 *>(pinA + 2 * (size_t)min(tid + u * T, npinA - 1));
+  double tB[3];
+  {
+    const int pc = min(tid, max(npinB, 1) - 1);  // (npinB = 0 at the first point of a solve: the array is there, unread)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tB[i] = pinB[(size_t)pc * 3 + i];
+  }
+  double dv = 0.0;
+  if constexpr (CODE) dv = D.dict[min(tid, D.n - 1)];
+  double2 qq[OX_FOLDM_NP], rr[OX_FOLDM_NP], pp[OX_FOLDM_NP], xx[OX_FOLDM_NP], dq[OX_FOLDM_NP];
+  unsigned short cq[OX_FOLDM_NP];
+#pragma unroll
+  for (int j = 0; j < OX_FOLDM_NP; ++j) {
+    const int64_t iw = i0 + j * stride;
+    const int64_t i = iw < n2 ? iw : min(i0, n2 - 1);
+    qq[j] = *reinterpret_cast<const double2 *>(vq + 2 * i);
+    rr[j] = *reinterpret_cast<const double2 *>(vr + 2 * i);
+    pp[j] = *reinterpret_cast<const double2 *>(vp + 2 * i);
+    xx[j] = *reinterpret_cast<const double2 *>(x + 2 * i);
+    if constexpr (CODE) cq[j] = *reinterpret_cast<const unsigned short *>(D.code + 2 * i);
+    else dq[j] = *reinterpret_cast<const double2 *>(D.v + 2 * i);
+  }
+  // (a fence the compiler cannot schedule across: every load above is issued before it -- "memory" --, and every use of
+  // the point's operands depends on its outputs; left alone the selects and sums below were hoisted in front of the
+  // rows' loads, which then waited behind the partial sums' round trip)
+  int na = npinA, nb = npinB;
+  asm volatile("" : "+s"(na), "+s"(nb) : : "memory");
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const bool in = tid + u * T < na;
+    tA[u].x = in ? tA[u].x : 0.0;
+    tA[u].y = in ? tA[u].y : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tB[i] = tid < nb ? tB[i] : 0.0;
+  reinterpret_cast<unsigned long long *>(&sh)[min(tid, KSP_STATE_WORDS - 1)] = sw;
+  if constexpr (CODE) dd[min(tid, D.n - 1)] = dv;
+  double v[5] = {0.0, 0.0, tB[0], tB[1], tB[2]};
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    v[0] += tA[u].x;
+    v[1] += tA[u].y;
+  }
+  if (na > 10 * T) {
+    for (int p = tid + 10 * T; p < na; p += T) {
+      v[0] += pinA[2 * (size_t)p];
+      v[1] += pinA[2 * (size_t)p + 1];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double sv = ox_wave_sum(v[i]);
+    if (lane == 0) red[i * 16 + wave] = sv;
+  }
+  ox_lds_barrier();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      double sv = lane < nw ? red[i * 16 + lane] : 0.0;
+      sv += __shfl_down(sv, 8, 64);
+      sv += __shfl_down(sv, 4, 64);
+      sv += __shfl_down(sv, 2, 64);
+      sv += __shfl_down(sv, 1, 64);
+      v[i] = sv;
+    }
+    if (tid == 0 && !sh.done) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) sums[i] = v[i];
+      for (int c = 0; c < P.nc; ++c) ksp_logic<PH_CGM_IT>(&sh, sums, c, P);
+      ksp_finish(&sh, P.nc_total);
+    }
+  }
+  ox_lds_barrier();
+  if (blockIdx.x == 0) {
+    ksp_state_store(Sout, &sh);
+    if (P.mirror) ksp_state_store(P.mirror, &sh);
+  }
+  if (sh.done) return;  // (uniform)
+  // ---- the rows: x += alpha p;  r -= alpha q;  z = D^-1 r;  p = z + beta p;  sums of r.z, z.z, p.q
+  const double alpha = sh.alpha[P.c0], beta = sh.beta[P.c0];
+  double s[3] = {0.0, 0.0, 0.0};
+  auto rows = [&](int64_t e, const double2 q2, double2 r, double2 p, double2 xv, const double d0, const double d1) {
+    xv.x = fma(alpha, p.x, xv.x);
+    xv.y = fma(alpha, p.y, xv.y);
+    r.x = fma(-alpha, q2.x, r.x);
+    r.y = fma(-alpha, q2.y, r.y);
+    const double z0 = d0 * r.x, z1 = d1 * r.y;
+    p.x = fma(beta, p.x, z0);
+    p.y = fma(beta, p.y, z1);
+    *reinterpret_cast<double2 *>(x + e) = xv;
+    *reinterpret_cast<double2 *>(vr + e) = r;
+    *reinterpret_cast<double2 *>(vp + e) = p;
+    s[0] = fma(r.x, z0, s[0]);
+    s[1] = fma(z0, z0, s[1]);
+    s[2] = fma(p.x, q2.x, s[2]);
+    s[0] = fma(r.y, z1, s[0]);
+    s[1] = fma(z1, z1, s[1]);
+    s[2] = fma(p.y, q2.y, s[2]);
+  };
+#pragma unroll
+  for (int j = 0; j < OX_FOLDM_NP; ++j) {
+    const int64_t i = i0 + j * stride;
+    if (i < n2) rows(2 * i, qq[j], rr[j], pp[j], xx[j], CODE ? dd[cq[j] & 0xff] : dq[j].x, CODE ? dd[cq[j] >> 8] : dq[j].y);
+  }
+  for (int64_t i = i0 + OX_FOLDM_NP * stride; i < n2; i += stride) {
+    const int64_t e = 2 * i;
+    rows(e, *reinterpret_cast<const double2 *>(vq + e), *reinterpret_cast<const double2 *>(vr + e),
+         *reinterpret_cast<const double2 *>(vp + e), *reinterpret_cast<const double2 *>(x + e), KSP_DINV(e), KSP_DINV(e + 1));
+  }
+  if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+    const int64_t e = n - 1;
+    const double pe = vp[e], qe = vq[e];
+    x[e] = fma(alpha, pe, x[e]);
+    const double r = fma(-alpha, qe, vr[e]), z = KSP_DINV(e) * r;
+    const double pn = fma(beta, pe, z);
+    vr[e] = r;
+    vp[e] = pn;
+    s[0] = fma(r, z, s[0]);
+    s[1] = fma(z, z, s[1]);
+    s[2] = fma(pn, qe, s[2]);
+  }
+  __syncthreads();  // (red is reused)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double sv = ox_wave_sum(s[i]);
+    if (lane == 0) red[i * 16 + wave] = sv;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double sv = lane < nw ? red[i * 16 + lane] : 0.0;
+      sv += __shfl_down(sv, 8, 64);
+      sv += __shfl_down(sv, 4, 64);
+      sv += __shfl_down(sv, 2, 64);
+      sv += __shfl_down(sv, 1, 64);
+      if (lane == 0) pout[(size_t)blockIdx.x * 3 + i] = sv;
+    }
+  }
+}
+
 template <int NC>
 static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
+  if (NC == 1 && !C.dist && n >= 2 && ksp_fold_blocks() > 0 && (count & 1) == 0) {
+    // folded: the state alternates S / S2 per iteration (an even batch leaves it in S, where the host and the next
+    // batch look for it), the update's partial sums between two arrays
+    const int nbs1 = ox_spmv_dist_nparts(C.A, nullptr, 1);
+    if ((int64_t)nbs1 * 2 < OX_PRERED_MIN) {
+      int64_t want = ((n >> 1) + OX_FOLD_T - 1) / OX_FOLD_T;
+      if (want < 1) want = 1;
+      const int nbf = (int)(want < ksp_fold_blocks() ? want : ksp_fold_blocks());
+      double *pu[2] = {C.partial2, C.partial2 + 3 * OX_FOLD_T};
+      for (int k = 0; k < count; ++k) {
+        KspState *Sin = (k & 1) ? C.S2 : C.S, *Sout = (k & 1) ? C.S : C.S2;
+        ox_spmv_set_epilogue_dinv(C.D.code, C.D.dict);
+        const int rc = ox_spmv_dist(C.A, V.p, V.q, 1, OX_EPI_CG_M2, C.dinv, nullptr, C.partial, &Sin->done, nullptr, C.st);
+        ox_spmv_set_epilogue_dinv(nullptr, nullptr);
+        if (rc) return -1;
+        KspParams Q = ksp_last_point(P, k, count);
+        Q.first = (first && k == 0) ? 1 : 0;
+        const int npb = Q.first ? 0 : nbf;
+        if (C.D.code)
+          hipLaunchKernelGGL(k_cgm_updatef<true>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, Sin, Sout, C.partial, nbs1,
+                             pu[(k + 1) & 1], npb, Q, V.x, V.r, V.q, C.D, V.p, pu[k & 1]);
+        else
+          hipLaunchKernelGGL(k_cgm_updatef<false>, dim3(nbf), dim3(OX_FOLD_T), 0, C.st, n, Sin, Sout, C.partial, nbs1,
+                             pu[(k + 1) & 1], npb, Q, V.x, V.r, V.q, C.D, V.p, pu[k & 1]);
+        OX_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   for (int k = 0; k < count; ++k) {
     ox_spmv_set_epilogue_dinv(C.D.code, C.D.dict);
     const int rc = ox_spmv_dist(C.A, V.p, V.q, NC, OX_EPI_CG_M2, C.dinv, nullptr, C.partial, done, C.dist, C.st);

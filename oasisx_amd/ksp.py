@@ -196,6 +196,17 @@ class KSPSolver:
         return (self._method()[0] == _lib.KSP_CG and not self._cg_merged()
                 and int(_lib.load().ox_ksp_set_fold_blocks(-2)) > 0)
 
+    def _cg_kernels_per_iteration(self) -> int:
+        """Kernels of one iteration of a one-column CG solve with this solver (reporting only: bench.py): 5 for the
+        standard recurrences, 3 with their points folded (one GPU), 3 for the merged-reduction form, 2 with its point
+        folded (one GPU, block sums of the mat-vec below the pre-reduction threshold: csrc/ox_ksp.hip cgm_iterations)."""
+        fold = (self._A is not None and self._A.pattern.dist is None
+                and int(_lib.load().ox_ksp_set_fold_blocks(-2)) > 0)
+        if self._A is not None and self._method()[0] == _lib.KSP_CG and self._cg_merged():
+            nbs = (((self._A.pattern.n_slices + 3) // 4) + 7) & ~7
+            return 2 if fold and 2 * nbs < 16384 else 3
+        return 3 if self._cg_folded() else 5
+
     def solve_block(self, B: FieldStorage, X: FieldStorage, ax0: FieldStorage | None = None):
         """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
         Returns the list of per-component converged reasons.  ``ax0``: the product A X of the initial
