@@ -445,17 +445,22 @@ __device__ __forceinline__ bool ksp_fold_point(const KspState *Sin, KspState *So
   double t[U][NVIN];  // thread t takes rows t, t + T, ...: the order k_ksp_scalar sums in
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int p = tid + u * T;
-    const int pc = min(p, npin - 1);
+    const int pc = min(tid + u * T, npin - 1);
 #pragma unroll
-    for (int i = 0; i < NVIN; ++i) {
-      const double val = pin[(size_t)pc * NVIN + i];
-      t[u][i] = p < npin ? val : 0.0;
-    }
+    for (int i = 0; i < NVIN; ++i) t[u][i] = pin[(size_t)pc * NVIN + i];
   }
   double dv = 0.0;
   if constexpr (CODE) dv = D.dict[min(tid, D.n - 1)];
   prefetch();
+  // (a fence the compiler cannot schedule across: every load above is issued before it -- "memory" --, and every use of
+  // the point's operands depends on its output; left alone the selects below were hoisted in front of the rows' loads,
+  // which then waited behind the partial sums' round trip: k_cg_update1f, seen in the ISA)
+  int np_ = npin;
+  asm volatile("" : "+s"(np_) : : "memory");
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int i = 0; i < NVIN; ++i) t[u][i] = tid + u * T < np_ ? t[u][i] : 0.0;
   // (unconditional: a load used only inside a branch is sunk into it, behind the prefetch; the surplus threads rewrite
   // the last word with its own value)
   reinterpret_cast<unsigned long long *>(sh)[min(tid, KSP_STATE_WORDS - 1)] = sw;
@@ -465,8 +470,8 @@ __device__ __forceinline__ bool ksp_fold_point(const KspState *Sin, KspState *So
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int i = 0; i < NVIN; ++i) v[i] += t[u][i];
-  if (npin > U * T) {  // (more than U x 1024 sums: not on this path's sizes)
-    for (int p = tid + U * T; p < npin; p += T)
+  if (np_ > U * T) {  // (more than U x 1024 sums: not on this path's sizes)
+    for (int p = tid + U * T; p < np_; p += T)
 #pragma unroll
       for (int i = 0; i < NVIN; ++i) v[i] += pin[(size_t)p * NVIN + i];
   }
