@@ -109,11 +109,25 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
       const v2h *__restrict__ hp = reinterpret_cast<const v2h *>(A.cols16 + base) + lane;
 #pragma unroll 4
       for (int k = 0; k < npair; ++k) {
+#ifdef OX_DIAG_NOSTREAM
+        // diagnostic (wrong results): no column / code streams at all -- columns are row + a wave-uniform stencil offset,
+        // values dictionary entries picked by k: the upper bound of ANY descriptor-compressed stream
+        double2 v;
+        v.x = dict[(2 * k) & 7];
+        v.y = dict[(2 * k + 1) & 7];
+        const int j0 = 2 * k, j1 = 2 * k + 1;
+        const int64_t d0 = (j0 % 5 - 2) + 257 * ((j0 / 5) % 5 - 2) + 12336 * (j0 / 25 - 1);
+        const int64_t d1 = (j1 % 5 - 2) + 257 * ((j1 / 5) % 5 - 2) + 12336 * (j1 / 25 - 1);
+        const int64_t nn = A.n_cols - 1;
+        mac(v, (int)min(max(row + d0, (int64_t)0), nn), (int)min(max(row + d1, (int64_t)0), nn));
+        (void)hp;
+#else
         const double2 v = load_vals(k);
         const v2h d = __builtin_nontemporal_load(hp + (size_t)k * 64);
         const int2 b = cb[k];
         const int dx = d.x, dy = d.y;
         mac(v, ((dx & 0x8000) ? b.y : b.x) + (dx & 0x7fff), ((dy & 0x8000) ? b.y : b.x) + (dy & 0x7fff));
+#endif
       }
     } else {
       const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(A.cols + base) + lane;
