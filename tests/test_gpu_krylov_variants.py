@@ -400,3 +400,51 @@ def test_folded_cg_matches_the_five_kernel_iteration_and_oracle(hip, dim, N, deg
                 assert r3[c] == -3 and it3[c] == 3, (blocks, r3, it3)
             # three iterations of the same recurrences: the same iterate up to the rounding of the dot products
             assert np.abs(x3[:, c] - ref[3][:, c]).max() <= 1e-12 * max(np.abs(ref[3][:, c]).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dim,N,deg,dictionary", [(2, 24, 2, False), (3, 16, 1, True), (2, 25, 1, False), (2, 1, 1, False)])
+def test_folded_merged_cg_matches_its_three_kernel_form(hip, dim, N, deg, dictionary):
+    """Round 4: the merged-reduction CG with its one synchronisation point inside the update kernel (k_cgm_updatef, 2
+    kernels per iteration; the state alternates between two blocks, so only even batches fold).  Fold on / off, even and
+    odd batch lengths (an odd ``check_every`` takes the three-kernel form), warm start included: same reasons, iteration
+    counts within 1 of each other and of the oracle, solutions to solver tolerance."""
+    from oasisx_amd import _lib
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oracle import ipcs_oracle as O
+
+    lib = _lib.load()
+    V, A, Acsr = _system(dim, N, deg, mass=3.0)
+    if dictionary:
+        A.freeze()
+    n = V.num_dofs
+    x = V.x.cpu().numpy()
+    b = np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1])
+    B = FieldStorage(n, 1, "cuda")
+    B.dev()[:, 0] = torch.from_numpy(b).cuda()
+    sol, reason, its, _ = O.jacobi_cg(Acsr, b, rtol=1e-10, atol=1e-50)
+    out = {}
+    try:
+        for blocks in (0, -1):
+            lib.ox_ksp_set_fold_blocks(blocks)
+            for every in (None, 3, 4):
+                ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
+                                       "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": True})
+                ksp.setOperators(A)
+                ksp.check_every = every
+                assert ksp._cg_merged() and ksp._cg_kernels_per_iteration() == (2 if blocks else 3)
+                X = FieldStorage(n, 1, "cuda")
+                r = ksp.solve_block(B, X)
+                it = ksp.iterations[0]
+                xs = X.dev()[:, 0].cpu().numpy().copy()
+                # a warm start from the solution: nothing left to do, x untouched
+                ksp.updateOptions({"ksp_initial_guess_nonzero": True, "ksp_rtol": 1e-6})
+                r2 = ksp.solve_block(B, X)
+                assert r2[0] == 2 and ksp.iterations[0] == 0 and np.array_equal(X.dev()[:, 0].cpu().numpy(), xs)
+                out[(blocks, every)] = (xs, it, r[0])
+    finally:
+        lib.ox_ksp_set_fold_blocks(-1)
+    for key, (xs, it, r) in out.items():
+        assert r == reason == 2, (key, r)
+        assert abs(it - its) <= 2 and abs(it - out[(0, None)][1]) <= 1, (key, it, its)
+        assert np.abs(xs - sol).max() < 1e-8 * max(np.abs(sol).max(), 1.0)
