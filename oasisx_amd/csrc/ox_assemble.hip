@@ -283,7 +283,13 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
     int32_t dd[U][KIND == OX_KIND_CONV ? ND : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+#ifdef OX_DIAG
+      // (OX_AF_DBG bit 2, diagnostic builds only: every pair reads one of 8 cells' geometry -- L1 hits --: what a
+      // dictionary of the cell geometry could save at most)
+      load_geom<GDIM>(cells.geom + (size_t)((F.dbg & 4) ? (e[u] & 7) : e[u]) * GS, G[u], adet[u]);
+#else
       load_geom<GDIM>(cells.geom + (size_t)e[u] * GS, G[u], adet[u]);
+#endif
       if constexpr (KIND == OX_KIND_CONV) {
 #pragma unroll
         for (int k = 0; k < ND; ++k) dd[u][k] = cell_dofs[(size_t)e[u] * ND + k];
