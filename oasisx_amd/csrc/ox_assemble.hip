@@ -302,7 +302,13 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
 #pragma unroll
         for (int k = 0; k < ND; ++k)
 #pragma unroll
+#ifdef OX_DIAG
+          // (OX_AF_DBG bit 3, diagnostic builds only: the coefficient gathers read 16 fixed dofs -- L1 hits --: what any
+          // staging of uab (an LDS window per slice, a per-cell pre-pass) could save at most)
+          for (int d = 0; d < GDIM; ++d) uc[u][k][d] = F.uab[(size_t)((F.dbg & 8) ? (dd[u][k] & 15) : dd[u][k]) * GDIM + d];
+#else
           for (int d = 0; d < GDIM; ++d) uc[u][k][d] = F.uab[(size_t)dd[u][k] * GDIM + d];
+#endif
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
