@@ -158,3 +158,51 @@ def test_gmsh_reader_refuses_binary_files(tmp_path):
     open(path, "w").write("$MeshFormat\n4.1 1 8\n$EndMeshFormat\n")
     with pytest.raises(ValueError, match="binary"):
         M.read_gmsh(path)
+
+
+MSH22_3D = """$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$Nodes
+5
+1 0 0 0
+2 1 0 0
+3 0 1 0
+4 0 0 1
+5 1 1 1
+$EndNodes
+$Elements
+5
+1 2 2 11 1 1 2 3
+2 2 2 12 2 2 3 5
+3 4 2 20 1 1 2 3 4
+4 4 2 21 2 2 3 4 5
+5 15 2 3 1 1
+$EndElements
+"""
+
+
+def test_gmsh_reader_tetrahedra_with_tagged_triangles(tmp_path):
+    """A 3-D .msh: tetrahedra become the cells (two volume tags), tagged triangles become facet tags on the mesh's own
+    facet numbering (one exterior face of each tetrahedron)."""
+    from oasisx_amd import mesh as M
+
+    path = str(tmp_path / "two_tets.msh")
+    open(path, "w").write(MSH22_3D)
+    mesh, ct, ft = M.read_gmsh(path, device="cpu")
+    assert mesh.gdim == 3 and mesh.num_vertices == 5 and mesh.num_cells == 2
+    assert sorted(ct.values.tolist()) == [20, 21] and ct.dim == 3
+    fv, _ = mesh._entities(2)
+    x = mesh.coords.numpy()
+    assert ft.dim == 2 and sorted(ft.values.tolist()) == [11, 12]
+    f11, f12 = ft.find(11), ft.find(12)
+    assert f11.shape[0] == 1 and f12.shape[0] == 1
+    assert np.allclose(x[fv[f11[0]], 2], 0.0)  # the triangle (1, 2, 3) lies in z = 0
+    assert {tuple(p) for p in x[fv[f12[0]]].tolist()} == {(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 1.0, 1.0)}
+    # volumes: 1/6 and 1/3
+    c = mesh.cells.numpy()
+    vol = np.abs(np.linalg.det(x[c[:, 1:]] - x[c[:, :1]])) / 6.0
+    assert np.allclose(sorted(vol.tolist()), [1.0 / 6.0, 1.0 / 3.0])
+    # a P2 space on it: 5 vertices + 9 edges
+    from oasisx_amd import fem
+    assert fem.functionspace(mesh, ("Lagrange", 2)).num_dofs == 14
