@@ -286,11 +286,19 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
 #ifdef OX_DIAG
       // (OX_AF_DBG bit 2, diagnostic builds only: every pair reads one of 8 cells' geometry -- L1 hits --: what a
       // dictionary of the cell geometry could save at most)
-      load_geom<GDIM>(cells.geom + (size_t)((F.dbg & 4) ? (e[u] & 7) : e[u]) * GS, G[u], adet[u]);
+      load_geom<GDIM>(cells.geom + (size_t)((F.dbg & 32) ? 0 : ((F.dbg & 4) ? (e[u] & 7) : e[u])) * GS, G[u], adet[u]);  // (bit 5: ONE cell: scalar loads)
 #else
       load_geom<GDIM>(cells.geom + (size_t)e[u] * GS, G[u], adet[u]);
 #endif
       if constexpr (KIND == OX_KIND_CONV) {
+#ifdef OX_DIAG
+        // (OX_AF_DBG bit 4, diagnostic builds only: NO cell-dof loads -- the gathers go to dofs e, e + 1, ...; with bit 2
+        // this prices a per-cell pre-pass that hands the pair loop G.u directly: 8 of its ~31 load instructions gone)
+        if (F.dbg & 16) {
+#pragma unroll
+          for (int k = 0; k < ND; ++k) dd[u][k] = e[u] + k;
+        } else
+#endif
 #pragma unroll
         for (int k = 0; k < ND; ++k) dd[u][k] = cell_dofs[(size_t)e[u] * ND + k];
       }
