@@ -113,8 +113,12 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
         // diagnostic (wrong results): no column / code streams at all -- columns are row + a wave-uniform stencil offset,
         // values dictionary entries picked by k: the upper bound of ANY descriptor-compressed stream
         double2 v;
-        v.x = dict[(2 * k) & 7];
-        v.y = dict[(2 * k + 1) & 7];
+        if (VAR & 4) {
+          v.x = dict[(2 * k) & 7];
+          v.y = dict[(2 * k + 1) & 7];
+        } else {
+          v = load_vals(k);  // (an f64-valued matrix keeps its value stream: only the columns are free)
+        }
         const int j0 = 2 * k, j1 = 2 * k + 1;
         const int64_t d0 = (j0 % 5 - 2) + 257 * ((j0 / 5) % 5 - 2) + 12336 * (j0 / 25 - 1);
         const int64_t d1 = (j1 % 5 - 2) + 257 * ((j1 / 5) % 5 - 2) + 12336 * (j1 / 25 - 1);
