@@ -75,7 +75,7 @@ def parse():
                     help="force the merged-reduction CG (OX_KSP_CG_MERGED: one synchronisation point, three kernels per "
                          "iteration) for the one-column pressure solve")
     ap.add_argument("--cg-fold-blocks", type=int, default=None,
-                    help="blocks of the folded one-column CG update kernels (ox_ksp_set_fold_blocks: 0 = the five-kernel "
+                    help="blocks of the folded one-column CG update kernels (solver option ksp_cg_fold_blocks: 0 = the five-kernel "
                          "iteration, default one block per compute unit)")
     ap.add_argument("--cg-single-reduction", default=None, choices=["true", "false"],
                     help="force -ksp_cg_single_reduction for the CG solves (default: true on partitioned operators only)")
@@ -362,7 +362,8 @@ def main():
         if args.cg_merged is not None:
             so["pressure"]["ksp_cg_merged_reduction"] = args.cg_merged == "true"
         if args.cg_fold_blocks is not None:
-            _lib.load().ox_ksp_set_fold_blocks(int(args.cg_fold_blocks))
+            for k in ("pressure", "scalar", "tentative"):
+                so[k]["ksp_cg_fold_blocks"] = int(args.cg_fold_blocks)
         S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
                                      solver_options=so, options=opts)
         return mesh, S_

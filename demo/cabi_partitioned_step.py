@@ -240,8 +240,8 @@ class RankIPCS:
         self.dinvA, self.dinvM, self.dinvP = dev.zeros(self.n_u), dev.zeros(self.n_u), dev.zeros(self.n_q)
         ck(lib.ox_jacobi_setup(C.byref(self.M), self.dinvM, None), "ox_jacobi_setup")
         ck(lib.ox_jacobi_setup(C.byref(self.Ap), self.dinvP, None), "ox_jacobi_setup")
-        wb = max(lib.ox_ksp_work_bytes(self.no_u, self.n_u, d, L.KSP_BCGS), lib.ox_ksp_work_bytes(self.no_u, self.n_u, d, L.KSP_CG),
-                 lib.ox_ksp_work_bytes(self.no_q, self.n_q, 1, L.KSP_CG))
+        wb = max(lib.ox_ksp_work_bytes_for(C.byref(self.A), d, L.KSP_BCGS), lib.ox_ksp_work_bytes_for(C.byref(self.M), d, L.KSP_CG),
+                 lib.ox_ksp_work_bytes_for(C.byref(self.Ap), 1, L.KSP_CG))
         self.work_bytes = int(wb)
         self.work = dev.zeros(wb, np.uint8)
         self.its = {}

@@ -64,11 +64,12 @@ extern "C" {
                               iteration instead of three -- rhat.v behind the first mat-vec; t.t, t.s, rhat.s,
                               rhat.t, s.s behind the second give omega, rho and |r| together (|r| by the
                               recurrence |s - omega t|^2, as PETSc's pipelined / improved BiCGStab variants do).
-                              Same Krylov space; iteration counts within +-2 of OX_KSP_BCGS.  The convergence test
-                              compares the RECURRENCE norm sqrt(max(0, s.s - 2 omega t.s + omega^2 t.t)), not the norm
-                              of the stored residual, and result->rnorm reports that value: near 1e-10..1e-12 relative
-                              it can sit below the true residual norm, so set rtol with that margin (the standard
-                              variant tests the stored residual) */
+                              Same Krylov space; iteration counts within +-2 of OX_KSP_BCGS.  Inside the loop the
+                              convergence test reads the RECURRENCE norm sqrt(max(0, s.s - 2 omega t.s + omega^2 t.t)),
+                              which near 1e-10..1e-12 relative can sit below the norm of the stored residual; once it
+                              reports convergence the solver sums r.r of the STORED residual (one extra reduction per
+                              solve), takes reason and result->rnorm from that -- the test PETSc's KSPBCGS makes
+                              (reference ksp.py:76) -- and, where it fails, re-seeds the shadow residual and carries on */
 
 #define OX_KSP_CG_MERGED 5 /* "cg", one right-hand side, ONE synchronisation point and THREE kernels per iteration instead of
                              two and five: the mat-vec q = A p also sums p.q and q.D^-1 q, from which alpha and -- with
@@ -174,6 +175,8 @@ typedef struct {
   int32_t its[4];            /* per component, iterations taken                          */
   double rnorm[4];           /* per component, final preconditioned residual norm        */
   double bnorm[4];           /* per component, preconditioned norm of b                  */
+  int32_t resumed[4];        /* OX_KSP_BCGS_MERGED: times the column was re-opened because its STORED residual failed
+                                the test its recurrence norm had passed (0 for every other method)  */
 } ox_ksp_result;
 
 /* ---- set-up: mesh -> spaces -> patterns (ox_setup.hip) ----------------------------------
@@ -464,6 +467,32 @@ int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *dinv, const do
                     int check_every, int max_restarts, void *work, size_t work_bytes,
                     ox_ksp_result *result, const ox_dist *dist, void *stream, const double *ax0,
                     const uint8_t *dinv_code, const double *dinv_dict, int n_dinv_dict);
+/* The same with every option of the solve in one block -- PETSc's KSP options (reference ksp.py:38-53 forwards any key to
+ * KSPSetFromOptions) and this library's schedule knobs, per call instead of per process:
+ *   divtol       -ksp_divtol: |D^-1 r| >= divtol |D^-1 b| ends the column with OX_DIVERGED_DTOL (KSPConvergedDefault;
+ *                PETSc's default 1e4 -- "divergence=10000." in -ksp_view); the older entry points run with that default
+ *   fold_blocks  one-column CG on one GPU: blocks of the folded update kernels; 0 = separate synchronisation points
+ *                (five kernels per iteration), -1 = ox_ksp_default_fold_blocks()
+ *   run_ahead    one-column solves queue one batch ahead of the state the host reads: 1 / 0, -1 = default (1)
+ * ox_ksp_options_default fills in PETSc's defaults (rtol 1e-5, atol 1e-50, divtol 1e4, max_it 10000, zero guess). */
+typedef struct {
+  double rtol, atol, divtol;
+  int32_t max_it, nonzero_guess, check_every, max_restarts;
+  int32_t fold_blocks, run_ahead;
+  const double *ax0;         /* see ox_ksp_solve_ax0                                      */
+  const uint8_t *dinv_code;  /* see ox_ksp_solve_dc                                       */
+  const double *dinv_dict;
+  int32_t n_dinv_dict;
+  int32_t reserved;
+} ox_ksp_options;
+int ox_ksp_options_default(ox_ksp_options *opt);
+int ox_ksp_solve_opt(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x, int ncomp,
+                     const ox_ksp_options *opt, void *work, size_t work_bytes, ox_ksp_result *result,
+                     const ox_dist *dist, void *stream);
+/* Workspace of a solve on THIS operator: ox_ksp_work_bytes sizes the partial-sum arrays for the lane = row grid; an
+ * operator that carries an LDS-window stream may launch more blocks than that (one per window block).  Callers with the
+ * ox_sell at hand use this one; ox_ksp_solve checks against it. */
+size_t ox_ksp_work_bytes_for(const ox_sell *A, int ncomp, int ksp_type);
 /* max_restarts: BiCGStab only.  0 = PETSc's KSPBCGS: a rho = rhat.r = 0 (or omega = 0) breakdown
  * ends the solve with OX_DIVERGED_BREAKDOWN.  > 0: re-seed the shadow residual (rhat <- r) and
  * continue, at most that many times per component (used when a direct solver was asked for). */
@@ -489,12 +518,15 @@ int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, doubl
  * 110/111 grad vectors, 120 div vector. */
 int ox_set_spmv_variant(int v); /* A/B switch of the SpMV micro-benchmark (tools/spmv_bench.py):
                                    1 = nontemporal matrix loads (default), 0 = plain loads */
-/* One-column CG on one GPU: blocks (of 1024 threads) of the two update kernels that fold the iteration's synchronisation
- * points into themselves (3 kernels per iteration instead of 5; replaces nothing in the reference: its PETSc KSPCG has the
- * same two reductions, ksp.py:71-78).  v = 0: the five-kernel form; v = -1: the default (one block per compute unit;
- * environment OX_CG_FOLD_BLOCKS overrides); v < -1: query only; returns the value in force.  Partitioned operators never fold (their points
- * carry an all-reduce). */
-int ox_ksp_set_fold_blocks(int v);
+/* One-column CG on one GPU folds the iteration's synchronisation points into its update kernels (3 kernels per iteration
+ * instead of 5; replaces nothing in the reference: its PETSc KSPCG has the same two reductions, ksp.py:71-78).  The number of
+ * 1024-thread blocks those kernels run is a per-solve option (ox_ksp_options.fold_blocks); this is the library's default
+ * for it: one block per compute unit.  Partitioned operators never fold (their points carry an all-reduce). */
+int ox_ksp_default_fold_blocks(void);
+/* Kernels one iteration of the given method launches on this operator with these options (reporting: bench.py);
+ * partitioned != 0: the operator has a halo plan. */
+int ox_ksp_kernels_per_iteration(int ksp_type, const ox_sell *A, int ncomp, int check_every, int fold_blocks,
+                                 int partitioned);
 int ox_profile_begin(int max_records, int sample_every); /* time every sample_every-th launch per tag */
 int ox_profile_end(void);
 int ox_profile_get(int tag, long long key, long long *count, double *total_ms); /* key: the matrix's

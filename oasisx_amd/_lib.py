@@ -153,6 +153,26 @@ class ox_ksp_result(C.Structure):
         ("its", C.c_int32 * 4),
         ("rnorm", C.c_double * 4),
         ("bnorm", C.c_double * 4),
+        ("resumed", C.c_int32 * 4),
+    ]
+
+
+class ox_ksp_options(C.Structure):
+    _fields_ = [
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("divtol", C.c_double),
+        ("max_it", C.c_int32),
+        ("nonzero_guess", C.c_int32),
+        ("check_every", C.c_int32),
+        ("max_restarts", C.c_int32),
+        ("fold_blocks", C.c_int32),
+        ("run_ahead", C.c_int32),
+        ("ax0", C.c_void_p),
+        ("dinv_code", C.c_void_p),
+        ("dinv_dict", C.c_void_p),
+        ("n_dinv_dict", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -225,7 +245,12 @@ SIGNATURES = {
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_window_retile": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_set_spmv_variant": (_I, [_I]),
-    "ox_ksp_set_fold_blocks": (_I, [_I]),
+    "ox_ksp_default_fold_blocks": (_I, []),
+    "ox_ksp_kernels_per_iteration": (_I, [_I, C.POINTER(ox_sell), _I, _I, _I, _I]),
+    "ox_ksp_options_default": (_I, [C.POINTER(ox_ksp_options)]),
+    "ox_ksp_solve_opt": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, C.POINTER(ox_ksp_options), _P, C.c_size_t,
+                              C.POINTER(ox_ksp_result), _P, _P]),
+    "ox_ksp_work_bytes_for": (C.c_size_t, [C.POINTER(ox_sell), _I, _I]),
     "ox_profile_begin": (_I, [_I, _I]),
     "ox_profile_end": (_I, []),
     "ox_profile_get": (_I, [_I, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(_D)]),

@@ -930,6 +930,22 @@ __global__ __launch_bounds__(256) void k_bcgs_xp(int64_t n, const KspState *S, i
   });
 }
 
+// Merged-reduction BiCGStab, once per solve: partial = {r.r} of the stored residual (PH_BCGSM_FIN re-tests on it the
+// columns its recurrence norm declared converged).
+template <int NC>
+__global__ __launch_bounds__(256) void k_rr(int64_t n, const double *__restrict__ vr, double *partial) {
+  __shared__ double red[4 * NC];
+  double s[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) s[i] = 0.0;
+  ox_flat_pairs<NC>(n, [&](int64_t e, int ca, int64_t, int cb, int64_t, bool two) {
+    const double2 r = ox_ld2(vr, e, two);
+    ox_acc<NC>(s, 0, ca, r.x, r.x);
+    if (two) ox_acc<NC>(s, 0, cb, r.y, r.y);
+  });
+  ksp_store_partial<NC>(s, red, partial);
+}
+
 // ------------------------------- host driver ---------------------------------------------
 static inline size_t ox_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -957,11 +973,15 @@ struct KspLayout {
   int nvec, nparts_max;
 };
 
-static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type) {
+// `grid_max`: the largest number of partial-sum rows a mat-vec on the operator writes (0: the lane = row grid only).
+// The LDS-window stream writes one row per WINDOW BLOCK, and with a short length-sort window (or few slices per block)
+// there are more window blocks than lane = row blocks: the arrays are sized for whichever grid is larger.
+static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type, int grid_max = 0) {
   KspLayout L;
   const int n_slices = (int)((n_rows + 63) / 64);
   const int nblk_spmv = (n_slices + 3) / 4;
-  const int nb8 = (nblk_spmv + 7) & ~7;
+  int nb8 = (nblk_spmv + 7) & ~7;
+  if (grid_max > nb8) nb8 = (grid_max + 7) & ~7;
   L.nparts_max = nb8 + 16 > OX_VEC_MAX_BLOCKS ? nb8 + 16 : OX_VEC_MAX_BLOCKS;  // (+16: interior / boundary launches round up separately)
   L.nvec = (ksp_type == OX_KSP_CG || ksp_type == OX_KSP_CG_MERGED) ? 3 : (ksp_type == OX_KSP_CG_SINGLE ? 5 : 6);  // (both BiCGStab variants: 6)
   L.state = 0;
@@ -978,8 +998,16 @@ static KspLayout ksp_layout(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_t
   return L;
 }
 
+// the window grid of the operator, whatever slice list or column count a launch uses (every launch's grid is at most
+// round8(n_wblocks), split launches of a partitioned operator at most 8 more: covered by the +16 above)
+static inline int ksp_grid_max(const ox_sell *A) { return (A && A->wb_ptr && A->n_wblocks > 0) ? ((A->n_wblocks + 7) & ~7) + 8 : 0; }
+
 extern "C" size_t ox_ksp_work_bytes(int64_t n_rows, int64_t n_cols, int ncomp, int ksp_type) {
   return ksp_layout(n_rows, n_cols, ncomp, ksp_type).total;
+}
+extern "C" size_t ox_ksp_work_bytes_for(const ox_sell *A, int ncomp, int ksp_type) {
+  if (!A) return 0;
+  return ksp_layout(A->n_rows, A->n_cols, ncomp, ksp_type, ksp_grid_max(A)).total;
 }
 
 static KspState *g_state_host = nullptr;
@@ -1069,6 +1097,7 @@ struct KspCtx {
   const ox_dist *dist;
   hipStream_t st;
   int nb, nbs;
+  int fold;  // blocks of the folded one-column CG update kernels (0: separate synchronisation points)
 };
 
 #define KSP_SYNC(PH, partial, nparts, nv)                                                       \
@@ -1076,10 +1105,11 @@ struct KspCtx {
     if (ksp_sync_point<PH>(C.S, partial, nparts, nv, C.sums, P, C.dist, C.st)) return -1;       \
   } while (0)
 
-// blocks of the folded CG update kernels (0: the five-kernel form); OX_CG_FOLD_BLOCKS overrides (tuning)
-static int g_fold_blocks = -1;
-static int ksp_fold_blocks() {
-  if (g_fold_blocks < 0) {
+// blocks of the folded CG update kernels: the library's default (a per-solve value comes in through ox_ksp_options;
+// the environment is read by the host layer, not here)
+static int ksp_fold_blocks_default() {
+  static int dflt = -1;
+  if (dflt < 0) {
     // ONE block per compute unit: a CU that receives a second 1024-thread block takes twice as long as the others
     // (128^3 pressure: 256 blocks 59.1 us per iteration, 262 blocks 66.0, 512 blocks 65.8, 128 blocks 62.5)
     hipDeviceProp_t prop;
@@ -1087,26 +1117,19 @@ static int ksp_fold_blocks() {
     int ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
-    const char *e = getenv("OX_CG_FOLD_BLOCKS");
-    int v = e ? atoi(e) : ncu;
-    if (v > OX_FOLD_T) v = OX_FOLD_T;  // (the second point reads one partial row per thread)
-    if (v < 0) v = 0;
-    g_fold_blocks = v;
+    dflt = ncu > OX_FOLD_T ? OX_FOLD_T : ncu;  // (the second point reads one partial row per thread)
   }
-  return g_fold_blocks;
+  return dflt;
 }
-extern "C" int ox_ksp_set_fold_blocks(int v) {
-  if (v >= -1) g_fold_blocks = v < 0 ? -1 : (v > OX_FOLD_T ? OX_FOLD_T : v);  // (v < -1: query only)
-  return ksp_fold_blocks();
-}
+static inline int ksp_fold_blocks_of(int v) { return v < 0 ? ksp_fold_blocks_default() : (v > OX_FOLD_T ? OX_FOLD_T : v); }
 template <int NC>
 static int cg_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
-  if (NC == 1 && !C.dist && n >= 2 && ksp_fold_blocks() > 0) {  // one column, one GPU: both points folded into the update kernels
+  if (NC == 1 && !C.dist && n >= 2 && C.fold > 0) {  // one column, one GPU: both points folded into the update kernels
     int64_t want = ((n >> 1) + OX_FOLD_T - 1) / OX_FOLD_T;
     if (want < 1) want = 1;
-    const int nbf = (int)(want < ksp_fold_blocks() ? want : ksp_fold_blocks());
+    const int nbf = (int)(want < C.fold ? want : C.fold);
     const int nbs1 = ox_spmv_dist_nparts(C.A, nullptr, 1);  // (block sums of the ONE-column mat-vec)
     for (int k = 0; k < count; ++k) {
       if (ox_spmv_dist(C.A, V.p, V.q, 1, OX_EPI_DOT, nullptr, nullptr, C.partial, done, nullptr, C.st)) return -1;
@@ -1316,14 +1339,14 @@ template <int NC>
 static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
   const int *done = &C.S->done;
-  if (NC == 1 && !C.dist && n >= 2 && ksp_fold_blocks() > 0 && (count & 1) == 0) {
+  if (NC == 1 && !C.dist && n >= 2 && C.fold > 0 && (count & 1) == 0) {
     // folded: the state alternates S / S2 per iteration (an even batch leaves it in S, where the host and the next
     // batch look for it), the update's partial sums between two arrays
     const int nbs1 = ox_spmv_dist_nparts(C.A, nullptr, 1);
     if ((int64_t)nbs1 * 2 < OX_PRERED_MIN) {
       int64_t want = ((n >> 1) + OX_FOLD_T - 1) / OX_FOLD_T;
       if (want < 1) want = 1;
-      const int nbf = (int)(want < ksp_fold_blocks() ? want : ksp_fold_blocks());
+      const int nbf = (int)(want < C.fold ? want : C.fold);
       double *pu[2] = {C.partial2, C.partial2 + 3 * OX_FOLD_T};
       for (int k = 0; k < count; ++k) {
         KspState *Sin = (k & 1) ? C.S2 : C.S, *Sout = (k & 1) ? C.S : C.S2;
@@ -1486,9 +1509,10 @@ static int ksp_run_ahead(const KspCtx &C, Iterate &&iterate, int batch, int &it,
 template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
-                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0, const KspDinv &Dc) {
+                   ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0, const KspDinv &Dc,
+                   int fold_blocks, int run_ahead) {
   const int64_t n = A->n_rows;
-  const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type);
+  const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type, ksp_grid_max(A));
   KspCtx C;
   C.A = A;
   C.dinv = dinv;
@@ -1502,6 +1526,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   C.st = st;
   C.nb = ox_vec_blocks(2 * (n > 0 ? n : 1));  // one row per thread
   C.nbs = ox_spmv_dist_nparts(A, dist, NC);
+  C.fold = fold_blocks;
   double *vec[6];
   for (int i = 0; i < L.nvec; ++i) vec[i] = reinterpret_cast<double *>(work + L.vec0 + L.vec_stride * i);
   if (!g_state_host) OX_HIP(hipHostMalloc(&g_state_host, 3 * sizeof(KspState)));
@@ -1549,98 +1574,121 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
                : (cg ? cg_iterations<N_>(C, W, Q, check_every)
                      : (bm ? bcgsm_iterations<N_>(C, W, Q, check_every, first) : bcgs_iterations<N_>(C, W, Q, check_every, first)));
   };
-  bool cg_finished = false;
-  static int run_ahead = -1;
-  if (run_ahead < 0) run_ahead = getenv("OX_KSP_RUN_AHEAD") ? atoi(getenv("OX_KSP_RUN_AHEAD")) : 1;
   // small batches (the tail of no-ops after convergence is about one batch), large enough for the host
   // to stay ahead: 8 pressure-CG iterations are 40 launches for 600 us of GPU time
   auto batch_of = [&](int every) { return every > 8 ? 8 : every; };
-  if (NC == 1 && run_ahead) {
-    int it = 0;
-    const int bsz = batch_of(check_every);
-    auto it1 = [&](int count) -> int {
-      const bool first = bm_first;
-      bm_first = false;
-      return cgs ? cgs_iterations<1>(C, V, P, count)
-             : cgm ? cgm_iterations<1>(C, V, P, count, first)
-                 : (cg ? cg_iterations<1>(C, V, P, count)
-                       : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count, first)));
-    };
-    if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
-  }
-  for (int it = 0; !(NC == 1 && run_ahead) && it <= P.max_it; it += check_every) {
-    if (iterate(std::integral_constant<int, NC>{}, V, P)) return -1;
-    if (ksp_read_state(C)) return -1;
-    if (g_state_host->done) break;
-    if (NC > 1) {
-      // Narrowing: the columns run in lockstep, so once all but one have converged the rest of
-      // the solve would drag NC-wide vectors along for nothing.  Extract the live column into
-      // compact vectors and continue with the 1-column kernels (same recurrences, same scalars:
-      // the state block is addressed through P.c0); insert x back at the end.
-      int live = -1, nlive = 0;
-      for (int c = 0; c < NC; ++c)
-        if (g_state_host->active[c]) live = c, ++nlive;
-      if (nlive == 1) {
-        double *cv[8];
-        for (int i = 0; i < 8; ++i) cv[i] = reinterpret_cast<double *>(work + L.narrow0 + L.narrow_stride * i);
-        KspVecs W{};
-        double *src[8] = {V.x, V.r, V.z, V.p, V.q, V.rhat, V.v, nullptr};
-        double **dst[8] = {&W.x, &W.r, &W.z, &W.p, &W.q, &W.rhat, &W.v, nullptr};
-        if (cg) src[2] = nullptr;  // no z vector: the second update kernel forms D^-1 r itself
-        if (cgs) {  // x, r, u, p, s (a recurrence: carried over), w
-          src[2] = V.u, dst[2] = &W.u;
-          src[4] = V.s, dst[4] = &W.s;
-          src[5] = V.w, dst[5] = &W.w;
-          src[6] = nullptr;
-        }
-        for (int i = 0; i < 7; ++i) {
-          *dst[i] = cv[i];
-          if (!src[i]) continue;
-          hipLaunchKernelGGL(k_extract_col, dim3(C.nb), dim3(256), 0, st, n, src[i], NC, live, cv[i]);
-          OX_LAUNCH_CHECK();
-        }
-        if (!cgs) {
-          W.s = cv[2];  // BiCGStab temporaries share the slots CG uses for z and q
-          W.t = cv[4];
-        }
-        KspParams P1 = P;
-        P1.nc = 1;
-        P1.c0 = live;
-        if (run_ahead) {
-          const int bsz = batch_of(check_every);
-          auto it1 = [&](int count) -> int {
-            return cgs ? cgs_iterations<1>(C, W, P1, count)
-                       : (cg ? cg_iterations<1>(C, W, P1, count)
-                             : (bm ? bcgsm_iterations<1>(C, W, P1, count, false) : bcgs_iterations<1>(C, W, P1, count, false)));
-          };
-          it += check_every;
-          if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
-        } else {
-          for (it += check_every; it <= P.max_it; it += check_every) {
-            if (iterate(std::integral_constant<int, 1>{}, W, P1)) return -1;
-            if (ksp_read_state(C)) return -1;
-            if (g_state_host->done) break;
+  int it = 0;  // iterations queued so far (the kernels stop by themselves at max_it)
+  bool tail_done = false;  // the narrowed continuation applied the deferred updates of its column itself
+  // The merged-reduction BiCGStab re-enters this loop when the STORED residual of a column fails the test its
+  // recurrence norm passed (PH_BCGSM_FIN); every other method leaves it after one pass.
+  for (;;) {
+    tail_done = false;
+    if (NC == 1 && run_ahead) {
+      const int bsz = batch_of(check_every);
+      auto it1 = [&](int count) -> int {
+        const bool first = bm_first;
+        bm_first = false;
+        return cgs ? cgs_iterations<1>(C, V, P, count)
+               : cgm ? cgm_iterations<1>(C, V, P, count, first)
+                   : (cg ? cg_iterations<1>(C, V, P, count)
+                         : (bm ? bcgsm_iterations<1>(C, V, P, count, first) : bcgs_iterations<1>(C, V, P, count, first)));
+      };
+      if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
+    }
+    for (; !(NC == 1 && run_ahead) && it <= P.max_it; it += check_every) {
+      if (iterate(std::integral_constant<int, NC>{}, V, P)) return -1;
+      if (ksp_read_state(C)) return -1;
+      if (g_state_host->done) break;
+      if (NC > 1) {
+        // Narrowing: the columns run in lockstep, so once all but one have converged the rest of
+        // the solve would drag NC-wide vectors along for nothing.  Extract the live column into
+        // compact vectors and continue with the 1-column kernels (same recurrences, same scalars:
+        // the state block is addressed through P.c0); insert x back at the end.
+        int live = -1, nlive = 0;
+        for (int c = 0; c < NC; ++c)
+          if (g_state_host->active[c]) live = c, ++nlive;
+        if (nlive == 1) {
+          double *cv[8];
+          for (int i = 0; i < 8; ++i) cv[i] = reinterpret_cast<double *>(work + L.narrow0 + L.narrow_stride * i);
+          KspVecs W{};
+          double *src[8] = {V.x, V.r, V.z, V.p, V.q, V.rhat, V.v, nullptr};
+          double **dst[8] = {&W.x, &W.r, &W.z, &W.p, &W.q, &W.rhat, &W.v, nullptr};
+          if (cg) src[2] = nullptr;  // no z vector: the second update kernel forms D^-1 r itself
+          if (cgs) {  // x, r, u, p, s (a recurrence: carried over), w
+            src[2] = V.u, dst[2] = &W.u;
+            src[4] = V.s, dst[4] = &W.s;
+            src[5] = V.w, dst[5] = &W.w;
+            src[6] = nullptr;
           }
-        }
-        if (cg) {  // the last x += alpha p (see k_cg_update2)
-          hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, C.D, W.p, 1);
+          for (int i = 0; i < 7; ++i) {
+            *dst[i] = cv[i];
+            if (!src[i]) continue;
+            hipLaunchKernelGGL(k_extract_col, dim3(C.nb), dim3(256), 0, st, n, src[i], NC, live, cv[i]);
+            OX_LAUNCH_CHECK();
+          }
+          if (!cgs) {
+            W.s = cv[2];  // BiCGStab temporaries share the slots CG uses for z and q
+            W.t = cv[4];
+          }
+          KspParams P1 = P;
+          P1.nc = 1;
+          P1.c0 = live;
+          if (run_ahead) {
+            const int bsz = batch_of(check_every);
+            auto it1 = [&](int count) -> int {
+              return cgs ? cgs_iterations<1>(C, W, P1, count)
+                         : (cg ? cg_iterations<1>(C, W, P1, count)
+                               : (bm ? bcgsm_iterations<1>(C, W, P1, count, false) : bcgs_iterations<1>(C, W, P1, count, false)));
+            };
+            it += check_every;
+            if (ksp_run_ahead(C, it1, bsz, it, P.max_it)) return -1;
+          } else {
+            for (it += check_every; it <= P.max_it; it += check_every) {
+              if (iterate(std::integral_constant<int, 1>{}, W, P1)) return -1;
+              if (ksp_read_state(C)) return -1;
+              if (g_state_host->done) break;
+            }
+          }
+          if (cg) {  // the last x += alpha p (see k_cg_update2)
+            hipLaunchKernelGGL((k_cg_update2<1>), dim3(C.nb), dim3(256), 0, st, n, C.S, P1.c0, W.x, W.r, C.D, W.p, 1);
+            OX_LAUNCH_CHECK();
+          }
+          if (bm && g_state_host->its[live] > 0) {
+            if (bcgsm_finish<1>(C, W, P1)) return -1;
+            // (the re-test below reads the stored residuals of all columns from the NC-wide block)
+            hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.r, NC, live, V.r);
+            OX_LAUNCH_CHECK();
+          }
+          tail_done = true;
+          hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.x, NC, live, x);
           OX_LAUNCH_CHECK();
+          break;
         }
-        if (bm && g_state_host->its[live] > 0 && bcgsm_finish<1>(C, W, P1)) return -1;
-        cg_finished = true;
-        hipLaunchKernelGGL(k_insert_col, dim3(C.nb), dim3(256), 0, st, n, W.x, NC, live, x);
-        OX_LAUNCH_CHECK();
-        break;
       }
     }
-  }
-  if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
-  if (bm && !cg_finished) {  // the x update of the last iteration (skipped by `done`); nothing ran if all converged at once
+    if (!g_state_host->done) OX_FAIL("ox_ksp_solve: device state never reported completion");
+    if (!bm) break;
     bool any = false;
     for (int c = 0; c < NC; ++c) any = any || g_state_host->its[c] > 0;
-    if (any && bcgsm_finish<NC>(C, V, P)) return -1;
+    if (!any) break;  // every column converged on the initial (stored) residual: nothing ran, nothing to re-test
+    // the x / r update of the last iteration (skipped by `done`)
+    if (!tail_done && bcgsm_finish<NC>(C, V, P)) return -1;
+    bool retest = false;
+    for (int c = 0; c < NC; ++c)
+      retest = retest || g_state_host->reason[c] == OX_CONVERGED_RTOL || g_state_host->reason[c] == OX_CONVERGED_ATOL;
+    if (!retest) break;
+    hipLaunchKernelGGL((k_rr<NC>), dim3(C.nb), dim3(256), 0, st, n, V.r, C.partial);
+    OX_LAUNCH_CHECK();
+    KSP_SYNC(PH_BCGSM_FIN, C.partial, C.nb, NC);
+    if (ksp_read_state(C)) return -1;
+    if (g_state_host->done) break;  // every stored residual passes (or a column ran out of iterations)
+    // resume: rhat <- r, p <- r in the re-opened columns (k_bcgs_p reads the restart flags); p = r in the others
+    hipLaunchKernelGGL((k_bcgs_p<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.r, V.p, V.v, V.rhat);
+    OX_LAUNCH_CHECK();
+    it = 0;
+    for (int c = 0; c < NC; ++c) it = g_state_host->its[c] > it ? g_state_host->its[c] : it;
   }
-  if (cg && !cg_finished) {  // the last x += alpha p (see k_cg_update2)
+  if (cg && !tail_done) {  // the last x += alpha p (see k_cg_update2)
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 1);
     OX_LAUNCH_CHECK();
   }
@@ -1649,8 +1697,84 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     result->its[c] = g_state_host->its[c];
     result->rnorm[c] = g_state_host->rn[c];
     result->bnorm[c] = g_state_host->bn[c];
+    result->resumed[c] = bm ? g_state_host->nresume[c] : 0;
   }
   return 0;
+}
+
+extern "C" int ox_ksp_options_default(ox_ksp_options *o) {
+  if (!o) OX_FAIL("ox_ksp_options_default: null argument");
+  memset(o, 0, sizeof(*o));
+  o->rtol = 1e-5;    // PETSc's KSP defaults (KSPCreate; -ksp_view: "relative=1e-05, absolute=1e-50, divergence=10000.")
+  o->atol = 1e-50;
+  o->divtol = 1e4;
+  o->max_it = 10000;
+  o->check_every = 1;
+  o->fold_blocks = -1;
+  o->run_ahead = -1;
+  return 0;
+}
+
+extern "C" int ox_ksp_default_fold_blocks(void) { return ksp_fold_blocks_default(); }
+
+extern "C" int ox_ksp_kernels_per_iteration(int ksp_type, const ox_sell *A, int ncomp, int check_every, int fold_blocks,
+                                            int partitioned) {
+  // what cg_iterations / cgm_iterations / ... launch per iteration for this operator (reporting: bench.py)
+  if (!A) return -1;
+  if (ksp_type == OX_KSP_CG_MERGED && ncomp > 1) ksp_type = OX_KSP_CG;
+  const bool one = ncomp == 1 && !partitioned && A->n_rows >= 2 && ksp_fold_blocks_of(fold_blocks) > 0;
+  const int batch = check_every > 8 ? 8 : (check_every < 1 ? 1 : check_every);
+  switch (ksp_type) {
+    case OX_KSP_CG: {
+      if (!one) return 5;
+      return ox_spmv_dist_nparts(A, nullptr, 1) >= OX_PRERED_MIN ? 4 : 3;  // (+ the pre-reduction of many block sums)
+    }
+    case OX_KSP_CG_MERGED:
+      return (one && (batch & 1) == 0 && (int64_t)ox_spmv_dist_nparts(A, nullptr, 1) * 2 < OX_PRERED_MIN) ? 2 : 3;
+    case OX_KSP_CG_SINGLE: return 3;
+    case OX_KSP_BCGS: return 8;
+    case OX_KSP_BCGS_MERGED: return 6;
+    default: return -1;
+  }
+}
+
+extern "C" int ox_ksp_solve_opt(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x, int ncomp,
+                                const ox_ksp_options *opt, void *work, size_t work_bytes, ox_ksp_result *result,
+                                const ox_dist *dist, void *stream) {
+  if (!A || !dinv || !b || !x || !work || !result || !opt) OX_FAIL("ox_ksp_solve: null argument");
+  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED &&
+      ksp_type != OX_KSP_CG_MERGED)
+    OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
+  if (ksp_type == OX_KSP_CG_MERGED && ncomp > 1) ksp_type = OX_KSP_CG;  // (the merged form is the one-column solver)
+  if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
+  if (work_bytes < ox_ksp_work_bytes_for(A, ncomp, ksp_type))
+    OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes, ox_ksp_work_bytes_for(A, ncomp, ksp_type));
+  if (opt->dinv_code && (!opt->dinv_dict || opt->n_dinv_dict < 1 || opt->n_dinv_dict > 256))
+    OX_FAIL("ox_ksp_solve: dinv dictionary of %d entries", opt->n_dinv_dict);
+  if (!(opt->divtol > 0.0)) OX_FAIL("ox_ksp_solve: divtol=%g (must be positive; PETSc's default is 1e4)", opt->divtol);
+  const int max_it = opt->max_it < 1 ? 1 : opt->max_it;
+  const int check_every = opt->check_every < 1 ? 1 : opt->check_every;
+  memset(result, 0, sizeof(*result));
+  KspParams P{};
+  P.rtol = opt->rtol;
+  P.atol = opt->atol;
+  P.dtol = opt->divtol;
+  P.max_it = max_it;
+  P.nc = ncomp;
+  P.c0 = 0;
+  P.nc_total = ncomp;
+  P.max_restarts = opt->max_restarts < 0 ? 0 : opt->max_restarts;
+  hipStream_t st = ox_stream(stream);
+  char *w = static_cast<char *>(work);
+  const KspDinv D{dinv, opt->dinv_code, opt->dinv_dict, opt->dinv_code ? opt->n_dinv_dict : 0};
+  const int fold = ksp_fold_blocks_of(opt->fold_blocks), ahead = opt->run_ahead < 0 ? 1 : (opt->run_ahead ? 1 : 0);
+  const int guess = opt->nonzero_guess;
+  const double *ax0 = opt->ax0;
+  switch (ncomp) {
+    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
+    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
+    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
+  }
 }
 
 extern "C" int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *dinv, const double *b,
@@ -1658,28 +1782,19 @@ extern "C" int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *din
                                int nonzero_guess, int check_every, int max_restarts, void *work,
                                size_t work_bytes, ox_ksp_result *result, const ox_dist *dist, void *stream,
                                const double *ax0, const uint8_t *dinv_code, const double *dinv_dict, int n_dinv_dict) {
-  if (!A || !dinv || !b || !x || !work || !result) OX_FAIL("ox_ksp_solve: null argument");
-  if (ksp_type != OX_KSP_CG && ksp_type != OX_KSP_BCGS && ksp_type != OX_KSP_CG_SINGLE && ksp_type != OX_KSP_BCGS_MERGED &&
-      ksp_type != OX_KSP_CG_MERGED)
-    OX_FAIL("ox_ksp_solve: ksp_type=%d", ksp_type);
-  if (ksp_type == OX_KSP_CG_MERGED && ncomp > 1) ksp_type = OX_KSP_CG;  // (the merged form is the one-column solver)
-  if (ncomp < 1 || ncomp > OX_MAXC) OX_FAIL("ox_ksp_solve: ncomp=%d out of range", ncomp);
-  if (work_bytes < ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type))
-    OX_FAIL("ox_ksp_solve: workspace too small (%zu < %zu)", work_bytes,
-            ox_ksp_work_bytes(A->n_rows, A->n_cols, ncomp, ksp_type));
-  if (dinv_code && (!dinv_dict || n_dinv_dict < 1 || n_dinv_dict > 256)) OX_FAIL("ox_ksp_solve: dinv dictionary of %d entries", n_dinv_dict);
-  if (max_it < 1) max_it = 1;
-  if (check_every < 1) check_every = 1;
-  memset(result, 0, sizeof(*result));
-  KspParams P{rtol, atol, max_it, ncomp, 0, ncomp, max_restarts < 0 ? 0 : max_restarts};
-  hipStream_t st = ox_stream(stream);
-  char *w = static_cast<char *>(work);
-  const KspDinv D{dinv, dinv_code, dinv_dict, dinv_code ? n_dinv_dict : 0};
-  switch (ncomp) {
-    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
-    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
-    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, nonzero_guess, check_every, w, result, dist, st, ax0, D);
-  }
+  ox_ksp_options o;
+  ox_ksp_options_default(&o);
+  o.rtol = rtol;
+  o.atol = atol;
+  o.max_it = max_it;
+  o.nonzero_guess = nonzero_guess;
+  o.check_every = check_every;
+  o.max_restarts = max_restarts;
+  o.ax0 = ax0;
+  o.dinv_code = dinv_code;
+  o.dinv_dict = dinv_dict;
+  o.n_dinv_dict = n_dinv_dict;
+  return ox_ksp_solve_opt(ksp_type, A, dinv, b, x, ncomp, &o, work, work_bytes, result, dist, stream);
 }
 
 extern "C" int ox_ksp_solve_ax0(int ksp_type, const ox_sell *A, const double *dinv, const double *b,

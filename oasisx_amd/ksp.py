@@ -23,6 +23,14 @@ Option mapping (PETSc string keys, as the reference passes them):
             (OX_KSP_BCGS_MERGED); default: true on mesh-partitioned operators, false on a single GPU
   ksp_rtol, ksp_atol, ksp_max_it, ksp_initial_guess_nonzero: as in PETSc (defaults 1e-5,
             1e-50, 10000, false -> the solution vector is zeroed before the solve)
+  ksp_divtol  as in PETSc (default 1e4): a column whose |D^-1 r| reaches divtol |D^-1 b| ends with
+            KSP_DIVERGED_DTOL (-4) instead of running to ksp_max_it
+  ksp_error_if_not_converged  as in PETSc (the reference sets it for its pressure solver, fracstep.py:570):
+            a negative converged reason raises ``KSPConvergenceError`` (PETSc: error 91) instead of being returned
+  ksp_cg_fold_blocks, ksp_run_ahead  (extensions: schedule knobs of THIS solver, passed to the library per call)
+            blocks of the folded one-column CG update kernels (0: five kernels per iteration; default: one per
+            compute unit, or the environment's OX_CG_FOLD_BLOCKS read once by this module) and whether one-column
+            solves queue one batch ahead of the state the host reads (default true; OX_KSP_RUN_AHEAD)
   ksp_bcgs_restarts (extension): BiCGStab restarts allowed after a rho/omega breakdown; default 0
             for an explicit "bcgs" (PETSc's KSPBCGS stops with DIVERGED_BREAKDOWN), 5 when the
             method stands in for a direct solver, which cannot break down (e.g. a cold start with
@@ -32,6 +40,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import os
 import typing
 
 import torch
@@ -40,13 +49,41 @@ from . import _lib
 from .fem import FieldStorage, Function
 from .la import SellMatrix
 
-__all__ = ["KSPSolver"]
+__all__ = ["KSPSolver", "KSPConvergenceError"]
+
+
+class KSPConvergenceError(RuntimeError):
+    """``ksp_error_if_not_converged``: the solve ended with a negative KSPConvergedReason (PETSc raises error 91,
+    "KSPSolve has not converged", at the same place: reference ksp.py:76 with fracstep.py:570)."""
+
+    def __init__(self, prefix, reasons, its):
+        self.reasons, self.iterations = list(reasons), list(its)
+        names = {-3: "DIVERGED_ITS", -4: "DIVERGED_DTOL", -5: "DIVERGED_BREAKDOWN", -9: "DIVERGED_NANORINF"}
+        what = ", ".join(f"{names.get(r, r)} after {i} iterations" for r, i in zip(self.reasons, self.iterations) if r <= 0)
+        super().__init__(f"KSPSolver[{prefix}]: KSPSolve has not converged ({what})")
+
+
+def _truthy(v) -> bool:
+    return v not in (False, 0, "false", "0", "False", None, "no", "off")
+
+
+def _env_int(name: str, default: int) -> int:
+    """Tuning defaults from the environment, read by the HOST layer once per solver and handed to the library per
+    call (the library itself keeps no process-wide switch for them)."""
+    try:
+        return int(os.environ[name])
+    except (KeyError, ValueError):
+        return default
 
 DIRECT_RTOL = 1e-12
 CG_MERGED_MAX_ROWS = 1 << 20
 KRYLOV_TYPES = ("cg", "bcgs", "bicgstab", "ibcgs", "pipebcgs", "fbcgsr")
-HONOURED_KEYS = ("ksp_type", "pc_type", "ksp_rtol", "ksp_atol", "ksp_max_it", "ksp_initial_guess_nonzero",
-                 "ksp_cg_single_reduction", "ksp_cg_merged_reduction", "ksp_bcgs_merged_reduction", "ksp_bcgs_restarts")
+HONOURED_KEYS = ("ksp_type", "pc_type", "ksp_rtol", "ksp_atol", "ksp_divtol", "ksp_max_it", "ksp_initial_guess_nonzero",
+                 "ksp_error_if_not_converged", "ksp_cg_single_reduction", "ksp_cg_merged_reduction",
+                 "ksp_bcgs_merged_reduction", "ksp_bcgs_restarts", "ksp_cg_fold_blocks", "ksp_run_ahead")
+# keys the reference itself sets next to a direct solver (fracstep.py:565-570): they configure MUMPS, which the Krylov
+# stand-in has no use for -- accepted silently with ksp_type=preonly
+DIRECT_ONLY_KEYS = ("pc_factor_mat_solver_type", "mat_mumps_icntl_24", "mat_mumps_icntl_25")
 
 
 class KSPSolver:
@@ -61,6 +98,8 @@ class KSPSolver:
         self.last_result = None
         self.check_every = None  # override of the automatic check interval (see solve_block)
         self._every = {}
+        self._env_fold = _env_int("OX_CG_FOLD_BLOCKS", -1)
+        self._env_ahead = _env_int("OX_KSP_RUN_AHEAD", -1)
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -100,7 +139,7 @@ class KSPSolver:
         elif pc == "none" and direct:
             warn("pc_type", "pc_type=none with ksp_type=preonly solves nothing in PETSc; runs the Krylov stand-in")
         for k in o:
-            if k in HONOURED_KEYS or (direct and k == "pc_factor_mat_solver_type"):
+            if k in HONOURED_KEYS or (direct and k in DIRECT_ONLY_KEYS):
                 continue
             warn(k, f"option {k}={o[k]!r} is not known to this path and is ignored")
 
@@ -187,25 +226,36 @@ class KSPSolver:
             self._merged_auto = rows <= CG_MERGED_MAX_ROWS
         return self._merged_auto
 
+    def _fold_blocks(self) -> int:
+        """Blocks of the folded one-column CG update kernels this solver asks for (-1: the library's default)."""
+        v = self._options.get("ksp_cg_fold_blocks")
+        return int(v) if v is not None else self._env_fold
+
+    def _run_ahead(self) -> int:
+        v = self._options.get("ksp_run_ahead")
+        return (1 if _truthy(v) else 0) if v is not None else self._env_ahead
+
     def _cg_folded(self) -> bool:
         """One-column standard CG on one GPU: the iteration's two synchronisation points are folded into the update
-        kernels (3 kernels per iteration: csrc/ox_ksp.hip k_cg_update1f / k_cg_update2f; ``ox_ksp_set_fold_blocks``).
+        kernels (3 kernels per iteration: csrc/ox_ksp.hip k_cg_update1f / k_cg_update2f; option ``ksp_cg_fold_blocks``).
         Partitioned operators never fold: their points carry an all-reduce."""
         if self._A is None or self._A.pattern.dist is not None:
             return False
+        fb = self._fold_blocks()
         return (self._method()[0] == _lib.KSP_CG and not self._cg_merged()
-                and int(_lib.load().ox_ksp_set_fold_blocks(-2)) > 0)
+                and (fb if fb >= 0 else int(_lib.load().ox_ksp_default_fold_blocks())) > 0)
 
     def _cg_kernels_per_iteration(self) -> int:
-        """Kernels of one iteration of a one-column CG solve with this solver (reporting only: bench.py): 5 for the
-        standard recurrences, 3 with their points folded (one GPU), 3 for the merged-reduction form, 2 with its point
-        folded (one GPU, block sums of the mat-vec below the pre-reduction threshold: csrc/ox_ksp.hip cgm_iterations)."""
-        fold = (self._A is not None and self._A.pattern.dist is None
-                and int(_lib.load().ox_ksp_set_fold_blocks(-2)) > 0)
-        if self._A is not None and self._method()[0] == _lib.KSP_CG and self._cg_merged():
-            nbs = (((self._A.pattern.n_slices + 3) // 4) + 7) & ~7
-            return 2 if fold and 2 * nbs < 16384 else 3
-        return 3 if self._cg_folded() else 5
+        """Kernels of one iteration of a one-column CG solve with this solver (reporting only: bench.py), as the LIBRARY
+        decides it for this operator, method, check interval and fold setting (``ox_ksp_kernels_per_iteration``)."""
+        if self._A is None:
+            return 5
+        meth = self._method()[0]
+        if meth in (_lib.KSP_CG, _lib.KSP_CG_SINGLE) and self._cg_merged():
+            meth = _lib.KSP_CG_MERGED
+        every = self.check_every or self._every.get((1, meth)) or self._interval_for(1, meth)
+        return int(_lib.load().ox_ksp_kernels_per_iteration(meth, self._A.ref(), 1, int(every), self._fold_blocks(),
+                                                            int(self._A.pattern.dist is not None)))
 
     def solve_block(self, B: FieldStorage, X: FieldStorage, ax0: FieldStorage | None = None):
         """Solve A X = B for all ``nc`` interleaved right-hand sides in lockstep.
@@ -245,7 +295,7 @@ class KSPSolver:
                                                    C.byref(nd), st), "ox_value_dictionary")
                 if nd.value > 0:
                     self._dcode, self._ddict = code, vdict[: nd.value]
-        need = lib.ox_ksp_work_bytes(A.pattern.n_rows, A.pattern.n_cols, nc, meth)
+        need = lib.ox_ksp_work_bytes_for(A.ref(), nc, meth)
         if self._work is None or self._work.shape[0] < need:
             self._work = torch.empty(int(need), dtype=torch.uint8, device=dev)
         res = _lib.ox_ksp_result()
@@ -256,24 +306,24 @@ class KSPSolver:
         # so check every iteration unless iterations are shorter than two reads.
         key = (nc, meth)
         if key not in self._every:
-            # from the matrix size alone (bytes per iteration at ~4 TB/s + launch latencies), NOT from a measured time:
-            # with several columns the interval decides at which iteration a solve narrows to its last live column,
-            # the 1-column kernels sum their dot products in another order than the NC-column ones, and a schedule
-            # that followed timing noise made the last bits of a step differ from run to run (round 4: seen as 1e-15
-            # differences between identical runs at sizes where an iteration takes about the 60 us of the threshold)
-            t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * A.pattern.nnz / 4.0e12 + 25e-6
-            self._every[key] = self._check_interval(nc, t_iter)
+            self._every[key] = self._interval_for(nc, meth)
         every = self.check_every or self._every[key]
         # a direct solver never breaks down: when one was asked for, let BiCGStab re-seed its shadow
         # residual on a rho/omega breakdown; an explicit "bcgs" behaves like PETSc's (reason -5)
         restarts = int(self._options.get("ksp_bcgs_restarts", 5 if direct else 0))
         dcode = getattr(self, "_dcode", None)
-        _lib.check(lib.ox_ksp_solve_dc(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, rtol, atol,
-                                       max_it, int(guess), int(every), restarts, _lib.ptr(self._work),
-                                       int(self._work.shape[0]), C.byref(res), A.pattern.dist, st,
-                                       ax0.ptr() if (ax0 is not None and guess) else None,
-                                       _lib.ptr(dcode), _lib.ptr(self._ddict) if dcode is not None else None,
-                                       int(self._ddict.shape[0]) if dcode is not None else 0),
+        opt = _lib.ox_ksp_options()
+        _lib.check(lib.ox_ksp_options_default(C.byref(opt)), "ox_ksp_options_default")
+        opt.rtol, opt.atol, opt.max_it = rtol, atol, max_it
+        opt.divtol = float(self._options.get("ksp_divtol", 1e4))  # PETSc's default ("divergence=10000." in -ksp_view)
+        opt.nonzero_guess, opt.check_every, opt.max_restarts = int(guess), int(every), restarts
+        opt.fold_blocks, opt.run_ahead = self._fold_blocks(), self._run_ahead()
+        opt.ax0 = ax0.ptr() if (ax0 is not None and guess) else None
+        if dcode is not None:
+            opt.dinv_code, opt.dinv_dict = _lib.ptr(dcode), _lib.ptr(self._ddict)
+            opt.n_dinv_dict = int(self._ddict.shape[0])
+        _lib.check(lib.ox_ksp_solve_opt(meth, A.ref(), _lib.ptr(self._dinv), B.ptr(), X.ptr(), nc, C.byref(opt),
+                                        _lib.ptr(self._work), int(self._work.shape[0]), C.byref(res), A.pattern.dist, st),
                    "ox_ksp_solve")
         if A.pattern.dist is not None:  # x.scatter_forward() (reference ksp.py:77)
             _lib.check(lib.ox_halo_forward(A.pattern.dist, X.ptr(), nc, st), "ox_halo_forward")
@@ -281,7 +331,18 @@ class KSPSolver:
         reasons = [int(res.reason[c]) for c in range(nc)]
         if direct:
             reasons = [_lib.CONVERGED_ITS if r > 0 else r for r in reasons]
+        if _truthy(self._options.get("ksp_error_if_not_converged", False)) and any(r <= 0 for r in reasons):
+            raise KSPConvergenceError(self._prefix, reasons, [int(res.its[c]) for c in range(nc)])
         return reasons
+
+    def _interval_for(self, nc: int, meth: int) -> int:
+        # from the matrix size alone (bytes per iteration at ~4 TB/s + launch latencies), NOT from a measured time:
+        # with several columns the interval decides at which iteration a solve narrows to its last live column,
+        # the 1-column kernels sum their dot products in another order than the NC-column ones, and a schedule
+        # that followed timing noise made the last bits of a step differ from run to run (round 4: seen as 1e-15
+        # differences between identical runs at sizes where an iteration takes about the 60 us of the threshold)
+        t_iter = (2 if meth in (_lib.KSP_BCGS, _lib.KSP_BCGS_MERGED) else 1) * 10.0 * self._A.pattern.nnz / 4.0e12 + 25e-6
+        return self._check_interval(nc, t_iter)
 
     def _check_interval(self, nc: int, t_iter: float) -> int:
         """Iterations enqueued between two host reads of the device state, from the time of one iteration."""

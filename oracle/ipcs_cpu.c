@@ -56,6 +56,7 @@ static int test_conv(double rn, double bn, double rtol, double atol) {
   if (!(rn == rn) || isinf(rn)) return -9;
   if (rn <= atol) return 3;
   if (rn <= rtol * bn) return 2;
+  if (bn > 0.0 && rn >= 1e4 * bn) return -4; /* KSPConvergedDefault: -ksp_divtol, PETSc's default 1e4 */
   return 0;
 }
 

@@ -535,17 +535,23 @@ CONVERGED_RTOL, CONVERGED_ATOL, CONVERGED_ITS = 2, 3, 4
 DIVERGED_ITS, DIVERGED_DTOL, DIVERGED_BREAKDOWN, DIVERGED_NANORINF = -3, -4, -5, -9
 
 
-def _reason(rn, bn, rtol, atol):
+def _reason(rn, bn, rtol, atol, divtol=1e4):
+    """KSPConvergedDefault (PETSc src/ksp/ksp/interface/iterativ.c; what ``KSP.solve`` of reference ksp.py:76 tests
+    with the options of ksp.py:38-53): NaN -> -9; |r| <= max(rtol |b|, atol) -> 2 / 3; |r| >= divtol |b| -> -4
+    (``-ksp_divtol``, default 1e4).  The divergence test needs |b| > 0 (PETSc's rnorm0 = 0 with a nonzero guess
+    flags ANY residual: a quirk neither side reproduces)."""
     if not np.isfinite(rn):
         return DIVERGED_NANORINF
     if rn <= atol:
         return CONVERGED_ATOL
     if rn <= rtol * bn:
         return CONVERGED_RTOL
+    if bn > 0.0 and rn >= divtol * bn:
+        return DIVERGED_DTOL
     return 0
 
 
-def jacobi_cg(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None):
+def jacobi_cg(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None, divtol=1e4):
     """Jacobi-preconditioned conjugate gradients (PETSc KSPCG + PCJACOBI)."""
     n = b.shape[0]
     dinv = 1.0 / A.diagonal() if dinv is None else dinv
@@ -554,7 +560,7 @@ def jacobi_cg(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None):
     z = dinv * r
     bn = np.linalg.norm(dinv * b)
     rn = np.linalg.norm(z)
-    reason = _reason(rn, bn, rtol, atol)
+    reason = _reason(rn, bn, rtol, atol, divtol)
     it = 0
     if reason:
         return x, reason, it, rn
@@ -571,7 +577,7 @@ def jacobi_cg(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None):
         z = dinv * r
         rn = np.linalg.norm(z)
         it += 1
-        reason = _reason(rn, bn, rtol, atol)
+        reason = _reason(rn, bn, rtol, atol, divtol)
         if reason:
             return x, reason, it, rn
         rz_new = r @ z
@@ -581,7 +587,7 @@ def jacobi_cg(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None):
     return x, DIVERGED_ITS, it, rn
 
 
-def jacobi_bicgstab(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None):
+def jacobi_bicgstab(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=None, divtol=1e4):
     """Left-Jacobi-preconditioned BiCGStab (PETSc KSPBCGS + PCJACOBI): the
     recurrence runs on the preconditioned system B A x = B b."""
     n = b.shape[0]
@@ -591,7 +597,7 @@ def jacobi_bicgstab(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=Non
     bn = np.linalg.norm(dinv * b)
     rn = np.linalg.norm(r)
     it = 0
-    reason = _reason(rn, bn, rtol, atol)
+    reason = _reason(rn, bn, rtol, atol, divtol)
     if reason:
         return x, reason, it, rn
     rhat = r.copy()
@@ -618,7 +624,7 @@ def jacobi_bicgstab(A, b, x0=None, rtol=1e-5, atol=1e-50, max_it=10000, dinv=Non
         r = s - omega * t
         rn = np.linalg.norm(r)
         it += 1
-        reason = _reason(rn, bn, rtol, atol)
+        reason = _reason(rn, bn, rtol, atol, divtol)
         if reason:
             return x, reason, it, rn
         if omega == 0.0:
@@ -637,6 +643,8 @@ class OracleKSP:
         self.rtol = float(o.get("ksp_rtol", 1e-5))
         self.atol = float(o.get("ksp_atol", 1e-50))
         self.max_it = int(o.get("ksp_max_it", 10000))
+        self.divtol = float(o.get("ksp_divtol", 1e4))
+        self.error_if_not_converged = o.get("ksp_error_if_not_converged", False) not in (False, 0, "0", "false")
         self.nonzero_guess = bool(o.get("ksp_initial_guess_nonzero", False))
         self.A = None
         self._lu = None
@@ -657,9 +665,11 @@ class OracleKSP:
         x0 = x.copy() if self.nonzero_guess else None
         dinv = 1.0 / self.A.diagonal() if self.pc_type == "jacobi" else np.ones(b.shape[0])
         fn = jacobi_cg if self.ksp_type == "cg" else jacobi_bicgstab
-        sol, reason, its, _ = fn(self.A, b, x0, self.rtol, self.atol, self.max_it, dinv)
+        sol, reason, its, _ = fn(self.A, b, x0, self.rtol, self.atol, self.max_it, dinv, self.divtol)
         x[:] = sol
         self.its = its
+        if self.error_if_not_converged and reason <= 0:  # PETSc: error 91 out of KSPSolve
+            raise RuntimeError(f"KSPSolve has not converged (reason {reason} after {its} iterations)")
         return reason
 
 

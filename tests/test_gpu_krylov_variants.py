@@ -339,7 +339,7 @@ def test_identical_runs_give_identical_bits_and_the_launch_schedule_does_not_fol
                                                      (3, 8, 2, 3, False), (2, 1, 1, 1, False), (3, 12, 1, 2, True)])
 def test_folded_cg_matches_the_five_kernel_iteration_and_oracle(hip, dim, N, deg, nc, dictionary):
     """Round 4: one-column CG on one GPU runs its two synchronisation points inside the update kernels
-    (k_cg_update1f / k_cg_update2f, 3 kernels per iteration; ``ox_ksp_set_fold_blocks``).  Against the five-kernel form
+    (k_cg_update1f / k_cg_update2f, 3 kernels per iteration; per-solver option ``ksp_cg_fold_blocks``).  Against the five-kernel form
     (fold off) and the oracle's PETSc-convention CG: same converged reasons, iteration counts within 1, solutions to
     solver tolerance; odd and even row counts (the pair loop's tail), a 4-row system, a value dictionary of the diagonal
     (1-byte codes in the update kernels), several columns (the folded kernels serve the narrowed tail of the lock-step
@@ -358,16 +358,17 @@ def test_folded_cg_matches_the_five_kernel_iteration_and_oracle(hip, dim, N, deg
     cols = [np.cos(2.0 * x[:, 0]) * (1.0 + x[:, 1]), 1e-3 * np.sin(5.0 * x[:, 0] * x[:, -1]), np.exp(x[:, 1])][:nc]
     B = FieldStorage(n, nc, "cuda")
     B.dev()[:] = torch.from_numpy(np.stack(cols, axis=1)).cuda()
-    default_blocks = lib.ox_ksp_set_fold_blocks(-1)
-    assert default_blocks > 0 and lib.ox_ksp_set_fold_blocks(-2) == default_blocks
+    default_blocks = lib.ox_ksp_default_fold_blocks()
+    assert default_blocks > 0
     out = {}
-    try:
+    if True:
         for blocks in (0, 1, 7, default_blocks, 1024):
-            assert lib.ox_ksp_set_fold_blocks(blocks) == blocks
+            fold = {"ksp_cg_fold_blocks": blocks}  # per solver: two solvers with different settings do not interfere
             ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
-                                   "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False})
+                                   "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False, **fold})
             ksp.setOperators(A)
             assert ksp._cg_folded() == (blocks > 0)
+            assert ksp._cg_kernels_per_iteration() == (3 if blocks > 0 else 5)
             X = FieldStorage(n, nc, "cuda")
             reasons = ksp.solve_block(B, X)
             sol = X.dev().cpu().numpy().copy()
@@ -375,20 +376,19 @@ def test_folded_cg_matches_the_five_kernel_iteration_and_oracle(hip, dim, N, deg
             # the solution as the right-hand side's answer: a second solve from it needs no iteration
             ksp2 = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-6, "ksp_atol": 1e-50,
                                     "ksp_initial_guess_nonzero": True, "ksp_cg_single_reduction": False,
-                                    "ksp_cg_merged_reduction": False})
+                                    "ksp_cg_merged_reduction": False, **fold})
             ksp2.setOperators(A)
             r2 = ksp2.solve_block(B, X)
             assert all(r == 2 for r in r2) and list(ksp2.iterations[:nc]) == [0] * nc
             assert np.array_equal(X.dev().cpu().numpy(), sol)  # untouched
             # cut by max_it: reason -3 after exactly that many iterations
             ksp3 = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-30, "ksp_atol": 1e-300,
-                                    "ksp_max_it": 3, "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False})
+                                    "ksp_max_it": 3, "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": False,
+                                    **fold})
             ksp3.setOperators(A)
             X3 = FieldStorage(n, nc, "cuda")
             r3 = ksp3.solve_block(B, X3)
             out[blocks] = (sol, its, reasons, X3.dev().cpu().numpy().copy(), list(r3), list(ksp3.iterations[:nc]))
-    finally:
-        lib.ox_ksp_set_fold_blocks(-1)
     ref = out[0]
     for c in range(nc):
         sol, reason, its, _ = O.jacobi_cg(Acsr, cols[c], rtol=1e-10, atol=1e-50)
@@ -424,15 +424,17 @@ def test_folded_merged_cg_matches_its_three_kernel_form(hip, dim, N, deg, dictio
     B.dev()[:, 0] = torch.from_numpy(b).cuda()
     sol, reason, its, _ = O.jacobi_cg(Acsr, b, rtol=1e-10, atol=1e-50)
     out = {}
-    try:
+    if True:
         for blocks in (0, -1):
-            lib.ox_ksp_set_fold_blocks(blocks)
             for every in (None, 3, 4):
                 ksp = KSPSolver(None, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-50,
-                                       "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": True})
+                                       "ksp_cg_single_reduction": False, "ksp_cg_merged_reduction": True,
+                                       "ksp_cg_fold_blocks": blocks})
                 ksp.setOperators(A)
                 ksp.check_every = every
-                assert ksp._cg_merged() and ksp._cg_kernels_per_iteration() == (2 if blocks else 3)
+                # (the library's own answer: the fold needs even batches, min(check interval, 8))
+                even = (min(every, 8) if every else min(ksp._interval_for(1, _lib.KSP_CG_MERGED), 8)) % 2 == 0
+                assert ksp._cg_merged() and ksp._cg_kernels_per_iteration() == (2 if blocks and even else 3)
                 X = FieldStorage(n, 1, "cuda")
                 r = ksp.solve_block(B, X)
                 it = ksp.iterations[0]
@@ -442,8 +444,6 @@ def test_folded_merged_cg_matches_its_three_kernel_form(hip, dim, N, deg, dictio
                 r2 = ksp.solve_block(B, X)
                 assert r2[0] == 2 and ksp.iterations[0] == 0 and np.array_equal(X.dev()[:, 0].cpu().numpy(), xs)
                 out[(blocks, every)] = (xs, it, r[0])
-    finally:
-        lib.ox_ksp_set_fold_blocks(-1)
     for key, (xs, it, r) in out.items():
         assert r == reason == 2, (key, r)
         assert abs(it - its) <= 2 and abs(it - out[(0, None)][1]) <= 1, (key, it, its)

@@ -143,3 +143,56 @@ def test_krylov_solves_and_time_steps_on_the_window_stream(hip, dim, N):
     its, its_o = S.iteration_counts(), R.its
     for k in ("tentative", "update"):
         assert all(abs(a - b) <= 1 for a, b in zip(its[k][:dim], its_o[k])), (its, its_o)
+
+
+def test_krylov_workspace_covers_the_window_grid_of_a_short_sort_window(hip):
+    """with a 64-row length-sort window every slice is its own window block, so the window mat-vec
+    launches n_slices blocks -- four times the lane = row grid the Krylov partial-sum arrays used to be sized for.  On an
+    operator of more than 4096 slices a three-column BiCGStab then wrote past them into the Krylov vectors.  The workspace
+    is sized from the operator's real grid now (``ox_ksp_work_bytes_for``): same solution as on the lane = row kernels."""
+    from oasisx_amd import _lib, fem
+    from oasisx_amd import mesh as M
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oasisx_amd.la import SellMatrix
+
+    lib = _lib.load()
+    mesh = M.create_rectangle(None, [[-1.0, -1.0], [1.0, 1.0]], [256, 256])
+    V = fem.FunctionSpace(mesh, 2, window=64)
+    assert V.build_windows()
+    P = V.pattern
+    assert P.n_slices > 4096 and P.n_wblocks > (P.n_slices + 3) // 4 + 64
+    A = SellMatrix(P, name="A")
+    rows_, k_ = P.slot_rows_k()
+    rl = np.zeros(P.n_slices * 64, dtype=np.int64)
+    rl[: P.n_rows] = P.row_len.cpu().numpy()
+    real = torch.from_numpy(k_ < rl[rows_]).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A.vals.copy_((torch.rand(P.size, dtype=torch.float64, device="cuda", generator=g) - 0.5) * real)
+    # diagonally dominant: the diagonal slot of each row (column == row) gets 40
+    diag = torch.from_numpy(P.cols.cpu().numpy() == rows_).cuda() & real
+    A.vals[diag] = 40.0
+    A.version += 1
+    assert lib.ox_ksp_work_bytes_for(A.ref(), 3, _lib.KSP_BCGS_MERGED) > lib.ox_ksp_work_bytes(P.n_rows, P.n_cols, 3, _lib.KSP_BCGS_MERGED)
+    n = P.n_rows
+    B = FieldStorage(n, 3, "cuda")
+    B.dev()[:] = torch.randn(n, 3, dtype=torch.float64, device="cuda", generator=g)
+    sols = {}
+    try:
+        for variant in (15, 31):
+            lib.ox_set_spmv_variant(variant)
+            for merged in (False, True):
+                ksp = KSPSolver(None, {"ksp_type": "bcgs", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_bcgs_merged_reduction": merged})
+                ksp.setOperators(A)
+                X = FieldStorage(n, 3, "cuda")
+                assert ksp.solve_block(B, X) == [2, 2, 2]
+                sols[(variant, merged)] = (X.dev().clone(), list(ksp.iterations[:3]))
+    finally:
+        lib.ox_set_spmv_variant(31)
+    ref = sols[(15, False)]
+    y = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    for key, (x, its) in sols.items():
+        assert all(abs(a - b) <= 2 for a, b in zip(its, ref[1])), (key, its, ref[1])
+        assert (x - ref[0]).abs().max() < 1e-8 * ref[0].abs().max(), key
+        A.mult(x, y, 3)
+        assert (y - B.dev()).abs().max() < 1e-7 * B.dev().abs().max(), key
