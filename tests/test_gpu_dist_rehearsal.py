@@ -115,3 +115,80 @@ def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory, tra
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, low_memory, transport, out), nprocs=world, join=True)
     assert len(out) == world, dict(out)
+
+
+def _retest_worker(rank, world, port, transport, out):
+    """Merged-reduction BiCGStab (the DEFAULT on a partitioned operator) on D^-1 A = I + 1e-9 E at rtol 1e-25: its
+    recurrence norm is rounding noise after one iteration (tests/test_gpu_ksp_options.py); the stored residual decides,
+    through an all-reduced r.r, identically on every rank."""
+    import torch.distributed as dist
+
+    os.environ["OX_TRANSPORT"] = transport
+    os.environ["OX_P2P_TIMEOUT_S"] = "30"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oasisx_amd import _lib
+        from oasisx_amd.fem import FieldStorage
+        from oasisx_amd.ksp import KSPSolver
+        from oasisx_amd.la import SellMatrix
+        from oasisx_amd.parallel import init_comm
+
+        comm = init_comm()
+        res = {}
+        for tag, cm in (("part", comm), ("serial", None)):
+            S, _ = _run(2, 12, 2, cm, steps=0)
+            Vi = S._Vi[0][0]
+            P = S._K.pattern
+            assert (P.dist is not None) == (cm is not None)
+            rows_, k_ = P.slot_rows_k()
+            rl = np.zeros(P.n_slices * 64, dtype=np.int64)
+            rl[: P.n_rows] = P.row_len.cpu().numpy()
+            real = k_ < rl[rows_]
+            diag = torch.from_numpy((P.cols.cpu().numpy() == rows_) & real).cuda()
+            x = Vi.x.cpu().numpy()
+            A = SellMatrix(P, name="A")
+            A.vals.copy_(1e-9 * S._K.vals)
+            # the diagonal and the right-hand sides as functions of the dof's position: the same system on every layout
+            d = 1.5 + 0.5 * np.sin(11.0 * x[:, 0] + 3.0) * np.cos(7.0 * x[:, 1])
+            A.vals[diag] += torch.from_numpy(d[rows_[diag.cpu().numpy()]]).cuda()
+            A.version += 1
+            nl, no = Vi.n_local, Vi.n_owned
+            cols = [np.sin(37.0 * x[:, 0]) * np.cos(23.0 * x[:, 1]) + 0.3, np.cos(5.0 * x[:, 0] * x[:, 1]) + x[:, 1],
+                    np.sin(91.0 * x[:, 0] + 17.0 * x[:, 1])]
+            B = FieldStorage(nl, 3, "cuda")
+            B.dev()[:] = torch.from_numpy(np.stack(cols, axis=1)).cuda()
+            ksp = KSPSolver(cm, {"ksp_type": "bcgs", "pc_type": "jacobi", "ksp_rtol": 1e-25, "ksp_atol": 1e-300, "ksp_max_it": 50})
+            ksp.setOperators(A)
+            assert ksp._method()[0] == (_lib.KSP_BCGS_MERGED if cm is not None else _lib.KSP_BCGS)
+            X = FieldStorage(nl, 3, "cuda")
+            reasons = ksp.solve_block(B, X)
+            r = ksp.last_result
+            res[tag] = (reasons, list(r.its[:3]), list(r.rnorm[:3]), list(r.bnorm[:3]), list(r.resumed[:3]),
+                        X.dev().cpu().numpy().copy(), x, no)
+        (rp, ip, rnp, bnp, resp, xp, cp, no), (rs, is_, rns, bns, _, xs, cs, _) = res["part"], res["serial"]
+        assert rp == [2, 2, 2] and rs == [2, 2, 2], (rp, rs)
+        for c in range(3):
+            assert rnp[c] <= 1e-25 * bnp[c], (c, rnp, bnp, resp)
+            assert abs(ip[c] - is_[c]) <= 1
+            assert abs(bnp[c] - bns[c]) <= 1e-12 * bns[c]  # the all-reduced norm of b is the serial one
+        kg = _key(cs)
+        og = np.argsort(kg)
+        iu = og[np.searchsorted(kg[og], _key(cp))]
+        assert np.abs(xp - xs[iu]).max() <= 1e-14 * np.abs(xs).max()  # owned AND ghost entries (scatter_forward)
+        out[rank] = (tuple(resp), tuple(ip))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["p2p", "host"])
+def test_partitioned_merged_bicgstab_retests_the_stored_residual(hip, transport):
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_retest_worker, args=(2, _free_port(), transport, out), nprocs=2, join=True)
+    assert len(out) == 2 and out[0] == out[1], dict(out)  # the same re-openings, the same iteration counts on both ranks
+    assert sum(out[0][0]) > 0, dict(out)  # at least one column was re-opened
