@@ -44,6 +44,9 @@ extern "C" {
 #endif
 
 #define OX_KV 2          /* entries of one row stored contiguously (16-B value loads) */
+#define OX_ROW_BLOCK_WAVES 8              /* slices (= waves) per row block of the one-launch assembly kernels        */
+#define OX_ROW_BLOCK_LDS (134 * 1024)     /* bytes of LDS accumulators per row block: 4 slices of 65-entry rows (the
+                                             vertex rows of a P2 box mesh), rows of up to 268 entries               */
 #define OX_SLICE 64      /* rows per slice = wavefront width */
 
 /* KSPConvergedReason values the step functions return (reference ksp.py:78,
@@ -212,6 +215,14 @@ typedef struct {
   const int32_t *bin_width_host;
   const int32_t *bin_slices; /* device [n_slices]                                           */
   const int32_t *widths_host;/* host [n_slices]                                             */
+  /* row blocks of the one-launch assembly (ox_assemble_first_blocks / ox_assemble_matrix_blocks): block b owns the
+   * CONSECUTIVE slices [row_blk_ptr[b], row_blk_ptr[b+1]) -- at most OX_ROW_BLOCK_WAVES of them, their storage slots
+   * together at most OX_ROW_BLOCK_LDS / 8 (greedy, in storage order); row_blk_entries = the largest block's slots
+   * (sizes the launch's LDS).  n_row_blocks = 0: a slice is wider than the budget, use the width bins. */
+  int32_t n_row_blocks;
+  int32_t reserved_rb;
+  const int32_t *row_blk_ptr;/* device [n_row_blocks + 1]                                   */
+  int64_t row_blk_entries;
 } ox_pattern_info;
 
 typedef struct {
@@ -424,6 +435,21 @@ int ox_assemble_first_au(int degree, const ox_cells *cells, const int32_t *cell_
                          const double *u1, const double *b0, double *b_first, double dt, double nu,
                          int n_bins, const int64_t *bin_ptr_host, const int32_t *bin_slices,
                          const int32_t *bin_width_host, void *stream, double *a_u1);
+
+/* The same two in ONE launch over the slices in storage order (round 5): row block b = the consecutive slices
+ * [blk_ptr[b], blk_ptr[b+1]), one per wave of a 512-thread block, accumulators for lds_entries storage slots per block
+ * (ox_pattern_info.n_row_blocks / row_blk_ptr / row_blk_entries).  The width bins send the slices of one length-sort
+ * window -- one compact region of the mesh -- to up to ten launches, each of which fetches that region's cell records
+ * and coefficients again (refined Delaunay mesh: 95.9 GB of HBM traffic per call for ~22 GB of streams); in storage
+ * order the rows of a cell meet in one L2.  Per slice the same operations in the same order: bit-identical results. */
+int ox_assemble_matrix_blocks(int kind, int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                              const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A, int n_blocks,
+                              const int32_t *blk_ptr, int64_t lds_entries, void *stream);
+int ox_assemble_first_blocks(int degree, const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj,
+                             const uint8_t *adj_pos, int pw, const ox_sell *A, const ox_sell *M, const ox_sell *K,
+                             const double *uab, const double *u1, const double *b0, double *b_first, double dt,
+                             double nu, int n_blocks, const int32_t *blk_ptr, int64_t lds_entries, void *stream,
+                             double *a_u1);
 
 /* ---- A6 / A8: assemble_vector(p * v.dx(i) * dx) and (dp.dx(i) * v * dx), all i at once
  *      (fracstep.py:487-497 and :618).  kind 0: out[r][i] = base[r][i] + scale * int p d_i(phi_r)

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OX_LIB_PATH") or os.path.join(_HERE, "liboasisx_hip.so")  # override: tuning builds
 
 KSP_CG, KSP_BCGS, KSP_CG_SINGLE, KSP_BCGS_MERGED, KSP_CG_MERGED = 1, 2, 3, 4, 5
+ROW_BLOCK_WAVES, ROW_BLOCK_LDS = 8, 134 * 1024  # OX_ROW_BLOCK_WAVES / OX_ROW_BLOCK_LDS of include/oasisx_hip.h
 CONVERGED_RTOL, CONVERGED_ATOL, CONVERGED_ITS = 2, 3, 4
 DIVERGED_ITS, DIVERGED_DTOL, DIVERGED_BREAKDOWN, DIVERGED_NANORINF = -3, -4, -5, -9
 
@@ -116,6 +117,10 @@ class ox_pattern_info(C.Structure):
         ("bin_width_host", C.c_void_p),
         ("bin_slices", C.c_void_p),
         ("widths_host", C.c_void_p),
+        ("n_row_blocks", C.c_int32),
+        ("reserved_rb", C.c_int32),
+        ("row_blk_ptr", C.c_void_p),
+        ("row_blk_entries", C.c_int64),
     ]
 
 
@@ -228,6 +233,11 @@ SIGNATURES = {
     "ox_assemble_first_au": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
                                   C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
                                   _D, _I, C.POINTER(_L), _P, C.POINTER(C.c_int32), _P, _P]),
+    "ox_assemble_matrix_blocks": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I, C.POINTER(ox_sell), _I, _P,
+                                       _L, _P]),
+    "ox_assemble_first_blocks": (_I, [_I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _P, _I,
+                                      C.POINTER(ox_sell), C.POINTER(ox_sell), C.POINTER(ox_sell), _P, _P, _P, _P, _D,
+                                      _D, _I, _P, _L, _P, _P]),
     "ox_assemble_grad_vector": (_I, [_I, _I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P,
                                      _P, _D, _P, _P]),
     "ox_assemble_div_vector": (_I, [_I, _I, C.POINTER(ox_cells), _P, C.POINTER(ox_adj), _L, _P, _D,

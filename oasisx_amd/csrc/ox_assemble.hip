@@ -8,6 +8,7 @@
 #include "fe_tables_h.h"
 #include "ox_kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define OX_KIND_MASS 0
 #define OX_KIND_STIFF 1
@@ -202,53 +203,26 @@ struct FirstArgs {
 #define OX_AF_SKIP_EPILOGUE(F) false
 #endif
 
-template <int GDIM, int DEG, int KIND, int PW, bool DICT = false, int U = 1>
-__global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
-                                                       ox_adj adj, const uint8_t *__restrict__ adj_pos,
-                                                       ox_sell A, FirstArgs F,
-                                                       const int32_t *__restrict__ slice_list, int n_list,
-                                                       int bin_width) {
+// Two ways of handing slices to waves:
+//  * width bins (BLK = false): one launch per bin over a LIST of slices of at most `bin_width` entries, 4 waves per block,
+//    accumulators [4][bin_width][64];
+//  * row blocks (BLK = true, round 5): ONE launch over the slices IN STORAGE ORDER; `slice_list` is then blk_ptr
+//    [n_list + 1]: block b owns the consecutive slices [blk_ptr[b], blk_ptr[b+1]) -- at most 8, one per wave, as many
+//    as the launch's LDS holds accumulators for (ox_pattern_info.row_blk_*).  The bins tear the slices of one
+//    length-sort window (= one compact region of the mesh) apart into up to ten launches, each of which fetches that
+//    region's cell records and coefficients again (refined Delaunay mesh, 18.9 M rows: 95.9 GB of HBM traffic per call
+//    for ~22 GB of streams, profiles/r04b_delaunay_pmc_hbm.csv); in storage order the ten rows of a cell pass through
+//    one L2 within a few blocks of each other.  Same per-slice arithmetic either way: bit-identical results.
+// one slice: the (row, cell) pair loop into the wave-private LDS accumulator `acc`, then the epilogue
+template <int GDIM, int DEG, int KIND, int PW, bool DICT, int U>
+__device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int32_t *__restrict__ cell_dofs, const ox_adj &adj,
+                                               const uint8_t *__restrict__ adj_pos, const ox_sell &A, const FirstArgs &F,
+                                               const int slice, double *acc, const int lane, const double *tconv,
+                                               const double *dM, const double *dK) {
   using E = Elem<GDIM, DEG>;
   constexpr int ND = E::ND, NQ = E::NQ, GS = E::GS;
   constexpr int NCB = COMBOS<GDIM, DEG>.n;
-  constexpr int TS = NCB * ND + 2;  // doubles per row dof in LDS: 16 B of padding put the rows of
-                                    // different i on different banks for the 16-byte reads
-  extern __shared__ double acc_all[];  // [4 waves][bin_width][64]
-  __shared__ double dM[DICT ? 256 : 1], dK[DICT ? 256 : 1];
-  __shared__ __attribute__((aligned(16))) double tconv[KIND == OX_KIND_CONV ? ND * TS : 2];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nthr = blockDim.x, nwave = blockDim.x >> 6;  // 4 waves per block, fewer for very wide rows
-  if constexpr (DICT) {
-    for (int i = threadIdx.x; i < F.nMd; i += nthr) dM[i] = F.Md[i];
-    for (int i = threadIdx.x; i < F.nKd; i += nthr) dK[i] = F.Kd[i];
-  }
-  if constexpr (KIND == OX_KIND_CONV) {
-    const double *src = &ct<GDIM, DEG>().t[0][0][0];
-    constexpr int NT = ND * NCB * ND, PER = (NT + 63) / 64;  // loads per thread of a 64-thread block
-    double tv[PER];
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {  // all loads first (one memory round trip), then the LDS writes
-      const int idx = threadIdx.x + r * nthr;
-      tv[r] = idx < NT ? src[idx] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {
-      const int idx = threadIdx.x + r * nthr;
-      if (idx < NT) {
-        const int i = idx / (NCB * ND);
-        tconv[i * TS + (idx - i * NCB * ND)] = tv[r];
-      }
-    }
-  }
-  if constexpr (DICT || KIND == OX_KIND_CONV) __syncthreads();
-  // 4 slices of the bin per block; blocks that share an XCD (equal blockIdx % 8) take one contiguous
-  // eighth of the bin's slices: the rows of a cell (its 4 vertices / 6 edges) then meet in ONE L2
-  // instead of being fetched by up to 8 (r01 PMC: 46.6 GB per assemble_first, every pair re-fetched
-  // its cell; with the chunked order 24.4 GB)
-  const int li = ox_xcd_remap(blockIdx.x, gridDim.x) * nwave + wave;
-  if (li >= n_list) return;
-  double *acc = acc_all + (size_t)wave * bin_width * 64;
-  const int slice = slice_list[li];
+  constexpr int TS = NCB * ND + 2;
   const int64_t base = A.slice_ptr[slice];
   const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
   for (int k = 0; k < width; ++k) acc[k * 64 + lane] = 0.0;
@@ -475,6 +449,69 @@ __global__ __launch_bounds__(256) void k_assemble_rows(ox_cells cells, const int
   }
 }
 
+template <int GDIM, int DEG, int KIND, int PW, bool DICT = false, int U = 1, bool BLK = false>
+__global__ __launch_bounds__(BLK ? 512 : 256) void k_assemble_rows(ox_cells cells, const int32_t *__restrict__ cell_dofs,
+                                                       ox_adj adj, const uint8_t *__restrict__ adj_pos,
+                                                       ox_sell A, FirstArgs F,
+                                                       const int32_t *__restrict__ slice_list, int n_list,
+                                                       int bin_width) {
+  using E = Elem<GDIM, DEG>;
+  constexpr int ND = E::ND;
+  constexpr int NCB = COMBOS<GDIM, DEG>.n;
+  constexpr int TS = NCB * ND + 2;  // doubles per row dof in LDS: 16 B of padding put the rows of
+                                    // different i on different banks for the 16-byte reads
+  extern __shared__ double acc_all[];  // [4 waves][bin_width][64]  (BLK: the row block's slices back to back)
+  __shared__ double dM[DICT ? 256 : 1], dK[DICT ? 256 : 1];
+  __shared__ __attribute__((aligned(16))) double tconv[KIND == OX_KIND_CONV ? ND * TS : 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;  // 4 waves per block, fewer for very wide rows
+  if constexpr (DICT) {
+    for (int i = threadIdx.x; i < F.nMd; i += nthr) dM[i] = F.Md[i];
+    for (int i = threadIdx.x; i < F.nKd; i += nthr) dK[i] = F.Kd[i];
+  }
+  if constexpr (KIND == OX_KIND_CONV) {
+    const double *src = &ct<GDIM, DEG>().t[0][0][0];
+    constexpr int NT = ND * NCB * ND, PER = (NT + 63) / 64;  // loads per thread of a 64-thread block
+    double tv[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {  // all loads first (one memory round trip), then the LDS writes
+      const int idx = threadIdx.x + r * nthr;
+      tv[r] = idx < NT ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int idx = threadIdx.x + r * nthr;
+      if (idx < NT) {
+        const int i = idx / (NCB * ND);
+        tconv[i * TS + (idx - i * NCB * ND)] = tv[r];
+      }
+    }
+  }
+  if constexpr (DICT || KIND == OX_KIND_CONV) __syncthreads();
+  if constexpr (BLK) {
+    // one block per row block; the blocks of one XCD take a contiguous eighth of them.  (A PERSISTENT grid -- one block per
+    // compute unit walking an interleaved share of the row blocks, tables staged once -- was measured and dropped: the
+    // static shares are uneven and every row block ends in a barrier: 128^3 box 7.83 -> 7.98 ms, refined Delaunay mesh
+    // 13.5 -> 16.9 ms.)
+    const int b = ox_xcd_remap(blockIdx.x, gridDim.x);  // (gridDim.x == n_list)
+    const int s0 = slice_list[b];
+    const int slice = s0 + wave;
+    if (slice >= slice_list[b + 1]) return;
+    // (consecutive slices: the entries before this one)
+    assemble_slice<GDIM, DEG, KIND, PW, DICT, U>(cells, cell_dofs, adj, adj_pos, A, F, slice,
+                                                 acc_all + (A.slice_ptr[slice] - A.slice_ptr[s0]), lane, tconv, dM, dK);
+  } else {
+    // 4 slices of the bin per block; blocks that share an XCD (equal blockIdx % 8) take one contiguous
+    // eighth of the bin's slices: the rows of a cell (its 4 vertices / 6 edges) then meet in ONE L2
+    // instead of being fetched by up to 8 (r01 PMC: 46.6 GB per assemble_first, every pair re-fetched
+    // its cell; with the chunked order 24.4 GB)
+    const int li = ox_xcd_remap(blockIdx.x, gridDim.x) * nwave + wave;
+    if (li >= n_list) return;
+    assemble_slice<GDIM, DEG, KIND, PW, DICT, U>(cells, cell_dofs, adj, adj_pos, A, F, slice_list[li],
+                                                 acc_all + (size_t)wave * bin_width * 64, lane, tconv, dM, dK);
+  }
+}
+
 template <int GDIM, int DEG, int KIND, int PW, bool DICT = false>
 static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj,
                          const uint8_t *adj_pos, const ox_sell *A, const FirstArgs &F, int n_bins,
@@ -529,6 +566,41 @@ static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const 
     if (rc) return rc;
   }
   return 0;
+}
+
+// row-block launch (k_assemble_rows<..., BLK = true>): one launch, 8 waves per block
+template <int GDIM, int DEG, int KIND, int PW, bool DICT = false>
+static int launch_row_blocks_t(const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj, const uint8_t *adj_pos,
+                               const ox_sell *A, const FirstArgs &F, int n_blocks, const int32_t *blk_ptr, int64_t lds_entries,
+                               hipStream_t st) {
+  if constexpr (KIND == OX_KIND_CONV && !DICT) {
+    if (F.Mc && F.Kc && F.Md && F.Kd && F.nMd >= 1 && F.nMd <= 256 && F.nKd >= 1 && F.nKd <= 256)
+      return launch_row_blocks_t<GDIM, DEG, KIND, PW, true>(cells, cell_dofs, adj, adj_pos, A, F, n_blocks, blk_ptr, lds_entries, st);
+  }
+  if (n_blocks <= 0) return 0;
+  const size_t lds = (size_t)lds_entries * sizeof(double);
+  if (lds > OX_ROW_BLOCK_LDS) OX_FAIL("assemble: a row block needs %zu B of LDS (limit %d)", lds, OX_ROW_BLOCK_LDS);
+  auto kern = k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1, true>;
+  if (lds > 32 * 1024)
+    OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(512), lds, st, *cells, cell_dofs, *adj, adj_pos, *A, F, blk_ptr,
+                     n_blocks, 0);
+  OX_LAUNCH_CHECK();
+  return 0;
+}
+template <int KIND>
+static int launch_row_blocks(int degree, const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj,
+                             const uint8_t *adj_pos, int pw, const ox_sell *A, const FirstArgs &F, int n_blocks,
+                             const int32_t *blk_ptr, int64_t lds_entries, hipStream_t st) {
+  const int g = cells->gdim;
+#define OX_ROWS_CASE(GD, DG, P)                                                                                       \
+  if (g == GD && degree == DG) {                                                                                      \
+    if (pw != P) OX_FAIL("assemble: adj_pos stride %d, expected %d", pw, P);                                          \
+    return launch_row_blocks_t<GD, DG, KIND, P>(cells, cell_dofs, adj, adj_pos, A, F, n_blocks, blk_ptr, lds_entries, st); \
+  }
+  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16)
+#undef OX_ROWS_CASE
+  OX_FAIL("assemble: unsupported gdim=%d degree=%d", g, degree);
 }
 
 template <int KIND>
@@ -601,6 +673,45 @@ extern "C" int ox_assemble_first(int degree, const ox_cells *cells, const int32_
                                  void *stream) {
   return ox_assemble_first_au(degree, cells, cell_dofs, adj, adj_pos, pw, A, M, K, uab, u1, b0, b_first, dt, nu, n_bins,
                               bin_ptr_host, bin_slices, bin_width_host, stream, nullptr);
+}
+
+extern "C" int ox_assemble_matrix_blocks(int kind, int degree, const ox_cells *cells, const int32_t *cell_dofs,
+                                         const ox_adj *adj, const uint8_t *adj_pos, int pw, const ox_sell *A, int n_blocks,
+                                         const int32_t *blk_ptr, int64_t lds_entries, void *stream) {
+  if (!cells || !cell_dofs || !adj || !adj_pos || !A || (n_blocks > 0 && !blk_ptr)) OX_FAIL("ox_assemble_matrix_blocks: null argument");
+  FirstArgs F{};
+  hipStream_t st = ox_stream(stream);
+  if (kind == OX_KIND_MASS)
+    return launch_row_blocks<OX_KIND_MASS>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_blocks, blk_ptr, lds_entries, st);
+  if (kind == OX_KIND_STIFF)
+    return launch_row_blocks<OX_KIND_STIFF>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_blocks, blk_ptr, lds_entries, st);
+  OX_FAIL("ox_assemble_matrix_blocks: kind=%d", kind);
+}
+
+extern "C" int ox_assemble_first_blocks(int degree, const ox_cells *cells, const int32_t *cell_dofs, const ox_adj *adj,
+                                        const uint8_t *adj_pos, int pw, const ox_sell *A, const ox_sell *M, const ox_sell *K,
+                                        const double *uab, const double *u1, const double *b0, double *b_first, double dt,
+                                        double nu, int n_blocks, const int32_t *blk_ptr, int64_t lds_entries, void *stream,
+                                        double *a_u1) {
+  if (!cells || !cell_dofs || !adj || !adj_pos || !A || !M || !K || !M->vals || !K->vals || !uab || !u1 || !b0 ||
+      !b_first || (n_blocks > 0 && !blk_ptr))
+    OX_FAIL("ox_assemble_first_blocks: null argument");
+  if (M->slice_ptr != A->slice_ptr || K->slice_ptr != A->slice_ptr)
+    OX_FAIL("ox_assemble_first: M, K and A must share one sparsity pattern");
+  if (!(dt > 0.0)) OX_FAIL("ox_assemble_first: dt=%g", dt);
+  FirstArgs F{M->vals, K->vals, uab, u1, b0, b_first, a_u1, 1.0 / dt, nu,
+              M->vcode, K->vcode, M->vdict, K->vdict, M->n_dict, K->n_dict};
+#ifdef OX_DIAG
+  {
+    const char *e = getenv("OX_AF_DBG");
+    F.dbg = e ? atoi(e) : 0;
+  }
+#endif
+  if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
+  const int rc = launch_row_blocks<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_blocks, blk_ptr, lds_entries,
+                                                 ox_stream(stream));
+  if (ox_prof_on) ox_prof_stop(ox_stream(stream));
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -521,6 +521,11 @@ __global__ __launch_bounds__(256) void k_slice_sizes(const int32_t *__restrict__
   }
 }
 
+// (Round 5 tried LENGTH CLASSES here -- lengths within a factor 1 + 2^-s share a sort key, so that the stable sort keeps
+// the rows of a class in their order along the locality curve and a slice holds mesh neighbours --: on the refined Delaunay
+// mesh of the bench, whose rows take few distinct lengths, s = 3 shrank the mean column window of a window block from 3093
+// to 2847 entries for 0.85 % more padding and moved neither assemble_first (13.7 ms) nor the mat-vecs by more than 3 %;
+// s >= 4 changed nothing.  Removed again: profiles/r05_assemble_row_blocks.txt.)
 __global__ __launch_bounds__(256) void k_window_keys(const int32_t *__restrict__ len, int64_t n, int window, int lmax,
                                                      uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -587,6 +592,10 @@ struct ox_pattern_store {  // SELL-64 pattern + 16-bit stream + width bins
   DevBuf slice_ptr, cols, row_len, cols16, cbase, bin_slices;
   std::vector<int32_t> widths, bin_width;
   std::vector<int64_t> bin_ptr;
+  // row blocks of the one-launch assembly kernels (include/oasisx_hip.h: ox_pattern_info.row_blk_*)
+  DevBuf row_blk_ptr;
+  int32_t n_row_blocks = 0;
+  int64_t row_blk_entries = 0;
 };
 
 struct ox_space {
@@ -715,6 +724,31 @@ int finish_pattern(ox_pattern_store &P, hipStream_t st) {
   OX_TRY(P.bin_slices.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(P.n_slices, 1)));
   if (P.n_slices)
     OX_HIP(hipMemcpyAsync(P.bin_slices.p, order.data(), sizeof(int32_t) * (size_t)P.n_slices, hipMemcpyHostToDevice, st));
+  // row blocks: consecutive slices in storage order, greedily, at most OX_ROW_BLOCK_WAVES per block and
+  // OX_ROW_BLOCK_LDS bytes of accumulators (fem.row_blocks is the torch twin)
+  std::vector<int32_t> blk(1, 0);
+  {
+    const int64_t cap = OX_ROW_BLOCK_LDS / (int64_t)sizeof(double);
+    int64_t used = 0, big = 0;
+    int cnt = 0;
+    bool fits = true;
+    for (int64_t s = 0; s < P.n_slices; ++s) {
+      const int64_t e = (int64_t)P.widths[s] * SLICE;
+      if (e > cap) fits = false;
+      if (cnt == OX_ROW_BLOCK_WAVES || used + e > cap) {
+        blk.push_back((int32_t)s);
+        used = 0, cnt = 0;
+      }
+      used += e, ++cnt;
+      big = std::max(big, used);
+    }
+    if (P.n_slices) blk.push_back((int32_t)P.n_slices);
+    if (!fits) blk.assign(1, 0), big = 0;  // a row wider than the budget: the width bins serve this pattern
+    P.n_row_blocks = (int32_t)blk.size() - 1;
+    P.row_blk_entries = big;
+  }
+  OX_TRY(P.row_blk_ptr.alloc(sizeof(int32_t) * blk.size()));
+  OX_HIP(hipMemcpyAsync(P.row_blk_ptr.p, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice, st));
   OX_HIP(hipStreamSynchronize(st));
   return 0;
 }
@@ -1192,6 +1226,7 @@ static void fill_pattern_view(const ox_pattern_store &P, ox_pattern_info *v) {
   v->bin_ptr_host = P.bin_ptr.data(), v->bin_width_host = P.bin_width.data();
   v->bin_slices = P.bin_slices.as<int32_t>();
   v->widths_host = P.widths.data();
+  v->n_row_blocks = P.n_row_blocks, v->row_blk_ptr = P.row_blk_ptr.as<int32_t>(), v->row_blk_entries = P.row_blk_entries;
 }
 
 extern "C" int ox_space_view(const ox_space *V, ox_space_info *v) {

@@ -194,10 +194,31 @@ def merge_small_bins(bin_width: np.ndarray, bin_ptr: np.ndarray):
     return np.asarray(bw, dtype=np.int32), np.asarray(bp, dtype=np.int64)
 
 
+def row_blocks(widths: np.ndarray):
+    """Row blocks of the one-launch assembly kernels (``ox_assemble_first_blocks``; the library's twin: finish_pattern):
+    consecutive slices in storage order, greedily, at most ROW_BLOCK_WAVES per block and ROW_BLOCK_LDS bytes of LDS
+    accumulators (width * 64 doubles per slice).  Returns (blk_ptr int32 [n_blocks + 1], entries of the largest block);
+    no blocks at all when one slice alone exceeds the budget (the width bins serve such a pattern)."""
+    cap = _lib.ROW_BLOCK_LDS // 8
+    blk, used, cnt, big = [0], 0, 0, 0
+    for s_, w in enumerate(np.asarray(widths, dtype=np.int64)):
+        e = int(w) * SLICE
+        if e > cap:
+            return np.zeros(1, dtype=np.int32), 0
+        if cnt == _lib.ROW_BLOCK_WAVES or used + e > cap:
+            blk.append(s_)
+            used, cnt = 0, 0
+        used, cnt = used + e, cnt + 1
+        big = max(big, used)
+    if len(widths):
+        blk.append(len(widths))
+    return np.asarray(blk, dtype=np.int32), int(big)
+
+
 class SellPattern:
     """SELL-64 sparsity pattern shared by every matrix on one (row space, col space)."""
 
-    def __init__(self, n_rows, n_cols, slice_ptr, cols, row_len, widths, nnz=None):
+    def __init__(self, n_rows, n_cols, slice_ptr, cols, row_len, widths, nnz=None, row_blk=None):
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.slice_ptr = slice_ptr  # int64 [n_slices+1] device
         self.cols = cols  # int32 device
@@ -219,6 +240,17 @@ class SellPattern:
         self.bin_width, self.bin_ptr = merge_small_bins(uw.numpy().astype(np.int32),
                                                         np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64))
         self.bin_slices = order.to(torch.int32).to(self.device)
+        # row blocks of the one-launch assembly kernels: (device blk_ptr, largest block's entries); the library's own when
+        # it built the pattern (native.pattern_from_info), else the twin
+        if row_blk is None:
+            bp, big = row_blocks(widths)
+            row_blk = (torch.from_numpy(bp).to(self.device), big)
+        self.row_blk_ptr, self.row_blk_entries = row_blk
+        self.n_row_blocks = int(self.row_blk_ptr.shape[0]) - 1
+
+    def blocks_args(self):
+        """(n_blocks, blk_ptr, lds_entries) of ``ox_assemble_first_blocks`` / ``ox_assemble_matrix_blocks``."""
+        return self.n_row_blocks, _lib.ptr(self.row_blk_ptr), int(self.row_blk_entries)
 
     def split_interior(self, n_owned: int):
         """Mesh-partitioned operators: list the slices with the interior ones first (no ghost column,

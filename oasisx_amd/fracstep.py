@@ -138,6 +138,13 @@ class FractionalStep_AB_CN:
             and (not lattice or (part is None and u_deg >= 2))
         self._spmv_windows = windows
         self._lattice = lattice
+        # options["assemble_row_blocks"]: the row kernels -- assemble_first, M, K, Ap -- run as ONE launch over the slices in
+        # storage order (ox_assemble_first_blocks) instead of one launch per width bin; bit-identical either way.
+        # Default: on for meshes that are not lattices (refined Delaunay mesh at the bench size: nine bins, 95.9 GB of
+        # HBM traffic and 18.3 ms per assemble_first -> one launch, 31.9 GB, 13.5 ms); off on lattice meshes, whose
+        # three bins re-fetch little (24.6 GB) and whose LDS-filling blocks pay the dispatch gap between row blocks
+        # (128^3: 7.44 ms with the bins, 7.83 ms in one launch; tools/af_bench.py, profiles/r05_assemble_row_blocks.txt)
+        self._row_blocks = bool((options or {}).get("assemble_row_blocks", not lattice))
         Vi = u_element if isinstance(u_element, FunctionSpace) else FunctionSpace(mesh, u_deg, window=window, part=part,
                                                                                   brick=windows and lattice)
         if isinstance(p_element, FunctionSpace):
@@ -267,11 +274,18 @@ class FractionalStep_AB_CN:
         self._Ap = SellMatrix(Q.pattern, symmetric=True, name="Ap")
 
     def _assemble_matrix(self, kind, V: FunctionSpace, adj_struct, Mat: SellMatrix):
-        nb, bptr, bsl, bw = V.pattern.bins_args()
-        _lib.check(self._lib.ox_assemble_matrix(kind, V.degree, C.byref(self._cells), _lib.ptr(V.cell_dofs),
-                                                C.byref(adj_struct), _lib.ptr(V.adj.adj_pos), V.adj.pw,
-                                                Mat.ref(), nb, bptr, bsl, bw, _lib.current_stream()),
-                   "ox_assemble_matrix")
+        if self._row_blocks and V.pattern.n_row_blocks > 0:  # one launch over the slices in storage order
+            nblk, bptr, ent = V.pattern.blocks_args()
+            _lib.check(self._lib.ox_assemble_matrix_blocks(kind, V.degree, C.byref(self._cells), _lib.ptr(V.cell_dofs),
+                                                           C.byref(adj_struct), _lib.ptr(V.adj.adj_pos), V.adj.pw,
+                                                           Mat.ref(), nblk, bptr, ent, _lib.current_stream()),
+                       "ox_assemble_matrix_blocks")
+        else:
+            nb, bptr, bsl, bw = V.pattern.bins_args()
+            _lib.check(self._lib.ox_assemble_matrix(kind, V.degree, C.byref(self._cells), _lib.ptr(V.cell_dofs),
+                                                    C.byref(adj_struct), _lib.ptr(V.adj.adj_pos), V.adj.pw,
+                                                    Mat.ref(), nb, bptr, bsl, bw, _lib.current_stream()),
+                       "ox_assemble_matrix")
         Mat.version += 1
 
     def _preassemble(self):
@@ -337,7 +351,6 @@ class FractionalStep_AB_CN:
         # u_ab = 1.5 u_1 - 0.5 u_2 (:432-434)
         _lib.check(lib.ox_axpby(n, 1.5, self._U1.rptr(), -0.5, self._U2.rptr(), self._UAB.ptr(), st), "ox_axpby")
         Vi = self._Vi[0][0]
-        nb, bptr, bsl, bw = Vi.pattern.bins_args()
         # With a nonzero initial guess the tentative solve starts from u (= u1 bit for bit unless someone
         # wrote to it since the last step): its first mat-vec A @ u1 falls out of the fused kernel's
         # epilogue (same entry order and operations as the SpMV).  Kept in the block of b3, free until
@@ -345,12 +358,24 @@ class FractionalStep_AB_CN:
         self._AU1_valid = False
         want_au = bool(self._solver_u._options.get("ksp_initial_guess_nonzero", False)) and \
             str(self._solver_u._options.get("ksp_type", "")).lower() != "preonly"
-        _lib.check(lib.ox_assemble_first_au(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
-                                            C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
-                                            self._A.ref(), self._M.ref(), self._K.ref(),
-                                            self._UAB.rptr(), self._U1.rptr(), self._B0.rptr(), self._BFIRST.ptr(),
-                                            float(dt), float(nu), nb, bptr, bsl, bw, st,
-                                            self._B3.ptr() if want_au else None), "ox_assemble_first")
+        if self._row_blocks and Vi.pattern.n_row_blocks > 0:
+            # ONE launch over the slices in storage order (round 5): the rows of a cell meet in one L2 instead of being
+            # torn apart into the launches of up to ten width bins (options["assemble_row_blocks"]; bit-identical)
+            nblk, bptr, ent = Vi.pattern.blocks_args()
+            _lib.check(lib.ox_assemble_first_blocks(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
+                                                    C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
+                                                    self._A.ref(), self._M.ref(), self._K.ref(),
+                                                    self._UAB.rptr(), self._U1.rptr(), self._B0.rptr(), self._BFIRST.ptr(),
+                                                    float(dt), float(nu), nblk, bptr, ent, st,
+                                                    self._B3.ptr() if want_au else None), "ox_assemble_first_blocks")
+        else:
+            nb, bptr, bsl, bw = Vi.pattern.bins_args()
+            _lib.check(lib.ox_assemble_first_au(Vi.degree, C.byref(self._cells), _lib.ptr(Vi.cell_dofs),
+                                                C.byref(self._adj_u), _lib.ptr(Vi.adj.adj_pos), Vi.adj.pw,
+                                                self._A.ref(), self._M.ref(), self._K.ref(),
+                                                self._UAB.rptr(), self._U1.rptr(), self._B0.rptr(), self._BFIRST.ptr(),
+                                                float(dt), float(nu), nb, bptr, bsl, bw, st,
+                                                self._B3.ptr() if want_au else None), "ox_assemble_first")
         self._A.version += 1
         # outlet terms int h n_i dv/dx_i ds (:445-446, :461-465)
         for bcp in self._bcs_p:

@@ -91,7 +91,9 @@ def pattern_from_info(P, owner, device, SellPattern):
     cols = dev_tensor(P.sell.cols, (int(P.size),), torch.int32, owner, device)
     row_len = dev_tensor(P.row_len, (int(P.sell.n_rows),), torch.int32, owner, device)
     widths = host_array(P.widths_host, ns, C.c_int32, np.int32)
-    pat = SellPattern(int(P.sell.n_rows), int(P.sell.n_cols), slice_ptr, cols, row_len, widths, nnz=int(P.nnz))
+    row_blk = (dev_tensor(P.row_blk_ptr, (int(P.n_row_blocks) + 1,), torch.int32, owner, device), int(P.row_blk_entries))
+    pat = SellPattern(int(P.sell.n_rows), int(P.sell.n_cols), slice_ptr, cols, row_len, widths, nnz=int(P.nnz),
+                      row_blk=row_blk)
     if P.size > 0 and P.sell.cols16:
         pat.cols16 = dev_tensor(P.sell.cols16, (int(P.size),), torch.int16, owner, device)
         pat.cbase = dev_tensor(P.sell.cbase, (2 * (int(P.size) // 128),), torch.int32, owner, device)
