@@ -247,6 +247,25 @@ def make_workload(name, N, np, torch):
     return {"nu": nu, "dt": dt, "box": box, "fns": fns, "p": pres, "desc": desc, "analytic": name != "cavity"}
 
 
+def predicted_line(args, world):
+    """What profiles/r05_predicted_scaling.json predicted for this workload, mesh size and rank count (None: no prediction
+    on file for it).  A PREDICTION made from one-GPU measurements (tools/predict_scaling.py), never a measurement."""
+    if args.workload != "tg" or args.mesh != "box" or args.udeg != 2:
+        return None
+    try:
+        path = os.path.join(ROOT, "profiles", "r05_predicted_scaling.json")
+        for line in open(path).read().splitlines():
+            d = json.loads(line)
+            if f"{args.N}^3" in d.get("workload", "") and str(world) in d.get("P", {}):
+                e = d["P"][str(world)]
+                return {"label": d["label"], "steps_per_s": e["steps_per_s"], "ms_per_step": e["ms_per_step"],
+                        "phases_ms": e["phases_ms"], "parallel_efficiency": e.get("parallel_efficiency"),
+                        "assumed": d["assumed"], "source": "profiles/r05_predicted_scaling.json"}
+    except Exception:
+        return None
+    return None
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher (no WORLD_SIZE in the environment): this process -- which has
     not touched the GPU -- starts the driver's own N > 1 command line as a CHILD process (one rank per GPU under
@@ -815,8 +834,15 @@ def main():
         transport_us = {"velocity_space": comm.time_transports(S._Vi[0][0]), "pressure_space": comm.time_transports(S._Q)}
     nnz_glob = [Pu.nnz, Pp.nnz]
     per_rank = None
+    phase_ms_max = None
     if world > 1:
         import torch.distributed as dist
+
+        # per phase the SLOWEST rank's device time: what the step waits for, and what tools/predict_scaling.py predicts
+        names = sorted(phase_ms)
+        tp = torch.tensor([phase_ms[k] for k in names], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        phase_ms_max = {k: float(v) for k, v in zip(names, tp.tolist())}
 
         tn = torch.tensor(nnz_glob, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tn)
@@ -878,6 +904,10 @@ def main():
             # ITS OWN rtol like any column, as PETSc's per-component solves would
             "krylov_last_solve": last_solves(),
             "phase_ms_per_step": phase_ms,  # device time between events around each phase method (rank 0)
+            "phase_ms_per_step_max_over_ranks": phase_ms_max,  # N > 1: the slowest rank per phase
+            # the PREDICTED line for this rank count (tools/predict_scaling.py: one-GPU measurements of every rank's local
+            # work + a modelled link; committed BEFORE any multi-GPU run) -- laid beside the measurement above
+            "prediction": predicted_line(args, world),
             # whole Jacobi-CG iteration of the pressure solve (SpMV + vector kernels + scalar kernels)
             "pressure_cg_iteration": piter_line,
             "accuracy": {"max_nodal_error_u_vs_analytic": err_u, "max_abs_u": umax, "t_end": clock["t"]},

@@ -17,7 +17,7 @@
  *   - multi-component vectors are interleaved: v[row*ncomp + comp];
  *   - process model: ONE process per GPU and ONE call at a time per process.  The library keeps
  *     per-process scratch (the reduction scratch of ox_dot / ox_remove_mean, the pinned copy of the
- *     Krylov state and of the fold table of ox_ksp_solve, the SpMV variant switch, the profiler's event
+ *     Krylov state of ox_ksp_solve, the profiler's event
  *     list): two host threads calling in concurrently, or two solves in flight on different streams, would
  *     share it.  This is the reference's model too (one PETSc solve at a time per MPI rank);
  *   - an x handed to ox_spmv / ox_ksp_solve on a matrix with a pair-slot stream (ps_*) must be FINITE in
@@ -149,7 +149,15 @@ typedef struct {
                                 its value dictionary: ox_window_retile)                                    */
   int32_t n_wblocks;         /* 0: no window stream                                                      */
   int32_t w_max;             /* largest window (entries)                                                 */
+  /* per-matrix schedule knobs of the mat-vec (results never depend on them: every storage level multiplies the same
+   * entries in the same order).  0 = the library's defaults */
+  int32_t levels;            /* storage levels ox_spmv may use on THIS matrix: OX_SPMV_LEVELS(mask) with mask bit 0
+                                nontemporal matrix stream, 1 the 16-bit column stream, 2 the 1-byte value codes, 3 the
+                                pair-slot stream, 4 the LDS-window stream -- each where the matrix carries it; 0 = all */
+  int32_t w_cap;             /* LDS-window stream: window entries the launch holds in LDS (0 = 6144 / 3072 / 2176 for
+                                1 / 2 / 3 right-hand sides); a block whose window is larger multiplies from `cols`  */
 } ox_sell;
+#define OX_SPMV_LEVELS(mask) (32 | ((mask) & 31))
 
 /* Cells of the mesh as the element kernels read them. */
 typedef struct {
@@ -542,8 +550,6 @@ int ox_remove_mean(int64_t n, int64_t n_apply, double *x, const double *w, doubl
 /* ---- measurement: per-kernel HIP-event timing on the launching stream (bench.py) ------- */
 /* tags: 10*ncomp+epi for SpMV (epi 0 plain, 1 CG p.q, 2/3 BiCGStab), 100 assemble_first,
  * 110/111 grad vectors, 120 div vector. */
-int ox_set_spmv_variant(int v); /* A/B switch of the SpMV micro-benchmark (tools/spmv_bench.py):
-                                   1 = nontemporal matrix loads (default), 0 = plain loads */
 /* One-column CG on one GPU folds the iteration's synchronisation points into its update kernels (3 kernels per iteration
  * instead of 5; replaces nothing in the reference: its PETSc KSPCG has the same two reductions, ksp.py:71-78).  The number of
  * 1024-thread blocks those kernels run is a per-solve option (ox_ksp_options.fold_blocks); this is the library's default
@@ -592,6 +598,11 @@ int ox_p2p_window_free(void *win_dev);
 int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wins, const int64_t *peer_recv_off,
                        const int64_t *peer_n_ghost, double timeout_s);
 int ox_dist_p2p_timeout(ox_dist *d, double timeout_s); /* change the bound of the peer waits */
+/* The plan's distributed mat-vecs: 1 = start the halo exchange, multiply the interior slices while it is in flight, the
+ * boundary slices after it has landed; 0 = exchange, then multiply; -1 = the transport's default (overlap on the xGMI
+ * windows and the callback transports, off on RCCL plans until the side-stream send/recv has run between two real GPUs).
+ * What DOLFINx/PETSc do inside MatMult (reference fracstep.py:453,497,632); never changes a result. */
+int ox_dist_set_overlap(ox_dist *d, int overlap);
 int ox_dist_disable_p2p(ox_dist *d);
 int ox_dist_status(const ox_dist *d);
 /* Same plan on a caller-supplied transport instead of RCCL (rehearsals on one GPU, other

@@ -50,6 +50,8 @@ class ox_sell(C.Structure):
         ("wvcode", C.c_void_p),
         ("n_wblocks", C.c_int32),
         ("w_max", C.c_int32),
+        ("levels", C.c_int32),
+        ("w_cap", C.c_int32),
     ]
 
 
@@ -254,7 +256,6 @@ SIGNATURES = {
                              C.c_size_t, C.POINTER(ox_ksp_result), _P, _P, _P, _P, _P, _I]),
     "ox_remove_mean": (_I, [_L, _L, _P, _P, _D, _P, _P]),
     "ox_window_retile": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
-    "ox_set_spmv_variant": (_I, [_I]),
     "ox_ksp_default_fold_blocks": (_I, []),
     "ox_ksp_kernels_per_iteration": (_I, [_I, C.POINTER(ox_sell), _I, _I, _I, _I]),
     "ox_ksp_options_default": (_I, [C.POINTER(ox_ksp_options)]),
@@ -280,6 +281,7 @@ SIGNATURES = {
     "ox_dist_enable_p2p": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_L), C.POINTER(_L), _D]),
     "ox_dist_p2p_timeout": (_I, [_P, _D]),
     "ox_dist_disable_p2p": (_I, [_P]),
+    "ox_dist_set_overlap": (_I, [_P, _I]),
     "ox_dist_status": (_I, [_P]),
     "ox_dist_create_custom": (_I, [_I, _I, _I, C.POINTER(C.c_int32), C.POINTER(_L), _P, C.POINTER(_L), _L, _L,
                                    _P, _P, _P, C.POINTER(_P)]),

@@ -522,31 +522,18 @@ static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const 
       return launch_rows_t<GDIM, DEG, KIND, PW, true>(cells, cell_dofs, adj, adj_pos, A, F, n_bins, bin_ptr,
                                                       bin_slices, bin_width, st);
   }
-  // pairs in flight per lane (see the kernel): OX_ASSEMBLE_U overrides (tuning)
-  static int u_env = -1;
-  if (u_env < 0) {
-    const char *e = getenv("OX_ASSEMBLE_U");
-    u_env = e ? atoi(e) : 0;
-  }
   for (int b = 0; b < n_bins; ++b) {
     const int64_t cnt = bin_ptr[b + 1] - bin_ptr[b];
     if (cnt <= 0) continue;
     // wave-private accumulators [width][64]; 4 waves per block unless the rows are so wide (unstructured
     // meshes: > 70 entries) that fewer fit beside the 17 KB of tables
-    static int nw_env = -1;
-    if (nw_env < 0) {
-      const char *e = getenv("OX_ASSEMBLE_NW");
-      nw_env = e ? atoi(e) : 0;
-    }
-    int nw = (nw_env == 1 || nw_env == 2 || nw_env == 4) ? nw_env : 4;
+    int nw = 4;
     while (nw > 1 && (size_t)nw * bin_width[b] * 64 * sizeof(double) > 140 * 1024) nw >>= 1;
     const size_t lds = (size_t)nw * bin_width[b] * 64 * sizeof(double);
     if (lds > 140 * 1024) OX_FAIL("assemble: row width %d needs %zu B of LDS", bin_width[b], lds);
-    // wide rows = many cells per row and one wave per SIMD: 3 pairs in flight; narrow rows: 2
-    // measured at 128^3 (tools/af_bench.py): U = 1 7.7 ms, 2: 9.0, 3: 9.3 -- the pair loop is bound by the
-    // address unit (every lane gathers from a different cell: ~30 divergent loads per pair), not by latency
-    int U = 1;
-    if (KIND == OX_KIND_CONV && u_env >= 1 && u_env <= 3) U = u_env;
+    // (U = 2 / 3 (row, cell) pairs in flight per lane were measured at 128^3 -- 9.0 / 9.3 ms against 7.7 with one: the
+    // pair loop is bound by the texture path, every lane gathering from another cell, not by latency -- and their
+    // instantiations and the OX_ASSEMBLE_U / OX_ASSEMBLE_NW tuning switches removed in round 5)
     auto go = [&](auto kern) -> int {
       if (lds > 32 * 1024)
         OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -556,13 +543,7 @@ static int launch_rows_t(const ox_cells *cells, const int32_t *cell_dofs, const 
       OX_LAUNCH_CHECK();
       return 0;
     };
-    int rc;
-    if constexpr (KIND == OX_KIND_CONV) {
-      rc = U == 3 ? go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 3>)
-                  : (U == 2 ? go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 2>) : go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1>));
-    } else {
-      rc = go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1>);
-    }
+    const int rc = go(k_assemble_rows<GDIM, DEG, KIND, PW, DICT, 1>);
     if (rc) return rc;
   }
   return 0;

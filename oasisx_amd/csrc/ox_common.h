@@ -65,6 +65,7 @@ struct ox_dist {
   // RCCL transport, overlapped exchange: the pack + send/recv run on a side stream between two events
   hipStream_t side;
   hipEvent_t ev_begin, ev_done;
+  int overlap;  // ox_dist_set_overlap: -1 the transport's default, 0 / 1 exchange-then-multiply / overlapped mat-vecs
 };
 
 // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give every XCD a

@@ -65,6 +65,7 @@ extern "C" int ox_dist_create(void *comm, int rank, int nranks, int n_peers, con
   ox_dist *d = static_cast<ox_dist *>(calloc(1, sizeof(ox_dist)));
   if (!d) OX_FAIL("ox_dist_create: out of memory");
   d->comm = comm;
+  d->overlap = -1;
   d->rank = rank;
   d->nranks = nranks;
   d->n_peers = n_peers;
@@ -251,6 +252,12 @@ extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wi
 extern "C" int ox_dist_p2p_timeout(ox_dist *d, double timeout_s) {
   if (!d || !d->p2p) OX_FAIL("ox_dist_p2p_timeout: the plan has no xGMI transport");
   d->p2p->timeout_ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);
+  return 0;
+}
+
+extern "C" int ox_dist_set_overlap(ox_dist *d, int overlap) {
+  if (!d) OX_FAIL("ox_dist_set_overlap: null plan");
+  d->overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
   return 0;
 }
 

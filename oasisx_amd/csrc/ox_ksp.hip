@@ -106,19 +106,12 @@ __device__ __forceinline__ void ksp_block_sum_t(double (&v)[NVT], int nv, double
   }
 }
 
-template <int PH>
-__global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
-                                                               const double *__restrict__ partial,
-                                                               int nparts, int nv, KspParams P, KspPart2 B) {
-  // (the merged-reduction CG is a one-column solver: 3 + 2 sums)
-  constexpr int NVT = PH == PH_CGM_IT ? ksp_ph_nv(PH) : ksp_ph_nv(PH) * OX_MAXC;
-  __shared__ double red[16 * NVT];
-  __shared__ double sums[NVT];
-  __shared__ KspState sh;
-  // state and partials are loaded in ONE memory round trip; the done flag is looked at afterwards
-  // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
-  ksp_state_load(&sh, S);
-  double v[NVT];
+// The sums of one synchronisation point: this thread's share of the partial rows (and of the point's second array B),
+// then the block tree.  Register arrays sized by the phase (NVT = ksp_ph_nv * columns): OX_MAX_NV-wide ones spill in a
+// 1024-thread block (16 us instead of 5).  Returns the number of sums; they are valid in thread 0.
+template <int PH, int NVT>
+__device__ __forceinline__ int ksp_point_sums(const double *__restrict__ partial, int nparts, int nv, const KspPart2 &B,
+                                              double (&v)[NVT], double *red /* [16 * NVT] */) {
   if constexpr (PH == PH_CGM_IT) {
     // 8 392 x 2 partial sums of the pressure mat-vec at 128^3: every thread's rows requested in ONE round (the
     // generic gather keeps 4 rows in flight)
@@ -145,7 +138,26 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
         if (j == i - nv && j < B.nv) v[i] = w[j];
   }
   nv += B.nv;
-  ksp_block_sum_t<NVT>(v, nv, red);  // contains a __syncthreads(): sh is complete after it
+  ksp_block_sum_t<NVT>(v, nv, red);  // contains a __syncthreads()
+  return nv;
+}
+// (the merged-reduction CG is a one-column solver: 3 + 2 sums)
+template <int PH>
+constexpr int ksp_nvt() { return PH == PH_CGM_IT ? ksp_ph_nv(PH) : ksp_ph_nv(PH) * OX_MAXC; }
+
+template <int PH>
+__global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
+                                                               const double *__restrict__ partial,
+                                                               int nparts, int nv, KspParams P, KspPart2 B) {
+  constexpr int NVT = ksp_nvt<PH>();
+  __shared__ double red[16 * NVT];
+  __shared__ double sums[NVT];
+  __shared__ KspState sh;
+  // state and partials are loaded in ONE memory round trip; the done flag is looked at afterwards
+  // (a leading `if (S->done) return` costs a dependent round trip of its own, ~1 us per launch)
+  ksp_state_load(&sh, S);
+  double v[NVT];
+  ksp_point_sums<PH, NVT>(partial, nparts, nv, B, v, red);  // contains a __syncthreads(): sh is complete after it
   if (!ksp_is_init(PH) && sh.done) {  // uniform: the state stays as it is; the host's copy of it is still due
     if (P.mirror) ksp_state_store(P.mirror, &sh);
     return;
@@ -161,6 +173,24 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar(KspState *S,
   if (P.mirror) ksp_state_store(P.mirror, &sh);  // the host reads the state of a batch from here: no copy kernel in the stream
 }
 
+// Reduction only (RCCL plans: the rank's sums of the point, both partial arrays in ONE launch, for the all-reduce that
+// follows).  Round 5: the generic k_reduce_partials -- OX_MAX_NV-wide arrays in a 1024-thread block, one launch per
+// array -- took 17.4 + 9.5 us of a 110-us partitioned pressure iteration (rocprofv3 on the self-loop plan of rank 0 of
+// 8 at 256^3: tools/predict_scaling.py); this is k_ksp_scalar's own gather.
+template <int PH>
+__global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_reduce(const double *__restrict__ partial, int nparts, int nv, KspPart2 B,
+                                                               double *__restrict__ out) {
+  constexpr int NVT = ksp_nvt<PH>();
+  __shared__ double red[16 * NVT];
+  double v[NVT];
+  const int n = ksp_point_sums<PH, NVT>(partial, nparts, nv, B, v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NVT; ++i)
+      if (i < n) out[i] = v[i];
+  }
+}
+
 // The same on the direct xGMI transport: the block's sums are all-reduced over the ranks' windows
 // inside the kernel (rank order: identical bits, hence identical decisions, on every rank), so a
 // distributed synchronisation point stays ONE kernel.
@@ -169,22 +199,21 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
                                                                    const double *__restrict__ partial,
                                                                    int nparts, int nv, KspParams P, ox_p2p_ar ar,
                                                                    KspPart2 B) {
-  __shared__ double red[16 * OX_MAX_NV];
+  constexpr int NVT = ksp_nvt<PH>();
+  __shared__ double red[16 * NVT];
   __shared__ KspState sh;
   __shared__ double vals[OX_P2P_MAXV + 1];
   __shared__ double stage[64][OX_P2P_MAXV + 1];
   ksp_state_load(&sh, S);
-  double v[OX_MAX_NV];
-  ksp_gather2(partial, nparts, nv, B, v);
-  nv += B.nv;
-  ox_block_sum_wide(v, nv, red);  // contains a __syncthreads(): sh is complete after it
+  double v[NVT];
+  nv = ksp_point_sums<PH, NVT>(partial, nparts, nv, B, v, red);  // contains a __syncthreads(): sh is complete after it
   // A queued sync point that runs after `done` still takes part in the exchange (the host has advanced
   // the sequence number for it; skipping would let two LIVE exchanges share a parity slot), it only
   // leaves the state alone.  `done` is the same on every rank (rank-ordered sums: identical bits).
   const bool idle = !ksp_is_init(PH) && sh.done;
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < OX_MAX_NV; ++i)
+    for (int i = 0; i < NVT; ++i)
       if (i < nv) vals[i] = idle ? 0.0 : v[i];
   }
   __syncthreads();
@@ -193,10 +222,8 @@ __global__ __launch_bounds__(OX_RED_THREADS) void k_ksp_scalar_p2p(KspState *S,
     if (P.mirror) ksp_state_store(P.mirror, &sh);
     return;
   }
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < OX_MAX_NV; ++i) v[i] = i < nv ? vals[i] : 0.0;
-    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, v, c, P);
+  if (threadIdx.x == 0) {  // (the logic indexes the sums at run time: `vals` is in LDS)
+    for (int c = 0; c < P.nc; ++c) ksp_logic<PH>(&sh, vals, c, P);
     ksp_finish(&sh, P.nc_total);
   }
   __syncthreads();
@@ -1060,8 +1087,8 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
     OX_LAUNCH_CHECK();
     return 0;
   }
-  if (ox_reduce_partials(partial, nparts, nv, sums, st)) return -1;
-  if (B.nv > 0 && ox_reduce_partials(B.partial, B.nparts, B.nv, sums + nv, st)) return -1;
+  hipLaunchKernelGGL((k_ksp_reduce<PH>), dim3(1), dim3(ox_red_threads(nmax)), 0, st, partial, nparts, nv, B, sums);
+  OX_LAUNCH_CHECK();
   nv += B.nv;  // ONE all-reduce for both arrays
   if (ox_allreduce_impl(dist, sums, nv, st)) return -1;
   hipLaunchKernelGGL((k_ksp_logic<PH>), dim3(1), dim3(64), 0, st, S, sums, P);

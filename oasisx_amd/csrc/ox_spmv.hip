@@ -622,35 +622,21 @@ static const int *ox_zero_flag(hipStream_t st) {
 // pair-slot stream, bit 4: the LDS-window stream, each where the matrix carries them (measured: tools/spmv_bench.py).
 // Every level multiplies the same entries in the same order: the switch never changes a result.
 #define OX_SPMV_DEFAULT_VARIANT 31
-static int g_spmv_variant = -1;
-extern "C" int ox_set_spmv_variant(int v) {  // tuning hook for tools/spmv_bench.py
-  g_spmv_variant = v & 31;
-  return 0;
-}
-static int spmv_variant() {
-  if (g_spmv_variant < 0) {
-    const char *e = getenv("OX_SPMV_VARIANT");
-    g_spmv_variant = e ? atoi(e) & 31 : OX_SPMV_DEFAULT_VARIANT;
-  }
-  return g_spmv_variant;
-}
+// (a per-matrix field, ox_sell.levels, set through the ABI by whoever owns the matrix: the process-wide switch and its
+// OX_SPMV_VARIANT environment variable of rounds 2-4 let one object's tuning call change another's schedule)
+static inline int spmv_levels(const ox_sell *A) { return (A->levels & 32) ? (A->levels & 31) : OX_SPMV_DEFAULT_VARIANT; }
 
 // LDS-window stream: window entries the kernel's LDS budget holds with ncomp right-hand sides (48 / 48 / 51 KB: three
-// resident blocks per CU with three columns); OX_WIN_CAP overrides (tuning).  0: the matrix has no window stream, or
+// resident blocks per CU with three columns); ox_sell.w_cap overrides (tuning).  0: the matrix has no window stream, or
 // the launch cannot use it (slice lists of a partitioned operator).
 static int spmv_window_cap(const ox_sell *A, int ncomp, const int32_t *list) {
   // slice lists: only the interior / boundary halves of a partitioned operator whose window blocks are split alike
   if (list && !(A->ib_slices && (list == A->ib_slices || list == A->ib_slices + A->n_interior))) return 0;
-  if (!(spmv_variant() & 16) || !A->wcode || !A->wt_ptr || !A->wlist || !A->wb_ptr || !A->wb_slices ||
+  if (!(spmv_levels(A) & 16) || !A->wcode || !A->wt_ptr || !A->wlist || !A->wb_ptr || !A->wb_slices ||
       !A->wb_waves || A->n_wblocks <= 0 || ncomp < 1 || ncomp > 3)
     return 0;
-  static int env = -1;
-  if (env < 0) {
-    const char *e = getenv("OX_WIN_CAP");
-    env = e ? atoi(e) : 0;
-  }
   const int dflt = ncomp == 1 ? 6144 : (ncomp == 2 ? 3072 : 2176);
-  const int cap = env > 0 ? env : dflt;
+  const int cap = A->w_cap > 0 ? A->w_cap : dflt;
   return A->w_max < cap ? A->w_max : cap;
 }
 static inline int spmv_window_grid_n(int nblocks) { return (nblocks + 7) & ~7; }
@@ -671,10 +657,10 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
                             hipStream_t st, const int32_t *list, int n_list) {
   const int nblk = list ? ox_spmv_blocks_n(n_list) : ox_spmv_blocks(A);
   if (nblk == 0) return 0;
-  spmv_variant();
-  int var = (A->cols16 && A->cbase) ? (g_spmv_variant & 7) : (g_spmv_variant & 1);
+  const int lv = spmv_levels(A);
+  int var = (A->cols16 && A->cbase) ? (lv & 7) : (lv & 1);
   // bit 3 off: ignore the pair-slot stream (tools/spmv_bench.py A/B)
-  const bool pairs = (g_spmv_variant & 8) && A->ps_ptr && A->ps_code && A->ps_base;
+  const bool pairs = (lv & 8) && A->ps_ptr && A->ps_code && A->ps_base;
   // value codes ride on the 16-bit column stream (one kernel family: 7 = all three)
   if ((var & 6) != 6 || !A->vcode || !A->vdict || A->n_dict < 1 || A->n_dict > 256) var &= 3;
   else var = 7;
@@ -744,26 +730,22 @@ int ox_spmv_launch(const ox_sell *A, const double *x, double *y, int ncomp, int 
   return spmv_launch_list(A, x, y, ncomp, epi, dinv, aux, partial, done, st, nullptr, 0);
 }
 
-// OX_HALO_OVERLAP: 1 = start the halo exchange, multiply the interior slices while it is in flight, the boundary
-// slices after it has landed; 0 = exchange, then multiply.  Unset: overlap on the xGMI-window transport and on
-// the callback transports (both exercised by the multi-rank rehearsals on one GPU); exchange-then-multiply on
-// RCCL plans -- there the overlap puts pack + ncclSend/ncclRecv on a side stream between two events while the
-// main stream may issue an ncclAllReduce on the same communicator, an ordering that has not run between two
-// real GPUs yet (no multi-GPU node in rounds 1-3): the conservative form stays the default until it has.
-static int g_overlap = -2;
+// Overlapped mat-vec of a partitioned operator: start the halo exchange, multiply the interior slices while it is in
+// flight, the boundary slices after it has landed -- or exchange, then multiply.  A field of the PLAN (ox_dist.overlap,
+// ox_dist_set_overlap; the host layer reads OX_HALO_OVERLAP once and sets it): -1 = the transport's default: overlap on
+// the xGMI-window transport and on the callback transports (both exercised by the multi-rank rehearsals on one GPU);
+// exchange-then-multiply on RCCL plans -- there the overlap puts pack + ncclSend/ncclRecv on a side stream between two
+// events while the main stream may issue an ncclAllReduce on the same communicator, an ordering that has not run between
+// two real GPUs yet (no multi-GPU node in rounds 1-5): the conservative form stays the default until it has.
 static bool ox_overlap_on(const ox_sell *A, const ox_dist *dist) {
-  if (g_overlap == -2) {
-    const char *e = getenv("OX_HALO_OVERLAP");
-    g_overlap = e ? (atoi(e) ? 1 : 0) : -1;
-  }
   if (!(dist && dist->n_peers > 0 && A->ib_slices && A->n_interior > 0)) return false;
-  if (g_overlap >= 0) return g_overlap != 0;
+  if (dist->overlap >= 0) return dist->overlap != 0;
   return !(dist->comm && !dist->p2p && !dist->halo_cb);  // RCCL plan: off by default
 }
 
 // partial-sum rows (= grid blocks) of the launch over `list` (nullptr: the whole operator)
 static int spmv_parts_of(const ox_sell *A, int ncomp, const int32_t *list, int n_list) {
-  const bool pairs = (spmv_variant() & 8) && A->ps_ptr && A->ps_code && A->ps_base;
+  const bool pairs = (spmv_levels(A) & 8) && A->ps_ptr && A->ps_code && A->ps_base;
   if (!pairs && spmv_window_cap(A, ncomp, list) > 0) {
     int wb0 = 0, wbn = 0;
     spmv_window_range(A, list, n_list, &wb0, &wbn);
@@ -984,7 +966,7 @@ extern "C" int ox_spmv_multi(int v2s, int gdim, const ox_sell *A, const double *
   if (nblk == 0) return 0;
   const int tag = v2s ? OX_TAG_RECT_V2S : OX_TAG_RECT_S2V;
   const bool dict = A->vcode && A->vdict && A->cols16 && A->cbase && A->n_dict >= 1 && A->n_dict <= 256 &&
-                    (g_spmv_variant < 0 || (g_spmv_variant & 4));
+                    (spmv_levels(A) & 4);
   if (ox_prof_on) ox_prof_start(tag, st, A->n_rows);
 #define OX_MULTI(GD, V, D) \
   hipLaunchKernelGGL((k_spmv_multi<GD, V, D>), dim3(nblk), dim3(256), 0, st, *A, x, base, scale, y)

@@ -855,10 +855,12 @@ class FunctionSpace:
 
         def host_transport():
             self.dist = comm.make_transport(self)
+            self._apply_plan_options()
             self.pattern.dist = self.dist
             self.pattern.split_interior(self.n_owned)
-            self.check_halo()
-            comm.active[self.degree] = "host"
+            if not getattr(comm, "self_loop", False):  # (parallel.SelfLoopComm: a plan folded onto one rank, timing only)
+                self.check_halo()
+            comm.active[self.degree] = "self-loop" if getattr(comm, "self_loop", False) else "host"
 
         if want == "host" or (want == "rccl" and comm.handle is None):
             if getattr(comm, "make_transport", None) is not None:
@@ -872,6 +874,7 @@ class FunctionSpace:
                                       self.n_local - self.n_owned, C.byref(out)), "ox_dist_create")
         if want in ("auto", "p2p") and comm.enable_p2p(self, out):
             self.dist = out
+            self._apply_plan_options()
             self.pattern.dist = out
             self.pattern.split_interior(self.n_owned)
             comm.active[self.degree] = "p2p"
@@ -885,10 +888,18 @@ class FunctionSpace:
             host_transport()
             return
         self.dist = out
+        self._apply_plan_options()
         self.pattern.dist = out
         self.pattern.split_interior(self.n_owned)
         self.check_halo()
         comm.active[self.degree] = "rccl"
+
+    def _apply_plan_options(self):
+        """Schedule knobs of the halo plan from the environment, read by the host layer and set through the ABI
+        (``OX_HALO_OVERLAP=0|1``: exchange-then-multiply / overlapped mat-vecs; unset: the transport's default)."""
+        v = _os.environ.get("OX_HALO_OVERLAP")
+        if v is not None and self.dist is not None:
+            _lib.check(_lib.load().ox_dist_set_overlap(self.dist, 1 if v not in ("0", "false", "") else 0), "ox_dist_set_overlap")
 
     def check_halo(self):
         """Self-test of the attached halo plan + transport: exchange the dof coordinates and require

@@ -457,7 +457,7 @@ class FractionalStep_AB_CN:
             # The reference switches its pressure solver to MUMPS LU here and sets ksp_error_if_not_converged (:565-572).
             # The direct solver has no device counterpart (the configured Krylov method runs on the
             # mean-free right-hand side); the error behaviour is kept: a failed solve raises instead of returning.
-            if not self._solver_p._options.get("ksp_error_if_not_converged"):
+            if "ksp_error_if_not_converged" not in self._solver_p._options:  # (an explicit setting of the caller stands)
                 self._solver_p.updateOptions({"ksp_error_if_not_converged": 1})
             # nullspace.remove(b2): subtract the arithmetic mean (:573-574)
             _lib.check(lib.ox_remove_mean(nqo, nqo, self._B2.ptr(), None, float(self._Q.num_dofs_global),

@@ -15,8 +15,9 @@ Option mapping (PETSc string keys, as the reference passes them):
             false (PETSc's default, faster there) on a single GPU
   ksp_cg_merged_reduction  (extension) one-column "cg" solves: OX_KSP_CG_MERGED -- alpha and beta from ONE synchronisation
             point (one all-reduce), three kernels per iteration instead of five, no extra vectors; same Krylov space,
-            same test on the true |D^-1 r|.  Default: true on operators of at most 2^20 local rows (launch-bound
-            iterations: the partitions of a multi-GPU run, small meshes), false above
+            same test on the true |D^-1 r|.  Default: true on mesh-partitioned operators (one all-reduce per iteration
+            without the two extra vectors of the single-reduction form) and on one GPU up to 2^20 rows (launch-bound
+            iterations: small meshes), false above
   ksp_bcgs_merged_reduction  (extension; also selected by ksp_type ibcgs / pipebcgs / fbcgsr, PETSc's reduced-
             synchronisation BiCGStab variants): two merged reductions (all-reduces) per iteration instead of
             three -- omega, rho and the residual norm from one reduction behind the second mat-vec
@@ -219,11 +220,14 @@ class KSPSolver:
         if self._A is None:
             return False
         if getattr(self, "_merged_auto", None) is None:
-            rows = self._A.pattern.n_rows
-            if self._A.pattern.dist is not None and getattr(self._comm, "size", 1) > 1:
-                # every rank must run the same recurrences (they differ in their collectives): the largest part decides
-                rows = int(self._comm.allreduce(rows, op="max"))
-            self._merged_auto = rows <= CG_MERGED_MAX_ROWS
+            if self._A.pattern.dist is not None:
+                # mesh-partitioned operators: ALWAYS.  One all-reduce per iteration like the single-reduction form, no
+                # extra vectors (7 vector passes against its 11): on the self-loop plan of one rank (tools/
+                # predict_scaling.py, round 5) 73 / 106 / 253 us per iteration at 1.1 / 2.1 / 8.5 M local rows against
+                # 73 / 107 / 291 for the Chronopoulos-Gear recurrences.  (The same on every rank: no agreement needed.)
+                self._merged_auto = True
+            else:
+                self._merged_auto = self._A.pattern.n_rows <= CG_MERGED_MAX_ROWS
         return self._merged_auto
 
     def _fold_blocks(self) -> int:

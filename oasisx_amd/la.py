@@ -2,11 +2,30 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 from .fem import SellPattern
+
+
+def _env_int(name):
+    try:
+        return int(os.environ[name])
+    except (KeyError, ValueError):
+        return None
+
+
+# tuning defaults of the mat-vec, read by the HOST layer once and written into every matrix's own ox_sell (the library
+# keeps no process-wide switch): storage levels (include/oasisx_hip.h: ox_sell.levels) and the LDS-window budget
+ENV_SPMV_LEVELS = _env_int("OX_SPMV_VARIANT")
+ENV_WIN_CAP = _env_int("OX_WIN_CAP")
+
+
+def _apply_schedule(struct, levels, w_cap):
+    struct.levels = 0 if levels is None else (32 | (int(levels) & 31))
+    struct.w_cap = 0 if not w_cap else int(w_cap)
 
 
 class SellMatrix:
@@ -23,6 +42,17 @@ class SellMatrix:
         self.ps_wide = 0
         self.wvcode = None  # value codes in the tile layout of the pattern's LDS-window stream, see freeze()
         self._struct = pattern.struct(self.vals)
+        self.levels, self.w_cap = ENV_SPMV_LEVELS, ENV_WIN_CAP
+        _apply_schedule(self._struct, self.levels, self.w_cap)
+
+    def set_levels(self, mask: int | None, w_cap: int | None = None):
+        """Storage levels the mat-vecs of THIS matrix may use (bit 0 nontemporal stream, 1 16-bit columns, 2 value codes,
+        3 pair slots, 4 LDS windows; None = all it carries) and, optionally, the LDS-window budget in entries.  A/B hook
+        of tests and tools: results never depend on it."""
+        self.levels = mask
+        if w_cap is not None:
+            self.w_cap = w_cap or None
+        _apply_schedule(self._struct, self.levels, self.w_cap)
 
     @property
     def struct(self) -> _lib.ox_sell:
@@ -129,6 +159,13 @@ class MultiSellMatrix:
         self.vals = torch.zeros(pattern.size * gdim, dtype=torch.float64, device=pattern.device)
         self._struct = pattern.struct(self.vals, compress=False)
         self.vcode = self.vdict = None
+        self.levels = ENV_SPMV_LEVELS
+        _apply_schedule(self._struct, self.levels, None)
+
+    def set_levels(self, mask: int | None):
+        """As ``SellMatrix.set_levels`` (bit 2 off: the f64 value streams instead of the packed value codes)."""
+        self.levels = mask
+        _apply_schedule(self._struct, self.levels, None)
 
     def ref(self):
         return C.byref(self._struct)
@@ -156,12 +193,14 @@ class MultiSellMatrix:
         full.vcode, full.vdict, full.n_dict = self.vcode.data_ptr(), self.vdict.data_ptr(), int(nd.value)
         self._plain = self._struct
         self._struct = full
+        _apply_schedule(self._struct, self.levels, None)
         return True
 
     def unfreeze(self):
         """Back to the f64 value stream (bench.py's dictionary-off leg); same results."""
         if self.vcode is not None:
             self._struct = self._plain
+            _apply_schedule(self._struct, self.levels, None)
             self.vcode = self.vdict = None
 
     def mult(self, v2s: bool, x, base, scale: float, y):

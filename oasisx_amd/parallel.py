@@ -320,6 +320,57 @@ class Comm:
         return out
 
 
+class SelfLoopComm(Comm):
+    """ONE rank of a ``size``-rank job, alone on the device (tools/predict_scaling.py): partition, spaces, halo plans,
+    operators and Krylov methods are those of rank ``rank`` in the real job -- interior / boundary slice lists, pack
+    kernels, grouped ncclSend / ncclRecv, ncclAllReduce at every synchronisation point, the partitioned defaults of
+    KSPSolver --, but the plans exchange with THIS rank itself through a one-rank RCCL communicator: every ghost entry
+    receives some owned value, every all-reduce sums one contribution.  Kernel and call-site costs of the rank are real,
+    its results are not those of the job (``collective`` is False: nothing here spans ranks).  Never a product path."""
+
+    collective = False
+    self_loop = True
+
+    def __init__(self, rank: int, size: int):
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        _lib.check(lib.ox_comm_unique_id(buf), "ox_comm_unique_id")
+        handle = C.c_void_p()
+        _lib.check(lib.ox_comm_create(buf.raw, 0, 1, C.byref(handle)), "ox_comm_create")
+        super().__init__(rank, size, handle, transport="host")  # ("host": attach_comm asks make_transport for the plan)
+
+    def make_transport(self, V):
+        """The rank's halo plan folded onto itself: one peer (this rank), as many values sent as the real plan
+        RECEIVES (the ghost block is filled completely, the pack kernel gathers as many entries as the real exchange
+        moves in), taken from the real send lists in turn."""
+        import numpy as np
+
+        lib = _lib.load()
+        h = V.halo
+        ng = V.n_local - V.n_owned
+        src = h["send_idx"]
+        if ng and src.numel() == 0:
+            src = torch.zeros(1, dtype=torch.int32, device=V.mesh.device)
+        send_idx = src.repeat((ng + max(src.numel(), 1) - 1) // max(src.numel(), 1))[:ng].contiguous() if ng else src[:0]
+        self._keep = getattr(self, "_keep", []) + [send_idx]
+        peers = np.zeros(1 if ng else 0, dtype=np.int32)
+        off = np.asarray([0, ng] if ng else [0], dtype=np.int64)
+        out = C.c_void_p()
+        _lib.check(lib.ox_dist_create(self.handle, 0, 1, int(peers.shape[0]), peers.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      off.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(send_idx),
+                                      off.ctypes.data_as(C.POINTER(C.c_int64)), V.n_owned, ng, C.byref(out)), "ox_dist_create")
+        return out
+
+    def allreduce(self, v, op=None):
+        return v
+
+    def _all_ok(self, ok: bool) -> bool:
+        return ok
+
+    def Barrier(self):
+        return None
+
+
 def init_comm() -> Comm:
     """Communicator of the current ``torch.distributed`` job.  With the nccl (= RCCL) backend the
     library's own ncclComm is created from a unique id broadcast over torch.distributed."""

@@ -117,3 +117,34 @@ def test_bench_under_the_driver_launch_line_with_two_ranks():
     assert d["config"]["parallelism"] == "mesh-partition x2" and d["config"]["transport"].startswith("p2p")
     assert d["cpu_baseline"] is None or "value" in d["cpu_baseline"]
     assert d["config"]["n_u_per_component"] == 33 ** 3 and d["config"]["n_p"] == 17 ** 3  # global sizes
+
+
+@pytest.mark.gpu
+def test_the_launcher_line_with_one_rank_is_the_plain_line():
+    """The driver's SCALE series starts at N = 1 under ``torch.distributed.run --nproc-per-node 1 bench.py --gpus 1``; its
+    BENCH line is plain ``python bench.py``.  The two must describe the same run: same config (but for ``launched_by``),
+    same Krylov iteration series, same kernels per iteration -- a one-rank job takes no partitioned code path."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tail = ["-N", "16", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu", "--no-pmc"]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *tail], capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", *tail]
+    launched = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert launched.returncode == 0, launched.stderr[-3000:]
+    a, b = (json.loads([ln for ln in o.stdout.strip().splitlines() if ln.strip().startswith("{")][-1]) for o in (plain, launched))
+    for d in (a, b):
+        assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "mesh-partition x1" and d["config"]["transport"] is None
+        assert d["config"]["ranks"] is None and d["phase_ms_per_step_max_over_ranks"] is None
+    ca, cb = dict(a["config"]), dict(b["config"])
+    assert ca.pop("launched_by") == "python" and cb.pop("launched_by") == "python"  # (one rank: no partitioned path either way)
+    assert ca == cb
+    assert a["krylov_iterations_series"] == b["krylov_iterations_series"]
+    assert a["pressure_cg_iteration"]["kernels_per_iteration"] == b["pressure_cg_iteration"]["kernels_per_iteration"]
+    assert a["roofline"]["kernel"] == b["roofline"]["kernel"] and a["roofline"]["bytes_moved_per_launch"] == b["roofline"]["bytes_moved_per_launch"]

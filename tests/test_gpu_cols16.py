@@ -97,11 +97,11 @@ def test_three_groups_fall_back_and_spmv_is_bit_identical():
         x = torch.as_tensor(rng.standard_normal((nn, nc)), device=dev).contiguous()
         ys = []
         for var in (1, 3):
-            lib.ox_set_spmv_variant(var)
+            A.set_levels(var)
             y = torch.zeros_like(x)
             A.mult(x, y, nc)
             ys.append(y.cpu().numpy())
-        lib.ox_set_spmv_variant(15)
+        A.set_levels(None)
         np.testing.assert_array_equal(ys[0], ys[1])
         ref = P.to_csr(A.vals) @ x.cpu().numpy()
         np.testing.assert_allclose(ys[1], ref, rtol=1e-13, atol=1e-13)
@@ -127,11 +127,11 @@ def test_value_dictionary_is_bit_identical_and_drops_when_values_change():
             x = torch.randn(n, nc, dtype=torch.float64, device="cuda").contiguous()
             ys = []
             for var in (3, 7, 15):
-                lib.ox_set_spmv_variant(var)
+                A.set_levels(var)
                 y = torch.zeros(A.pattern.n_rows, nc, dtype=torch.float64, device="cuda")
                 A.mult(x, y, nc)
                 ys.append(y.cpu().numpy())
-            lib.ox_set_spmv_variant(15)
+            A.set_levels(None)
             np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
             np.testing.assert_array_equal(ys[0].view(np.int64), ys[2].view(np.int64))
     # the assembled convective matrix has no small dictionary
@@ -173,11 +173,11 @@ def test_rectangular_operators_with_value_codes_are_bit_identical():
         x = torch.randn(nx, dtype=torch.float64, device="cuda")
         ys = []
         for var in (3, 7):  # bit 2 off: f64 values + int32 columns; on: codes
-            lib.ox_set_spmv_variant(var)
+            Mat.set_levels(var)
             y = torch.zeros(ny, dtype=torch.float64, device="cuda")
             Mat.mult(v2s, C.c_void_p(x.data_ptr()), None, 0.5, C.c_void_p(y.data_ptr()))
             ys.append(y.cpu().numpy())
-        lib.ox_set_spmv_variant(15)
+        Mat.set_levels(None)
         np.testing.assert_array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
         assert np.abs(ys[0]).max() > 0
     S6, _, _ = make_hip_problem(3, 6, u_deg=2, low_memory=False)
@@ -248,11 +248,11 @@ def test_pair_slot_stream_decodes_to_the_entries_and_spmv_is_bit_identical(dim, 
         x = torch.randn(P.n_cols, nc, dtype=torch.float64, device="cuda").contiguous()
         ys = []
         for var in (7, 15):
-            lib.ox_set_spmv_variant(var)
+            A.set_levels(var)
             y = torch.zeros(P.n_rows, nc, dtype=torch.float64, device="cuda")
             A.mult(x, y, nc)
             ys.append(y)
-        lib.ox_set_spmv_variant(15)
+        A.set_levels(None)
         assert torch.equal(ys[0], ys[1])
     # Krylov epilogues (CG: p.Ap; BiCGStab: D^-1 A with rhat.v and t.t, t.s): same iterates bit for bit
     from oasisx_amd.fem import FieldStorage
@@ -263,7 +263,7 @@ def test_pair_slot_stream_decodes_to_the_entries_and_spmv_is_bit_identical(dim, 
         for kind in ("cg", "bcgs"):
             sols = []
             for var in (7, 15):
-                lib.ox_set_spmv_variant(var)
+                A.set_levels(var)
                 ks = KSPSolver(None, {"ksp_type": kind, "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_atol": 1e-30,
                                       "ksp_max_it": 25})
                 ks.setOperators(A)
@@ -271,5 +271,5 @@ def test_pair_slot_stream_decodes_to_the_entries_and_spmv_is_bit_identical(dim, 
                 B.dev().copy_(rhs)
                 ks.solve_block(B, X)
                 sols.append((X.dev().clone(), ks.iterations))
-            lib.ox_set_spmv_variant(15)
+            A.set_levels(None)
             assert sols[0][1] == sols[1][1] and torch.equal(sols[0][0], sols[1][0]), (kind, nc)

@@ -79,11 +79,11 @@ def test_symmetry_and_bit_identity_of_the_compressed_streams(problem):
         z = torch.randn(n, 1, dtype=torch.float64, device="cuda", generator=g)
         ys = []
         for var in (1, 3, 7, 15):  # int32 columns + f64 values; 16-bit columns; + 1-byte value codes; pair slots
-            lib.ox_set_spmv_variant(var)
+            A.set_levels(var)
             y = _vec(n)
             A.mult(x, y, 1)
             ys.append(y)
-        lib.ox_set_spmv_variant(15)
+        A.set_levels(None)
         assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]) and torch.equal(ys[0], ys[3])
         if A is S._Ap:
             assert A.ps_code is not None, "the P1 stiffness matrix pairs up well: the pair-slot stream must exist"

@@ -254,13 +254,13 @@ def test_overlapped_spmv_on_the_rccl_self_loop(hip):
         x[:n_owned] = torch.rand(n_owned, nc, dtype=torch.float64, device="cuda", generator=g)
         ys = []
         for var in (7, 15):
-            hip.ox_set_spmv_variant(var)
+            A.set_levels(var)
             x[n_owned:] = float("nan")
             y = torch.zeros(n_owned, nc, dtype=torch.float64, device="cuda")
             A.mult(x, y, nc)
             torch.cuda.synchronize()
             ys.append(y)
-        hip.ox_set_spmv_variant(15)
+        A.set_levels(None)
         assert torch.equal(ys[0], ys[1])
         assert (ys[1] - dense @ x).abs().max() < 1e-13
     _lib.check(hip.ox_dist_destroy(d), "ox_dist_destroy")

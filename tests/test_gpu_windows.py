@@ -91,19 +91,20 @@ def test_window_stream_reproduces_the_columns_and_the_matvec_bit_for_bit(hip, ki
             x = torch.randn(P.n_cols, nc, dtype=torch.float64, device="cuda")
             for Mat in (A, Md):
                 y0, y1 = torch.zeros(P.n_rows, nc, dtype=torch.float64, device="cuda"), torch.full((P.n_rows, nc), 9.0, dtype=torch.float64, device="cuda")
-                lib.ox_set_spmv_variant(15)
+                Mat.set_levels(15)
                 Mat.mult(x, y0, nc)
-                lib.ox_set_spmv_variant(31)
+                Mat.set_levels(31)
                 Mat.mult(x, y1, nc)
                 assert torch.equal(y0, y1)
                 ref = Mat.to_scipy() @ x.cpu().numpy()
                 assert np.abs(y1.cpu().numpy() - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
         x = torch.randn(P.n_cols, 3, dtype=torch.float64, device="cuda")
         y0, y1 = torch.zeros(P.n_rows, 3, dtype=torch.float64, device="cuda"), torch.zeros(P.n_rows, 3, dtype=torch.float64, device="cuda")
-        lib.ox_set_spmv_variant(15)
+        A.set_levels(15)
         A.mult(x, y0, 3)
     finally:
-        lib.ox_set_spmv_variant(31)
+        A.set_levels(None)
+        Md.set_levels(None)
     assert torch.equal(y0, (A.mult(x, y1, 3), y1)[1])
 
 
@@ -180,7 +181,7 @@ def test_krylov_workspace_covers_the_window_grid_of_a_short_sort_window(hip):
     sols = {}
     try:
         for variant in (15, 31):
-            lib.ox_set_spmv_variant(variant)
+            A.set_levels(variant)
             for merged in (False, True):
                 ksp = KSPSolver(None, {"ksp_type": "bcgs", "pc_type": "jacobi", "ksp_rtol": 1e-10, "ksp_bcgs_merged_reduction": merged})
                 ksp.setOperators(A)
@@ -188,7 +189,7 @@ def test_krylov_workspace_covers_the_window_grid_of_a_short_sort_window(hip):
                 assert ksp.solve_block(B, X) == [2, 2, 2]
                 sols[(variant, merged)] = (X.dev().clone(), list(ksp.iterations[:3]))
     finally:
-        lib.ox_set_spmv_variant(31)
+        A.set_levels(None)
     ref = sols[(15, False)]
     y = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
     for key, (x, its) in sols.items():

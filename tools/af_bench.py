@@ -32,7 +32,7 @@ for blocks in modes:
     for _ in range(10): S.assemble_first(0.01, 0.01)
     e1.record(); torch.cuda.synchronize()
     out[blocks] = (S._A.vals.clone(), S._BFIRST.dev().clone())
-    print(f"row_blocks={blocks} OX_ASSEMBLE_U={os.environ.get('OX_ASSEMBLE_U','default')}: assemble_first {e0.elapsed_time(e1)/10:.3f} ms; "
+    print(f"row_blocks={blocks}: assemble_first {e0.elapsed_time(e1)/10:.3f} ms; "
           f"checksum {float(S._A.vals.sum()):.12e} {float(S._BFIRST.dev().sum()):.12e}", flush=True)
 if len(out) == 2:
     print("bit-identical:", torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1]))

@@ -45,12 +45,12 @@ print(f"16-bit column stream covers {P.frac16:.4f} of the stored entries; CSR by
 res = {v: [] for v in variants}
 ref_y = None
 for v in variants:  # every variant must reproduce the first one bit for bit
-    lib.ox_set_spmv_variant(v); y.zero_(); A.mult(x, y, nc); torch.cuda.synchronize()
+    A.set_levels(v); y.zero_(); A.mult(x, y, nc); torch.cuda.synchronize()
     if ref_y is None: ref_y = y.clone()
     else: print(f"variant {v} bit-identical to variant {variants[0]}: {torch.equal(ref_y, y)}")
 for rnd in range(int(os.environ.get('ROUNDS', '7'))):
     for v in variants:
-        lib.ox_set_spmv_variant(v)
+        A.set_levels(v)
         for _ in range(5): A.mult(x, y, nc)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = int(os.environ.get('REPS', '100'))

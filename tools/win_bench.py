@@ -27,7 +27,7 @@ WINDOW = int(os.environ.get("WINDOW", "4096"))
 
 
 def timed(A, x, y, nc, variant):
-    lib.ox_set_spmv_variant(variant)
+    A.set_levels(variant)
     for _ in range(3):
         A.mult(x, y, nc)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,9 +78,9 @@ for brick in ([int(b) for b in os.environ.get("BRICKS", "1,0").split(",")] if ki
         for nc in (1, 3):
             x = (torch.sin(torch.arange(P.n_cols * nc, device="cuda", dtype=torch.float64) * 1e-3) + 1).reshape(P.n_cols, nc).contiguous()
             y0, y1 = torch.zeros_like(x), torch.zeros_like(x)
-            lib.ox_set_spmv_variant(15)
+            A.set_levels(15)
             A.mult(x, y0, nc)
-            lib.ox_set_spmv_variant(31)
+            A.set_levels(31)
             A.mult(x, y1, nc)
             torch.cuda.synchronize()
             same = torch.equal(y0, y1)
@@ -97,4 +97,3 @@ for brick in ([int(b) for b in os.environ.get("BRICKS", "1,0").split(",")] if ki
                   f"{b:8.1f} us ({wstream / b / 1e3 / 8000:.3f} on {wstream / 1e6:.0f} MB) | x{a / b:.2f} | bit-identical {same}", flush=True)
     del V, P, Mm, Am, mesh
     torch.cuda.empty_cache()
-lib.ox_set_spmv_variant(31)
