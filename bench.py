@@ -473,7 +473,7 @@ def main():
         if W2["analytic"]:
             Xd2 = S2._Vi[0][0].x[: S2._n_u].T
             res["max_nodal_error_u_vs_analytic"] = max(
-                float((S2._U.dev()[: S2._n_u][:, i] - f(Xd2, clk["t"])).abs().max()) for i, f in enumerate(W2["fns"]))
+                float((S2._U.rdev()[: S2._n_u][:, i] - f(Xd2, clk["t"])).abs().max()) for i, f in enumerate(W2["fns"]))
         if not args.no_cpu:
             # the next step of THIS workload on the host (oracle/ipcs_cpu.c on its own mesh, numbering and operators,
             # fed the device's state through the dof coordinates) against the device's: a timed figure with its check
@@ -603,7 +603,7 @@ def main():
     phase_ms = {k: sum(a.elapsed_time(b) for a, b in v) / args.steps for k, v in phase_events.items() if k != "_on"}
     # accuracy at the end of the timed steps: nodal error against the analytic field (rank-local dofs)
     Xd = S._Vi[0][0].x[: S._n_u].T
-    Ud = S._U.dev()[: S._n_u]
+    Ud = S._U.rdev()[: S._n_u]
     err_u = max(float((Ud[:, i] - f(Xd, clock["t"])).abs().max()) for i, f in enumerate(fns)) if W["analytic"] else None
     umax = float(Ud.abs().max())
 

@@ -1553,7 +1553,14 @@ int build_windows(ox_space *V, hipStream_t st) {
 extern "C" int ox_space_windows(ox_space *V, ox_window_info *v) {
   if (!V || !v) OX_FAIL("ox_space_windows: null argument");
   if (!V->row_pos.p && V->n > 0) OX_FAIL("ox_space_windows: the space carries no locality positions");
-  if (!V->windows_built) OX_TRY(build_windows(V, nullptr));
+  if (!V->windows_built && build_windows(V, nullptr)) {
+    // a failed build (out of memory in a 2-GiB key chunk, ...) leaves nothing half-built behind: the space stays usable
+    // on the lane = row kernels, and a later call starts from scratch
+    V->wb_slices.release(), V->wb_waves.release(), V->wb_ptr.release();
+    V->wlist.release(), V->wt_ptr.release(), V->wcode.release();
+    V->n_wblocks = 0, V->w_max = 0;
+    return -1;
+  }
   memset(v, 0, sizeof(*v));
   v->n_wblocks = V->n_wblocks, v->w_max = V->w_max;
   v->n_list = V->n_list, v->n_tiles = V->n_tiles, v->n_over_16bit = V->n_over_16bit;

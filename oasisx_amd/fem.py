@@ -1304,7 +1304,9 @@ class FieldStorage:
         # bumped whenever the block MAY have been written: every hand-out of a writable view -- a host check-out,
         # ``dev()``, ``ptr()`` (DirichletBC.apply, KSPSolver.solve_block and any ``S._U.dev()[...] = ...`` go through
         # them) -- counts as a write.  FractionalStep_AB_CN keeps "u still equals u1 bit for bit" on it and reads the
-        # two blocks through ``rdev()`` / ``rptr()`` (read-only by contract) while that matters.
+        # two blocks through ``rdev()`` / ``rptr()`` (read-only by contract) while that matters.  Monitoring code between
+        # steps (error norms, writers, callbacks) should read through ``rdev()`` / ``rptr()`` / ``rhost()`` too: a
+        # ``dev()`` for a pure read is safe but silently costs the tentative solve its free first mat-vec.
         self.generation = 0
 
     def mark_written(self):
@@ -1345,6 +1347,13 @@ class FieldStorage:
     def rptr(self):
         """Device pointer for a kernel that only reads the block."""
         return C.c_void_p(self._sync().data_ptr())
+
+    def rhost(self) -> np.ndarray:
+        """A host COPY of the block for reading (writers, monitors, error norms): unlike ``host()`` nothing is checked
+        out, so the block does not count as written (``generation`` stays: the solver's ``A u1`` shortcut survives)."""
+        if self._shared:
+            return self._host.copy()
+        return self._sync()[: self.n].cpu().numpy()
 
 
 class Vector:

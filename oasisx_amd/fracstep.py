@@ -262,12 +262,20 @@ class FractionalStep_AB_CN:
             self._grad_p_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "grad_p")
             self._divu_Mat = MultiSellMatrix(self._pat_qv, mesh.gdim, "divu")
         # LDS-window stream of the velocity pattern (M, K, A share it): single-GPU operators of a degree-2 space
+        def windows(space, what):
+            # (an optional storage level: a failed build -- out of device memory in its sorts -- leaves the space on the
+            # lane = row kernels, with a warning; results are the same either way)
+            try:
+                space.build_windows()
+            except _lib.OasisxHipError as e:
+                logging.getLogger("oasisx").warning("LDS-window stream of the %s pattern not built (%s): its mat-vecs run "
+                                                    "on the lane = row kernels", what, e)
         if self._spmv_windows:
-            Vi.build_windows()
+            windows(Vi, "velocity")
         # the pressure matrix too where it has no pair-slot stream to lose (meshes that are not lattices carry no
         # value dictionary): refined Delaunay mesh, 2.4 M P1 rows: 120 -> 86 us per mat-vec, 0.73 of the HBM peak
         if self._options.get("spmv_windows_pressure", self._spmv_windows and not self._lattice) and mesh.device.type == "cuda":
-            Q.build_windows()
+            windows(Q, "pressure")
         self._M = SellMatrix(Vi.pattern, symmetric=True, name="M")
         self._K = SellMatrix(Vi.pattern, symmetric=True, name="K")
         self._A = SellMatrix(Vi.pattern, symmetric=False, name="A")
@@ -424,6 +432,13 @@ class FractionalStep_AB_CN:
                 same = self._comm.allreduce(0.0 if same else 1.0, op="max") == 0.0
             if same:
                 ax0 = self._B3
+            elif not getattr(self, "_shortcut_note", False):
+                # (said once: a monitor that reads u through dev() / host() between steps makes every step pay one
+                # mat-vec more than it has to)
+                self._shortcut_note = True
+                logging.getLogger("oasisx").info(
+                    "tentative solve: u was handed out writable since the last step (FieldStorage.dev() / ptr() / host()): "
+                    "the A u1 product of assemble_first is not reused; read-only access goes through rdev() / rptr() / rhost()")
         self._u_is_u1 = None  # the solve below writes u
         errors = np.asarray(self._solver_u.solve_block(self._RHS1, self._U, ax0=ax0), dtype=np.int32)
         # diff = sum_i || u_i^old - u_i ||_2 (:523-524)

@@ -104,7 +104,7 @@ class VTXWriter:
                '</DataArray></FieldData>\n',
                f'<Piece NumberOfPoints="{X.shape[0]}" NumberOfCells="{offsets.shape[0]}">\n<PointData>\n']
         for f in self._fns:
-            h = f._storage.host()
+            h = f._storage.rhost()  # (a read: the block is not checked out)
             if f._comp is None:  # blocked function: vector data, padded to 3 components
                 v = np.zeros((h.shape[0], 3))
                 v[:, : h.shape[1]] = h

@@ -294,7 +294,8 @@ def _read_gmsh(path):
                     k += 1
                     off = 4 if dim == 0 else 7  # tag + a point, or tag + a bounding box
                     nph = int(t[off])
-                    phys[(dim, int(t[0]))] = int(t[off + 1]) if nph > 0 else 0
+                    # (Gmsh 4.1 writes the physical tag of an entity with REVERSED orientation negative: the group is |tag|)
+                    phys[(dim, int(t[0]))] = abs(int(t[off + 1])) if nph > 0 else 0
         body = sec["Nodes"]
         nblocks = int(body[0].split()[0])
         k, ids, pts = 1, [], []

@@ -285,7 +285,8 @@ def from_mesh(coords, cells, u_deg, p_deg, ksp, body_force=None):
     M = sp.csr_matrix((Mv, ci, rp), shape=(nv_dofs, nv_dofs))
     K = sp.csr_matrix((Kv, ci, rp), shape=(nv_dofs, nv_dofs))
     Ap = sp.csr_matrix((pv, pci, prp), shape=(nq_dofs, nq_dofs))
-    if body_force is not None and any(callable(f_) for f_ in body_force):
+    if body_force is not None and not all(isinstance(f_, (int, float, np.integer, np.floating)) for f_ in body_force):
+        # (callables, Functions, Constants with array values: everything but plain numbers)
         raise NotImplementedError("the C port assembles constant body forces only")
     f = np.zeros(d) if body_force is None else np.asarray(body_force, dtype=np.float64)
     b0 = f[:, None] * wv[None, :]
@@ -374,7 +375,7 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     else:
         p0, p1, nn = mesh_def
         key = (tuple(float(v) for v in p0), tuple(float(v) for v in p1), tuple(int(v) for v in nn), Vi.degree, Q.degree,
-               tuple(sorted(ksp.items())), tuple(S._body_force))
+               tuple(sorted(ksp.items())), tuple(repr(f_) for f_ in S._body_force))
     if not reuse_setup:  # (bench.py opts in: its legs follow one another on the same box; nothing is kept otherwise)
         key, _LAST_SETUP = None, None
     if key is not None and _LAST_SETUP is not None and _LAST_SETUP[0] == key:
@@ -395,11 +396,11 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     lo, hi = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)
     pv = match_by_coordinates(Vi.x[:n].cpu().numpy(), x_v, lo, hi)  # product index of the port's dof k
     pq = pv if Q is Vi else match_by_coordinates(Q.x[:nq].cpu().numpy(), x_q, lo, hi)
-    cpu.u[:] = S._U.dev()[:n].cpu().numpy()[pv].T
-    cpu.u1[:] = S._U1.dev()[:n].cpu().numpy()[pv].T
-    cpu.u2[:] = S._U2.dev()[:n].cpu().numpy()[pv].T
-    cpu.p[:] = S._P.dev()[:nq, 0].cpu().numpy()[pq]
-    cpu.dp[:] = S._DP.dev()[:nq, 0].cpu().numpy()[pq]
+    cpu.u[:] = S._U.rdev()[:n].cpu().numpy()[pv].T
+    cpu.u1[:] = S._U1.rdev()[:n].cpu().numpy()[pv].T
+    cpu.u2[:] = S._U2.rdev()[:n].cpu().numpy()[pv].T
+    cpu.p[:] = S._P.rdev()[:nq, 0].cpu().numpy()[pq]
+    cpu.dp[:] = S._DP.rdev()[:nq, 0].cpu().numpy()[pq]
     t_setup = time.perf_counter() - t0
     clock["t"] += dt
     Xbc = np.zeros((3, cpu.bc_dofs.shape[0]))
@@ -419,8 +420,8 @@ def run_cpu_baseline(S, clock, dt, nu, ksp, bc_values_at, gpu_step=None, mesh_de
     if gpu_step is not None:
         clock["t"] -= dt
         gpu_step()
-        ug = S._U1.dev()[:n].cpu().numpy()[pv].T
-        pg = S._P.dev()[:nq, 0].cpu().numpy()[pq]
+        ug = S._U1.rdev()[:n].cpu().numpy()[pv].T
+        pg = S._P.rdev()[:nq, 0].cpu().numpy()[pq]
         out["gpu_vs_cpu_rel_l2_u"] = float(np.linalg.norm(ug - cpu.u1) / np.linalg.norm(cpu.u1))
         out["gpu_vs_cpu_rel_l2_p"] = float(np.linalg.norm(pg - cpu.p) / max(np.linalg.norm(cpu.p), 1e-300))
         out["gpu_vs_cpu_max_abs_u"] = float(np.abs(ug - cpu.u1).max())
