@@ -1370,7 +1370,7 @@ static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P,
     // folded: the state alternates S / S2 per iteration (an even batch leaves it in S, where the host and the next
     // batch look for it), the update's partial sums between two arrays
     const int nbs1 = ox_spmv_dist_nparts(C.A, nullptr, 1);
-    if ((int64_t)nbs1 * 2 < OX_PRERED_MIN) {
+    if (nbs1 <= 10 * OX_FOLD_T) {  // (every thread's <= 10 partial rows of the mat-vec are requested in one round)
       int64_t want = ((n >> 1) + OX_FOLD_T - 1) / OX_FOLD_T;
       if (want < 1) want = 1;
       const int nbf = (int)(want < C.fold ? want : C.fold);
@@ -1757,7 +1757,7 @@ extern "C" int ox_ksp_kernels_per_iteration(int ksp_type, const ox_sell *A, int 
       return ox_spmv_dist_nparts(A, nullptr, 1) >= OX_PRERED_MIN ? 4 : 3;  // (+ the pre-reduction of many block sums)
     }
     case OX_KSP_CG_MERGED:
-      return (one && (batch & 1) == 0 && (int64_t)ox_spmv_dist_nparts(A, nullptr, 1) * 2 < OX_PRERED_MIN) ? 2 : 3;
+      return (one && (batch & 1) == 0 && ox_spmv_dist_nparts(A, nullptr, 1) <= 10 * OX_FOLD_T) ? 2 : 3;
     case OX_KSP_CG_SINGLE: return 3;
     case OX_KSP_BCGS: return 8;
     case OX_KSP_BCGS_MERGED: return 6;

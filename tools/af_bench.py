@@ -18,7 +18,9 @@ S = None
 for blocks in modes:
     if S is None:
         S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, bcs_p=[],
-                                    options={"low_memory_version": True, "assemble_row_blocks": blocks})
+                                    options=dict({"low_memory_version": True, "assemble_row_blocks": blocks},
+                                                 **({"spmv_windows": True} if os.environ.get("BRICK") == "1" else {})))
+        print("brick order of the P2 numbering:", S._Vi[0][0].brick, flush=True)
         g = torch.Generator(device="cuda").manual_seed(1)
         S._U1.dev().copy_(torch.randn(S._U1.dev().shape, dtype=torch.float64, device="cuda", generator=g))
         S._U2.dev().copy_(torch.randn(S._U2.dev().shape, dtype=torch.float64, device="cuda", generator=g))
