@@ -303,6 +303,12 @@ int ox_space_view(const ox_space *space, ox_space_info *view);
  * re-tiled per matrix: ox_window_retile).  Worth it where the rows of 8 consecutive slices share their columns:
  * any mesh in Z-order, box meshes in brick order (ox_space_create_ordered). */
 int ox_space_windows(ox_space *space, ox_window_info *view);
+/* The same with blocks whose window holds more than split_entries columns cut in two (4 + 4 slices; 0 = never,
+ * ox_space_windows): for patterns whose mat-vecs run with three right-hand sides -- the LDS budget of such a launch is
+ * 2176 window entries, a block beyond it multiplies from the int32 columns.  One-column launches (budget 6144) lose
+ * ~9 % to the extra lists: the velocity pattern yes, the pressure pattern no.  A call with another split_entries than
+ * the stream was built with builds it anew (views handed out before are stale then). */
+int ox_space_windows_split(ox_space *space, int split_entries, ox_window_info *view);
 int ox_space_destroy(ox_space *space);
 /* pattern of a mixed operator, rows = dofs of `rows`, columns = dofs of `cols` (fracstep.py:315,336,352) */
 int ox_rect_create(const ox_space *rows, const ox_space *cols, ox_rect **out);

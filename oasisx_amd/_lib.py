@@ -203,6 +203,7 @@ SIGNATURES = {
     "ox_space_create_part": (_I, [_P, _I, _I, _P, _L, _I, _L, C.POINTER(_P)]),
     "ox_space_view": (_I, [_P, C.POINTER(ox_space_info)]),
     "ox_space_windows": (_I, [_P, C.POINTER(ox_window_info)]),
+    "ox_space_windows_split": (_I, [_P, _I, C.POINTER(ox_window_info)]),
     "ox_space_destroy": (_I, [_P]),
     "ox_rect_create": (_I, [_P, _P, C.POINTER(_P)]),
     "ox_rect_view": (_I, [_P, C.POINTER(ox_rect_info)]),

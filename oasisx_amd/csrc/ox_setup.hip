@@ -616,6 +616,7 @@ struct ox_space {
   int32_t n_wblocks = 0, w_max = 0;
   int64_t n_list = 0, n_tiles = 0, n_over_16bit = 0;
   bool windows_built = false;
+  int windows_split = 0;  // split_entries the stream was built with
 };
 
 struct ox_rect {
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_win_codes(const int64_t *__restrict__ s
     }
 }
 
-int build_windows(ox_space *V, hipStream_t st) {
+int build_windows(ox_space *V, hipStream_t st, int split_entries) {
   const ox_pattern_store &P = V->P;
   const int ns = (int)P.n_slices;
   if (ns == 0 || P.size == 0) {
@@ -1418,7 +1419,7 @@ int build_windows(ox_space *V, hipStream_t st) {
   const int bpw = (spw + spb - 1) / spb;
   const int nwin = (ns + spw - 1) / spw;
   const int c_last = ns - (nwin - 1) * spw;
-  const int nb = (nwin - 1) * bpw + (c_last + spb - 1) / spb;
+  int nb = (nwin - 1) * bpw + (c_last + spb - 1) / spb;
   auto nblk = [](int64_t n) { return (unsigned)((n + 255) / 256); };
   const int64_t *slice_ptr = P.slice_ptr.as<int64_t>();
   const int32_t *cols = P.cols.as<int32_t>();
@@ -1442,66 +1443,64 @@ int build_windows(ox_space *V, hipStream_t st) {
   hipLaunchKernelGGL(k_win_blocks, dim3(nblk(ns)), dim3(256), 0, st, order.as<int32_t>(), ns, spw, bpw, spb, V->wb_slices.as<int32_t>(),
                      blk_of_slice.as<int32_t>());
   OX_LAUNCH_CHECK();
-  OX_TRY(V->wb_waves.alloc(sizeof(uint16_t) * (size_t)nb));
-  hipLaunchKernelGGL(k_win_schedule, dim3(nblk(nb)), dim3(256), 0, st, V->wb_slices.as<int32_t>(), slice_ptr, nb,
-                     V->wb_waves.as<uint16_t>());
-  OX_LAUNCH_CHECK();
   order.release();
   // ---- window lists: distinct (block, column) keys, chunks of whole sort windows ------------------------------------
   std::vector<int64_t> sp_h((size_t)ns + 1);
   OX_HIP(hipMemcpyAsync(sp_h.data(), slice_ptr, sizeof(int64_t) * ((size_t)ns + 1), hipMemcpyDeviceToHost, st));
   OX_HIP(hipStreamSynchronize(st));
   const int64_t chunk_slots = (int64_t)1 << 28;  // 2 GiB of keys per chunk (+ the sort's double buffer)
-  std::vector<std::unique_ptr<DevBuf>> parts;
-  std::vector<int64_t> part_n;
+  DevBuf ukey, wsize;
   int64_t total = 0;
-  for (int w0 = 0; w0 < nwin;) {
-    int w1 = w0 + 1;
-    const int s0 = w0 * spw;
-    while (w1 < nwin && sp_h[(size_t)std::min(ns, (w1 + 1) * spw)] - sp_h[(size_t)s0] <= chunk_slots) ++w1;
-    const int s1 = std::min(ns, w1 * spw);
-    const int64_t slot0 = sp_h[(size_t)s0], m = sp_h[(size_t)s1] - slot0;
-    if (m > 0) {
-      DevBuf k_in, k_out, flag, pos;
-      OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)m));
-      OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)m));
-      hipLaunchKernelGGL(k_win_entry_keys, dim3((s1 - s0 + 3) / 4), dim3(256), 0, st, slice_ptr, cols, blk_of_slice.as<int32_t>(), s0,
-                         s1, slot0, k_in.as<uint64_t>());
-      OX_LAUNCH_CHECK();
-      {
-        size_t tb = 0;
-        const int end_bit = std::min(64, 32 + bits_for((uint64_t)nb));
-        OX_HIP(rocprim::radix_sort_keys(nullptr, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
-        DevBuf tmp;
-        OX_TRY(tmp.alloc(tb));
-        OX_HIP(rocprim::radix_sort_keys(tmp.p, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
+  // the sorted distinct (block, column) keys of the current block assignment, the blocks' offsets into them and sizes
+  auto make_lists = [&](int nb_) -> int {
+    std::vector<std::unique_ptr<DevBuf>> parts;
+    std::vector<int64_t> part_n;
+    total = 0;
+    for (int w0 = 0; w0 < nwin;) {
+      int w1 = w0 + 1;
+      const int s0 = w0 * spw;
+      while (w1 < nwin && sp_h[(size_t)std::min(ns, (w1 + 1) * spw)] - sp_h[(size_t)s0] <= chunk_slots) ++w1;
+      const int s1 = std::min(ns, w1 * spw);
+      const int64_t slot0 = sp_h[(size_t)s0], m = sp_h[(size_t)s1] - slot0;
+      if (m > 0) {
+        DevBuf k_in, k_out, flag, pos;
+        OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)m));
+        OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)m));
+        hipLaunchKernelGGL(k_win_entry_keys, dim3((s1 - s0 + 3) / 4), dim3(256), 0, st, slice_ptr, cols, blk_of_slice.as<int32_t>(), s0,
+                           s1, slot0, k_in.as<uint64_t>());
+        OX_LAUNCH_CHECK();
+        {
+          size_t tb = 0;
+          const int end_bit = std::min(64, 32 + bits_for((uint64_t)nb_));
+          OX_HIP(rocprim::radix_sort_keys(nullptr, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
+          DevBuf tmp;
+          OX_TRY(tmp.alloc(tb));
+          OX_HIP(rocprim::radix_sort_keys(tmp.p, tb, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (size_t)m, 0, end_bit, st));
+          OX_HIP(hipStreamSynchronize(st));
+        }
+        k_in.release();
+        OX_TRY(flag.alloc(sizeof(int64_t) * ((size_t)m + 1)));
+        OX_TRY(pos.alloc(sizeof(int64_t) * ((size_t)m + 1)));
+        hipLaunchKernelGGL(k_win_flag_unique, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), m, flag.as<int64_t>());
+        OX_LAUNCH_CHECK();
+        OX_HIP(hipMemsetAsync(flag.as<int64_t>() + m, 0, sizeof(int64_t), st));
+        OX_TRY(exclusive_scan_i64(flag.as<int64_t>(), pos.as<int64_t>(), (size_t)m + 1, st));
+        int64_t nu = 0;
+        OX_HIP(hipMemcpyAsync(&nu, pos.as<int64_t>() + m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         OX_HIP(hipStreamSynchronize(st));
+        flag.release();
+        parts.emplace_back(new DevBuf());
+        OX_TRY(parts.back()->alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(nu, 1)));
+        hipLaunchKernelGGL(k_win_compact, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), pos.as<int64_t>(), m,
+                           parts.back()->as<uint64_t>());
+        OX_LAUNCH_CHECK();
+        OX_HIP(hipStreamSynchronize(st));
+        part_n.push_back(nu);
+        total += nu;
       }
-      k_in.release();
-      OX_TRY(flag.alloc(sizeof(int64_t) * ((size_t)m + 1)));
-      OX_TRY(pos.alloc(sizeof(int64_t) * ((size_t)m + 1)));
-      hipLaunchKernelGGL(k_win_flag_unique, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), m, flag.as<int64_t>());
-      OX_LAUNCH_CHECK();
-      OX_HIP(hipMemsetAsync(flag.as<int64_t>() + m, 0, sizeof(int64_t), st));
-      OX_TRY(exclusive_scan_i64(flag.as<int64_t>(), pos.as<int64_t>(), (size_t)m + 1, st));
-      int64_t nu = 0;
-      OX_HIP(hipMemcpyAsync(&nu, pos.as<int64_t>() + m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-      OX_HIP(hipStreamSynchronize(st));
-      flag.release();
-      parts.emplace_back(new DevBuf());
-      OX_TRY(parts.back()->alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(nu, 1)));
-      hipLaunchKernelGGL(k_win_compact, dim3(nblk(m)), dim3(256), 0, st, k_out.as<uint64_t>(), pos.as<int64_t>(), m,
-                         parts.back()->as<uint64_t>());
-      OX_LAUNCH_CHECK();
-      OX_HIP(hipStreamSynchronize(st));
-      part_n.push_back(nu);
-      total += nu;
+      w0 = w1;
     }
-    w0 = w1;
-  }
-  DevBuf ukey;
-  OX_TRY(ukey.alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(total, 1)));
-  {
+    OX_TRY(ukey.alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(total, 1)));
     int64_t off = 0;
     for (size_t i = 0; i < parts.size(); ++i) {  // chunks are in block order: the concatenation is sorted
       OX_HIP(hipMemcpyAsync(ukey.as<uint64_t>() + off, parts[i]->p, sizeof(uint64_t) * (size_t)part_n[i], hipMemcpyDeviceToDevice, st));
@@ -1509,12 +1508,60 @@ int build_windows(ox_space *V, hipStream_t st) {
     }
     OX_HIP(hipStreamSynchronize(st));
     parts.clear();
+    OX_TRY(V->wb_ptr.alloc(sizeof(int64_t) * ((size_t)nb_ + 1)));
+    OX_TRY(wsize.alloc(sizeof(int32_t) * (size_t)nb_));
+    hipLaunchKernelGGL(k_win_block_ptr, dim3(nblk(nb_ + 1)), dim3(256), 0, st, ukey.as<uint64_t>(), total, nb_, V->wb_ptr.as<int64_t>(),
+                       wsize.as<int32_t>());
+    OX_LAUNCH_CHECK();
+    return 0;
+  };
+  OX_TRY(make_lists(nb));
+  // ---- blocks whose window exceeds `split_entries` are cut in two (round 5; 0: never) -------------------------------------
+  // A block of 8 slices whose window holds more entries than the LDS budget of a three-column launch (2176) multiplies
+  // from the int32 columns inside that launch, at the lane = row speed; its two halves -- 4 slices each, neighbours along
+  // the locality curve, one per wave -- mostly fit.  Refined Delaunay mesh, 18.9 M P2 rows (tools/win_bench.py, A/B in
+  // one gpurun call): 36 864 -> 59 575 blocks, mean window 3093 -> 2380 entries, three-column mat-vec 1876-1904 -> 1748 us,
+  // ONE-column mat-vec (budget 6144: nothing was over it) 1091-1174 -> 1203-1280 us -- so the caller decides per space
+  // (the velocity pattern yes, the pressure pattern no).  One level only: a second cut (blocks of 2 slices, half the
+  // waves of a 256-thread block idle) measured 1760 / 1360 us.
+  for (int round = 0; round < 1 && split_entries > 0; ++round) {
+    std::vector<int32_t> ws((size_t)nb), sl((size_t)nb * 8);
+    OX_HIP(hipMemcpyAsync(ws.data(), wsize.p, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, st));
+    OX_HIP(hipMemcpyAsync(sl.data(), V->wb_slices.p, sizeof(int32_t) * (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+    OX_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> sl2, bos((size_t)ns, 0);
+    sl2.reserve(sl.size() + sl.size() / 2);
+    int nsplit = 0;
+    for (int b = 0; b < nb; ++b) {
+      int cnt = 0;
+      while (cnt < 8 && sl[(size_t)b * 8 + cnt] >= 0) ++cnt;
+      const bool split = ws[(size_t)b] > split_entries && cnt > 4;
+      const int cut = split ? (cnt + 1) / 2 : cnt;
+      for (int part = 0; part < (split ? 2 : 1); ++part) {
+        const int j0 = part ? cut : 0, j1 = part ? cnt : cut;
+        const int nbk = (int)(sl2.size() / 8);
+        for (int j = 0; j < 8; ++j) {
+          const int32_t s_ = (j0 + j < j1) ? sl[(size_t)b * 8 + j0 + j] : -1;
+          sl2.push_back(s_);
+          if (s_ >= 0) bos[(size_t)s_] = nbk;
+        }
+      }
+      nsplit += split ? 1 : 0;
+    }
+    if (nsplit > 0) {
+      nb = (int)(sl2.size() / 8);
+      OX_TRY(V->wb_slices.alloc(sizeof(int32_t) * sl2.size()));
+      OX_HIP(hipMemcpyAsync(V->wb_slices.p, sl2.data(), sizeof(int32_t) * sl2.size(), hipMemcpyHostToDevice, st));
+      OX_HIP(hipMemcpyAsync(blk_of_slice.p, bos.data(), sizeof(int32_t) * (size_t)ns, hipMemcpyHostToDevice, st));
+      OX_HIP(hipStreamSynchronize(st));
+      OX_TRY(make_lists(nb));
+    } else {
+      break;
+    }
   }
-  OX_TRY(V->wb_ptr.alloc(sizeof(int64_t) * ((size_t)nb + 1)));
-  DevBuf wsize;
-  OX_TRY(wsize.alloc(sizeof(int32_t) * (size_t)nb));
-  hipLaunchKernelGGL(k_win_block_ptr, dim3(nblk(nb + 1)), dim3(256), 0, st, ukey.as<uint64_t>(), total, nb, V->wb_ptr.as<int64_t>(),
-                     wsize.as<int32_t>());
+  OX_TRY(V->wb_waves.alloc(sizeof(uint16_t) * (size_t)nb));
+  hipLaunchKernelGGL(k_win_schedule, dim3(nblk(nb)), dim3(256), 0, st, V->wb_slices.as<int32_t>(), slice_ptr, nb,
+                     V->wb_waves.as<uint16_t>());
   OX_LAUNCH_CHECK();
   OX_TRY(V->wlist.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1)));
   hipLaunchKernelGGL(k_win_list, dim3(nblk(total)), dim3(256), 0, st, ukey.as<uint64_t>(), total, V->wlist.as<int32_t>());
@@ -1545,15 +1592,21 @@ int build_windows(ox_space *V, hipStream_t st) {
   OX_HIP(hipStreamSynchronize(st));
   V->n_wblocks = nb, V->w_max = wmax, V->n_list = total, V->n_tiles = n_tiles, V->n_over_16bit = (int64_t)over;
   V->windows_built = true;
+  V->windows_split = split_entries;
   return 0;
 }
 
 }  // namespace
 
-extern "C" int ox_space_windows(ox_space *V, ox_window_info *v) {
+extern "C" int ox_space_windows_split(ox_space *V, int split_entries, ox_window_info *v);
+extern "C" int ox_space_windows(ox_space *V, ox_window_info *v) { return ox_space_windows_split(V, 0, v); }
+
+extern "C" int ox_space_windows_split(ox_space *V, int split_entries, ox_window_info *v) {
   if (!V || !v) OX_FAIL("ox_space_windows: null argument");
   if (!V->row_pos.p && V->n > 0) OX_FAIL("ox_space_windows: the space carries no locality positions");
-  if (!V->windows_built && build_windows(V, nullptr)) {
+  if (split_entries < 0) split_entries = 0;
+  if (V->windows_built && V->windows_split != split_entries) V->windows_built = false;  // (another cut: built anew)
+  if (!V->windows_built && build_windows(V, nullptr, split_entries)) {
     // a failed build (out of memory in a 2-GiB key chunk, ...) leaves nothing half-built behind: the space stays usable
     // on the lane = row kernels, and a later call starts from scratch
     V->wb_slices.release(), V->wb_waves.release(), V->wb_ptr.release();

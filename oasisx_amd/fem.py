@@ -689,10 +689,11 @@ class FunctionSpace:
         if part is not None:
             self.halo = self._build_halo(part, ghost_owner, cd0g)
 
-    def build_windows(self) -> bool:
+    def build_windows(self, split: int = 0) -> bool:
         """LDS-window stream of the space's square pattern (M, K, A share it): see ``SellPattern.build_windows``.
         The rows' positions in the pure locality order are recomputed from the dof coordinates with the key the
-        numbering was made with."""
+        numbering was made with.  ``split`` > 0 (library-built spaces): blocks whose window holds more entries are cut
+        in two -- for patterns multiplied with three right-hand sides (``ox_space_windows_split``)."""
         mesh = self.mesh
         if mesh.device.type != "cuda" or self.pattern.size == 0 or getattr(self.pattern, "wcode", None) is not None:
             return getattr(self.pattern, "wcode", None) is not None
@@ -701,7 +702,7 @@ class FunctionSpace:
 
             P, own, dev = self.pattern, self.native.handle, mesh.device
             w = _lib.ox_window_info()
-            _lib.check(_lib.load().ox_space_windows(own.ptr, C.byref(w)), "ox_space_windows")
+            _lib.check(_lib.load().ox_space_windows_split(own.ptr, int(split), C.byref(w)), "ox_space_windows")
             nb = int(w.n_wblocks)
             if nb == 0:
                 return False

@@ -262,16 +262,18 @@ class FractionalStep_AB_CN:
             self._grad_p_Mat = MultiSellMatrix(self._pat_vq, mesh.gdim, "grad_p")
             self._divu_Mat = MultiSellMatrix(self._pat_qv, mesh.gdim, "divu")
         # LDS-window stream of the velocity pattern (M, K, A share it): single-GPU operators of a degree-2 space
-        def windows(space, what):
+        def windows(space, what, split=0):
             # (an optional storage level: a failed build -- out of device memory in its sorts -- leaves the space on the
             # lane = row kernels, with a warning; results are the same either way)
             try:
-                space.build_windows()
+                space.build_windows(split)
             except _lib.OasisxHipError as e:
                 logging.getLogger("oasisx").warning("LDS-window stream of the %s pattern not built (%s): its mat-vecs run "
                                                     "on the lane = row kernels", what, e)
         if self._spmv_windows:
-            windows(Vi, "velocity")
+            # (its mat-vecs run with gdim right-hand sides: blocks beyond the LDS budget of a three-column launch are cut
+            # in two; the one-column pressure pattern keeps whole blocks -- csrc/ox_setup.hip build_windows)
+            windows(Vi, "velocity", 2176 if mesh.gdim == 3 else 3072)
         # the pressure matrix too where it has no pair-slot stream to lose (meshes that are not lattices carry no
         # value dictionary): refined Delaunay mesh, 2.4 M P1 rows: 120 -> 86 us per mat-vec, 0.73 of the HBM peak
         if self._options.get("spmv_windows_pressure", self._spmv_windows and not self._lattice) and mesh.device.type == "cuda":

@@ -37,17 +37,25 @@ def _space_impl(kind, dim, n, brick, fem, M):
     return fem.FunctionSpace(mesh, 2, window=1024, brick=brick)
 
 
-@pytest.mark.parametrize("setup", ["native", "torch"])
+@pytest.mark.parametrize("setup,split", [("native", 0), ("torch", 0), ("native", 1200)])
 @pytest.mark.parametrize("kind,dim,n,brick", [("box", 3, 17, True), ("box", 3, 9, False), ("box", 2, 40, True),
                                              ("delaunay", 3, 6, False), ("delaunay", 2, 14, False)])
-def test_window_stream_reproduces_the_columns_and_the_matvec_bit_for_bit(hip, kind, dim, n, brick, setup):
+def test_window_stream_reproduces_the_columns_and_the_matvec_bit_for_bit(hip, kind, dim, n, brick, setup, split):
+    """``split``: blocks whose window holds more entries are cut in two (``ox_space_windows_split``, what the solver asks
+    for on its velocity pattern): the same checks on blocks of 4 + 4 slices."""
     from oasisx_amd import _lib
     from oasisx_amd.la import SellMatrix
 
     V = _space(kind, dim, n, brick, setup)
     assert (V.native is not None) == (setup == "native")
-    assert V.build_windows()
+    assert V.build_windows(split)
     P = V.pattern
+    if split:
+        wsz = (P.wb_ptr[1:] - P.wb_ptr[:-1]).cpu().numpy()
+        cnt = (P.wb_slices.cpu().numpy() >= 0).sum(axis=1)
+        assert ((wsz <= split) | (cnt <= 4)).all()  # a block over the bound has been cut (one level: 4 slices may stay over)
+        if dim == 3:
+            assert (cnt <= 4).any(), "the bound is meant to cut blocks of these meshes"
     # ---- structure: every slice in exactly one block, every slot's column recovered from its window ----------------
     sl = P.wb_slices.cpu().numpy()
     used = np.sort(sl[sl >= 0])

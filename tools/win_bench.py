@@ -62,7 +62,7 @@ for brick in ([int(b) for b in os.environ.get("BRICKS", "1,0").split(",")] if ki
     Am.vals.copy_(Mm.vals * (1.0 + 0.25 * torch.sin(torch.arange(P.size, device="cuda", dtype=torch.float64))))
     Am.version += 1
     t0 = time.perf_counter()
-    built = V.build_windows()
+    built = V.build_windows(int(os.environ.get("SPLIT", "0")))  # SPLIT=2176: over-budget blocks cut in two
     torch.cuda.synchronize()
     t_win = time.perf_counter() - t0
     # the structs were made before the windows existed: refresh them
