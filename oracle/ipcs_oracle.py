@@ -98,11 +98,16 @@ def local_edges(d: int):
     return [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
 
 
+def local_faces(d: int):
+    """Local face f of a tetrahedron = the three vertices other than f (the P3 face dofs, in this order)."""
+    if d != 3:
+        raise ValueError("faces carry dofs on tetrahedra only")
+    return [(1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2)]
+
+
 def num_cell_dofs(d: int, degree: int) -> int:
     if degree == 3:
-        if d != 2:
-            raise ValueError("Lagrange degree 3 is restated on triangles only")
-        return 10
+        return 10 if d == 2 else 20  # vertices + 2 per edge + (the cell's own dof | one per face)
     return d + 1 if degree == 1 else (d + 1) + len(local_edges(d))
 
 
@@ -113,38 +118,64 @@ def num_cell_dofs(d: int, degree: int) -> int:
 GLL3 = (0.5 - 0.5 / math.sqrt(5.0), 0.5 + 0.5 / math.sqrt(5.0))
 
 
-def p3_nodes_2d() -> np.ndarray:
-    """Barycentric coordinates (10, 3) of the P3 nodes: vertices, then per local edge (a, b) the node nearer a and
-    the node nearer b, then the centroid."""
-    nodes = [np.eye(3)[a] for a in range(3)]
-    for a, b in local_edges(2):
+def p3_nodes(d: int) -> np.ndarray:
+    """Barycentric coordinates (nd, d + 1) of the P3 nodes: vertices, then per local edge (a, b) the node nearer a and
+    the node nearer b, then -- triangles -- the centroid, or -- tetrahedra -- the centroids of the four faces."""
+    nv = d + 1
+    nodes = [np.eye(nv)[a] for a in range(nv)]
+    for a, b in local_edges(d):
         for t in GLL3:
-            v = np.zeros(3)
+            v = np.zeros(nv)
             v[a], v[b] = 1.0 - t, t
             nodes.append(v)
-    nodes.append(np.full(3, 1.0 / 3.0))
+    if d == 2:
+        nodes.append(np.full(3, 1.0 / 3.0))
+    else:
+        for f in local_faces(3):
+            v = np.zeros(4)
+            v[list(f)] = 1.0 / 3.0
+            nodes.append(v)
     return np.array(nodes)
 
 
-def _p3_monomials(x, y):
-    """The 10 monomials of degree <= 3 and their x / y derivatives at points (x, y)."""
-    ex = [(i, j) for i in range(4) for j in range(4 - i)]
-    m = np.stack([x ** i * y ** j for i, j in ex], axis=1)
-    mx = np.stack([i * x ** max(i - 1, 0) * y ** j if i > 0 else np.zeros_like(x) for i, j in ex], axis=1)
-    my = np.stack([j * x ** i * y ** max(j - 1, 0) if j > 0 else np.zeros_like(x) for i, j in ex], axis=1)
-    return m, mx, my
+def p3_nodes_2d() -> np.ndarray:
+    return p3_nodes(2)
 
 
-_P3_COEF = None
+def _p3_exponents(d: int):
+    if d == 2:
+        return [(i, j) for i in range(4) for j in range(4 - i)]
+    return [(i, j, k) for i in range(4) for j in range(4 - i) for k in range(4 - i - j)]
 
 
-def _p3_coefficients():
-    global _P3_COEF
-    if _P3_COEF is None:
-        n = p3_nodes_2d()
-        V, _, _ = _p3_monomials(n[:, 1], n[:, 2])  # reference coordinates (x, y) = (lambda_1, lambda_2)
-        _P3_COEF = np.linalg.inv(V)  # column i: monomial coefficients of phi_i
-    return _P3_COEF
+def _p3_monomials(*xs):
+    """The monomials of degree <= 3 in d = len(xs) variables (10 / 20) and their partial derivatives at the points:
+    (m, dm_0, ..., dm_{d-1})."""
+    d = len(xs)
+    ex = _p3_exponents(d)
+
+    def mono(e, skip=None):
+        out = np.ones_like(xs[0])
+        for v in range(d):
+            pw = e[v] - (1 if v == skip else 0)
+            out = out * xs[v] ** max(pw, 0)
+        return out
+    m = np.stack([mono(e) for e in ex], axis=1)
+    ders = []
+    for v in range(d):
+        ders.append(np.stack([e[v] * mono(e, skip=v) if e[v] > 0 else np.zeros_like(xs[0]) for e in ex], axis=1))
+    return (m, *ders)
+
+
+_P3_COEF = {}
+
+
+def _p3_coefficients(d: int = 2):
+    if d not in _P3_COEF:
+        n = p3_nodes(d)
+        V = _p3_monomials(*[n[:, a] for a in range(1, d + 1)])[0]  # reference coordinates = (lambda_1, ..., lambda_d)
+        _P3_COEF[d] = np.linalg.inv(V)  # column i: monomial coefficients of phi_i
+    return _P3_COEF[d]
 
 
 def tabulate(d: int, degree: int, bary: np.ndarray):
@@ -172,17 +203,17 @@ def tabulate(d: int, degree: int, bary: np.ndarray):
             dphi[:, nv + e, a] = 4 * bary[:, b]
             dphi[:, nv + e, b] = 4 * bary[:, a]
         return phi, dphi
-    if degree == 3 and d == 2:
-        # phi as a polynomial of (lambda_1, lambda_2) alone (lambda_0 = 1 - lambda_1 - lambda_2 eliminated): its
-        # derivative with respect to lambda_0 is then 0 and grad phi = phi_x grad lambda_1 + phi_y grad lambda_2
-        Cf = _p3_coefficients()
-        m, mx, my = _p3_monomials(bary[:, 1], bary[:, 2])
-        phi = m @ Cf
-        dphi = np.zeros((Q, 10, 3))
-        dphi[:, :, 1] = mx @ Cf
-        dphi[:, :, 2] = my @ Cf
+    if degree == 3:
+        # phi as a polynomial of (lambda_1, ..., lambda_d) alone (lambda_0 = 1 - sum eliminated): its derivative with
+        # respect to lambda_0 is then 0 and grad phi = sum_{b >= 1} d phi / d lambda_b grad lambda_b
+        Cf = _p3_coefficients(d)
+        tabs = _p3_monomials(*[bary[:, a] for a in range(1, d + 1)])
+        phi = tabs[0] @ Cf
+        dphi = np.zeros((Q, phi.shape[1], nv))
+        for b in range(1, nv):
+            dphi[:, :, b] = tabs[b] @ Cf
         return phi, dphi
-    raise ValueError("Lagrange degree 1 and 2 (and 3 on triangles) are restated")
+    raise ValueError("Lagrange degree 1, 2 and 3 are restated")
 
 
 # ----------------------------------------------------------------------------
@@ -273,20 +304,35 @@ def build_dofmap(cells: np.ndarray, nverts: int, degree: int):
     edge_verts = np.stack([uniq // nverts, uniq % nverts], axis=1)
     if degree == 3:
         # two dofs per edge, numbered from its lower global vertex to its higher one: nverts + 2 e + {0, 1}; the
-        # cell lists, per local edge (a, b), the node nearer a first; then one interior dof per cell
-        if d != 2:
-            raise ValueError("Lagrange degree 3 is restated on triangles only")
+        # cell lists, per local edge (a, b), the node nearer a first; then one interior dof per cell (triangles) or one
+        # dof per face, faces numbered by ascending sorted vertex triple (tetrahedra)
         ne, nc = uniq.shape[0], cells.shape[0]
-        ed = np.empty((nc, 3, 2), dtype=np.int64)
+        ed = np.empty((nc, len(edges), 2), dtype=np.int64)
         for k, (a, b) in enumerate(edges):
             flip = (cells[:, a] > cells[:, b]).astype(np.int64)  # the node nearer a is the edge's SECOND dof
             ed[:, k, 0] = nverts + 2 * edge_ids[:, k] + flip
             ed[:, k, 1] = nverts + 2 * edge_ids[:, k] + 1 - flip
-        interior = nverts + 2 * ne + np.arange(nc, dtype=np.int64)
-        cell_dofs = np.concatenate([cells, ed.reshape(nc, 6), interior[:, None]], axis=1)
-        return cell_dofs, nverts + 2 * ne + nc, edge_verts
+        if d == 2:
+            interior = nverts + 2 * ne + np.arange(nc, dtype=np.int64)
+            cell_dofs = np.concatenate([cells, ed.reshape(nc, 6), interior[:, None]], axis=1)
+            return cell_dofs, nverts + 2 * ne + nc, edge_verts
+        _, face_ids, nf = _face_ids(cells, nverts)
+        cell_dofs = np.concatenate([cells, ed.reshape(nc, 12), nverts + 2 * ne + face_ids], axis=1)
+        return cell_dofs, nverts + 2 * ne + nf, edge_verts
     cell_dofs = np.concatenate([cells, nverts + edge_ids], axis=1)
     return cell_dofs, nverts + uniq.shape[0], edge_verts
+
+
+def _face_ids(cells, nverts):
+    """Faces of a tetrahedral mesh numbered by ascending sorted vertex triple: (face vertices (nf, 3), ids (nc, 4), nf)."""
+    tri = np.stack([np.sort(cells[:, list(f)], axis=1) for f in local_faces(3)], axis=1)  # (nc, 4, 3)
+    nv64 = np.int64(nverts)
+    if float(nverts) ** 3 >= 2.0 ** 62:
+        raise ValueError("face keys overflow int64")
+    key = (tri[:, :, 0] * nv64 + tri[:, :, 1]) * nv64 + tri[:, :, 2]
+    uniq, inv = np.unique(key.ravel(), return_inverse=True)
+    fv = np.stack([uniq // (nv64 * nv64), (uniq // nv64) % nv64, uniq % nv64], axis=1)
+    return fv, inv.reshape(key.shape), int(uniq.shape[0])
 
 
 def dof_coordinates(coords, degree, edge_verts, cells=None):
@@ -295,6 +341,9 @@ def dof_coordinates(coords, degree, edge_verts, cells=None):
     if degree == 3:
         lo, hi = coords[edge_verts[:, 0]], coords[edge_verts[:, 1]]
         on_edges = np.stack([(1.0 - t) * lo + t * hi for t in GLL3], axis=1).reshape(-1, coords.shape[1])
+        if coords.shape[1] == 3:
+            fv, _, _ = _face_ids(cells, coords.shape[0])
+            return np.concatenate([coords, on_edges, coords[fv].mean(axis=1)], axis=0)
         return np.concatenate([coords, on_edges, coords[cells].mean(axis=1)], axis=0)
     mid = 0.5 * (coords[edge_verts[:, 0]] + coords[edge_verts[:, 1]])
     return np.concatenate([coords, mid], axis=0)
