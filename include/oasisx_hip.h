@@ -244,6 +244,8 @@ typedef struct {
   const uint8_t *adj_pos;       /* device [n_pairs][pw]                                      */
   const int64_t *pair_start;    /* device [n_dofs+1]: cells per dof = pair_start[r+1] - pair_start[r] */
   ox_pattern_info pattern;      /* square operator on the space (M, K, A share it: fracstep.py:293-294) */
+  int64_t n_faces;              /* degree 3 on tetrahedra: faces (one dof each: initial id n_vertices + 2 n_edges + face) */
+  const uint64_t *face_keys;    /* device [n_faces]: (v0 * n_vertices + v1) * n_vertices + v2 of the sorted triple, ascending */
 } ox_space_info;
 
 typedef struct {

@@ -143,6 +143,8 @@ class ox_space_info(C.Structure):
         ("adj_pos", C.c_void_p),
         ("pair_start", C.c_void_p),
         ("pattern", ox_pattern_info),
+        ("n_faces", C.c_int64),
+        ("face_keys", C.c_void_p),
     ]
 
 

@@ -6,6 +6,7 @@
 // so the rule is exact, as FFCx's is in the reference).
 #include "fe_tables.h"
 #include "fe_tables_h.h"
+#include "fe_tables_h3.h"
 #include "ox_kernels.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -14,25 +15,30 @@
 #define OX_KIND_STIFF 1
 #define OX_KIND_CONV 2
 
-// RULE 0: the degree-5 rules (every form of a P1 / P2 velocity is integrated exactly); RULE 1 (triangles): the degree-9
-// rule a P3 velocity needs (convection: 3 + 2 + 3 = 8).  A kernel that couples two elements tabulates both on the rule
-// of the higher one (OX_RULE_OF).  P3 = Basix's gll_warped variant (reference fracstep.py:170,181), triangles only.
+// RULE 0: the degree-5 rules (every form of a P1 / P2 velocity is integrated exactly); RULE 1: the degree-9 rule a P3
+// velocity needs (convection: 3 + 2 + 3 = 8) -- 25 collapsed Gauss-Jacobi points on triangles, 70 Grundmann-Moeller points
+// on tetrahedra (round 5).  A kernel that couples two elements tabulates both on the rule of the higher one (OX_RULE_OF).
+// P3 = Basix's gll_warped variant (reference fracstep.py:170,181).
 #define OX_RULE_OF(DA, DB) (((DA) == 3 || (DB) == 3) ? 1 : 0)
 template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
 struct Elem {
-  static_assert(DEG >= 1 && DEG <= 3 && (DEG < 3 || GDIM == 2), "Lagrange degree 1, 2 (and 3 on triangles)");
-  static_assert(RULE == 0 || GDIM == 2, "the high-order rule is tabulated on triangles");
+  static_assert(DEG >= 1 && DEG <= 3, "Lagrange degree 1, 2, 3");
   static_assert(DEG < 3 || RULE == 1, "P3 needs the degree-9 rule");
   static constexpr int NV = GDIM + 1;
-  static constexpr int ND = DEG == 1 ? GDIM + 1 : (DEG == 3 ? 10 : (GDIM == 2 ? 6 : 10));
-  static constexpr int NQ = RULE == 1 ? OX_NQ2H : (GDIM == 2 ? OX_NQ2 : OX_NQ3);
+  // P3: vertices + 2 per edge + the cell's own dof (triangles) / one per face (tetrahedra)
+  static constexpr int ND = DEG == 1 ? GDIM + 1 : (DEG == 3 ? (GDIM == 2 ? 10 : 20) : (GDIM == 2 ? 6 : 10));
+  static constexpr int NQ = RULE == 1 ? (GDIM == 2 ? OX_NQ2H : OX_NQ3H) : (GDIM == 2 ? OX_NQ2 : OX_NQ3);
   static constexpr int GS = GDIM == 2 ? 6 : 10;
   __host__ __device__ static constexpr double w(int q) {
-    if constexpr (RULE == 1) return OX_QW2H[q];
+    if constexpr (RULE == 1 && GDIM == 3) return OX_QW3H[q];
+    else if constexpr (RULE == 1) return OX_QW2H[q];
     else return GDIM == 2 ? OX_QW2[q] : OX_QW3[q];
   }
   __host__ __device__ static constexpr double phi(int q, int k) {
-    if constexpr (RULE == 1 && DEG == 1) return OX_PHI2H_1[q][k];
+    if constexpr (RULE == 1 && GDIM == 3 && DEG == 1) return OX_PHI3H_1[q][k];
+    else if constexpr (RULE == 1 && GDIM == 3 && DEG == 2) return OX_PHI3H_2[q][k];
+    else if constexpr (RULE == 1 && GDIM == 3) return OX_PHI3H_3[q][k];
+    else if constexpr (RULE == 1 && DEG == 1) return OX_PHI2H_1[q][k];
     else if constexpr (RULE == 1 && DEG == 2) return OX_PHI2H_2[q][k];
     else if constexpr (RULE == 1) return OX_PHI2H_3[q][k];
     else if constexpr (GDIM == 2 && DEG == 1) return OX_PHI2_1[q][k];
@@ -41,7 +47,10 @@ struct Elem {
     else return OX_PHI3_2[q][k];
   }
   __host__ __device__ static constexpr double dphi(int q, int k, int b) {
-    if constexpr (RULE == 1 && DEG == 1) return OX_DPHI2H_1[q][k][b];
+    if constexpr (RULE == 1 && GDIM == 3 && DEG == 1) return OX_DPHI3H_1[q][k][b];
+    else if constexpr (RULE == 1 && GDIM == 3 && DEG == 2) return OX_DPHI3H_2[q][k][b];
+    else if constexpr (RULE == 1 && GDIM == 3) return OX_DPHI3H_3[q][k][b];
+    else if constexpr (RULE == 1 && DEG == 1) return OX_DPHI2H_1[q][k][b];
     else if constexpr (RULE == 1 && DEG == 2) return OX_DPHI2H_2[q][k][b];
     else if constexpr (RULE == 1) return OX_DPHI2H_3[q][k][b];
     else if constexpr (GDIM == 2 && DEG == 1) return OX_DPHI2_1[q][k][b];
@@ -81,12 +90,16 @@ __device__ const RtTab<3, 1> RT31 = make_rt<3, 1>();
 __device__ const RtTab<3, 2> RT32 = make_rt<3, 2>();
 __device__ const RtTab<2, 3, 1> RT23 = make_rt<2, 3, 1>();
 __device__ const RtTab<2, 2, 1> RT22H = make_rt<2, 2, 1>();  // P2 rows next to a P3 velocity (div(u) q, rows Q)
+__device__ const RtTab<3, 3, 1> RT33 = make_rt<3, 3, 1>();   // P3 on tetrahedra (round 5)
+__device__ const RtTab<3, 2, 1> RT32H = make_rt<3, 2, 1>();
 template <int GDIM, int DEG, int RULE = (DEG == 3 ? 1 : 0)>
 __device__ __forceinline__ const RtTab<GDIM, DEG, RULE> &rt() {
-  if constexpr (RULE == 1 && DEG == 3) return RT23;
+  if constexpr (RULE == 1 && DEG == 3 && GDIM == 3) return RT33;
+  else if constexpr (RULE == 1 && DEG == 3) return RT23;
   else if constexpr (RULE == 1) {
     static_assert(DEG == 2, "row tables on the high-order rule: P2 and P3");
-    return RT22H;
+    if constexpr (GDIM == 3) return RT32H;
+    else return RT22H;
   } else if constexpr (GDIM == 2 && DEG == 1) return RT21;
   else if constexpr (GDIM == 2 && DEG == 2) return RT22;
   else if constexpr (GDIM == 3 && DEG == 1) return RT31;
@@ -154,12 +167,35 @@ __device__ const ConvTab<3, 2> CT32 = make_conv<3, 2>();
 __device__ const ConvTab<2, 3> CT23 = make_conv<2, 3>();
 template <int GDIM, int DEG>
 __device__ __forceinline__ const ConvTab<GDIM, DEG> &ct() {
+  static_assert(!(GDIM == 3 && DEG == 3), "P3 tetrahedra: convection by quadrature (QuadTab33), no tensor table");
   if constexpr (DEG == 3) return CT23;
   else if constexpr (GDIM == 2 && DEG == 1) return CT21;
   else if constexpr (GDIM == 2 && DEG == 2) return CT22;
   else if constexpr (GDIM == 3 && DEG == 1) return CT31;
   else return CT32;
 }
+
+// P3 on tetrahedra: the tensor T[i][k][(j, b)] the kernels above read from LDS would be 20 x 20 x 60 doubles = 192 KB --
+// it does not fit.  The convection rows of that element are formed by QUADRATURE at run time instead: the values and
+// derivatives of all 20 basis functions at the 70 points sit in device memory and are read with wave-uniform indices
+// (scalar loads: every lane of a wave is at the same point q and basis function k / j); only w_q phi_i(x_q) depends on
+// the lane (its row dof i) and comes from an LDS copy [20][70].
+struct QuadTab33 {
+  double phi[OX_NQ3H][20];
+  double dphi[OX_NQ3H][20][3];  // d / d lambda_1..3 (the lambda_0 column of the P3 tabulation is identically zero)
+};
+constexpr QuadTab33 make_qt33() {
+  QuadTab33 t{};
+  for (int q = 0; q < OX_NQ3H; ++q)
+    for (int k = 0; k < 20; ++k) {
+      t.phi[q][k] = OX_PHI3H_3[q][k];
+      for (int b = 0; b < 3; ++b) t.dphi[q][k][b] = OX_DPHI3H_3[q][k][b + 1];
+    }
+  return t;
+}
+__device__ const QuadTab33 QT33 = make_qt33();
+template <int GDIM, int DEG>
+inline constexpr bool OX_CONV_BY_QUADRATURE = (GDIM == 3 && DEG == 3);
 
 template <int GDIM>
 __device__ __forceinline__ void load_geom(const double *__restrict__ g, double (&G)[GDIM + 1][GDIM],
@@ -221,7 +257,8 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
                                                const double *dM, const double *dK) {
   using E = Elem<GDIM, DEG>;
   constexpr int ND = E::ND, NQ = E::NQ, GS = E::GS;
-  constexpr int NCB = COMBOS<GDIM, DEG>.n;
+  constexpr bool QUAD = OX_CONV_BY_QUADRATURE<GDIM, DEG>;
+  constexpr int NCB = QUAD ? 1 : COMBOS<GDIM, DEG>.n;
   constexpr int TS = NCB * ND + 2;
   const int64_t base = A.slice_ptr[slice];
   const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
@@ -245,7 +282,10 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
       iloc[u] = adj.adj_loc[pidx];
       ok[u] = inb && e[u] >= 0;
       if (!ok[u]) e[u] = 0;  // loads stay unconditional (cell 0), the result is not accumulated
-      if constexpr (PW == 16) {
+      if constexpr (PW == 32) {
+        *reinterpret_cast<uint4 *>(pos[u]) = *reinterpret_cast<const uint4 *>(adj_pos + pidx * 32);
+        *reinterpret_cast<uint4 *>(pos[u] + 16) = *reinterpret_cast<const uint4 *>(adj_pos + pidx * 32 + 16);
+      } else if constexpr (PW == 16) {
         *reinterpret_cast<uint4 *>(pos[u]) = *reinterpret_cast<const uint4 *>(adj_pos + pidx * 16);
       } else if constexpr (PW == 8) {
         *reinterpret_cast<uint2 *>(pos[u]) = *reinterpret_cast<const uint2 *>(adj_pos + pidx * 8);
@@ -329,6 +369,35 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
 #pragma unroll
             for (int b = 0; b <= GDIM; ++b)
               if (E::dphi(q, j, b) != 0.0) c[j] = fma(E::dphi(q, j, b), h[b], c[j]);
+        }
+      } else if constexpr (QUAD) {
+        // convection row of a P3 tetrahedron by quadrature (see QuadTab33): at every point u_ab(x_q) = sum_k phi_k uc_k,
+        // beta_b = G[b] . u_ab, and C[i][j] += w_q phi_i(x_q) sum_b beta_b d(phi_j)/d(lambda_b)
+        const double *__restrict__ wpi = tconv + i * NQ;  // (LDS: w_q phi_i(x_q) of THIS lane's row dof)
+        for (int q = 0; q < NQ; ++q) {
+          double uq[GDIM];
+#pragma unroll
+          for (int d = 0; d < GDIM; ++d) uq[d] = 0.0;
+#pragma unroll
+          for (int k = 0; k < ND; ++k) {
+            const double pk = QT33.phi[q][k];
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) uq[d] = fma(pk, uc[u][k][d], uq[d]);
+          }
+          const double wq = wpi[q];
+          double sb[GDIM];  // w phi_i beta_b for b = 1..3 (the lambda_0 derivatives of the tabulation are zero)
+#pragma unroll
+          for (int b = 1; b <= GDIM; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int d = 0; d < GDIM; ++d) v = fma(G[u][b][d], uq[d], v);
+            sb[b - 1] = wq * v;
+          }
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+#pragma unroll
+            for (int b = 0; b < GDIM; ++b) c[j] = fma(QT33.dphi[q][j][b], sb[b], c[j]);
+          }
         }
       } else {
         // convection row: C[i][j] = int (uab . grad phi_j) phi_i   (fracstep.py:355-358), as the tensor
@@ -457,19 +526,24 @@ __global__ __launch_bounds__(BLK ? 512 : 256) void k_assemble_rows(ox_cells cell
                                                        int bin_width) {
   using E = Elem<GDIM, DEG>;
   constexpr int ND = E::ND;
-  constexpr int NCB = COMBOS<GDIM, DEG>.n;
+  constexpr bool QUAD = OX_CONV_BY_QUADRATURE<GDIM, DEG>;
+  constexpr int NCB = QUAD ? 1 : COMBOS<GDIM, DEG>.n;
   constexpr int TS = NCB * ND + 2;  // doubles per row dof in LDS: 16 B of padding put the rows of
                                     // different i on different banks for the 16-byte reads
   extern __shared__ double acc_all[];  // [4 waves][bin_width][64]  (BLK: the row block's slices back to back)
   __shared__ double dM[DICT ? 256 : 1], dK[DICT ? 256 : 1];
-  __shared__ __attribute__((aligned(16))) double tconv[KIND == OX_KIND_CONV ? ND * TS : 2];
+  // (P3 tetrahedra: w_q phi_i(x_q), [ND][NQ], for the quadrature form of the convection rows)
+  __shared__ __attribute__((aligned(16))) double tconv[KIND == OX_KIND_CONV ? (QUAD ? ND * E::NQ : ND * TS) : 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nthr = blockDim.x, nwave = blockDim.x >> 6;  // 4 waves per block, fewer for very wide rows
   if constexpr (DICT) {
     for (int i = threadIdx.x; i < F.nMd; i += nthr) dM[i] = F.Md[i];
     for (int i = threadIdx.x; i < F.nKd; i += nthr) dK[i] = F.Kd[i];
   }
-  if constexpr (KIND == OX_KIND_CONV) {
+  if constexpr (KIND == OX_KIND_CONV && QUAD) {
+    const auto &Rq = rt<GDIM, DEG>();
+    for (int idx = threadIdx.x; idx < ND * E::NQ; idx += nthr) tconv[idx] = Rq.wphi[idx / E::NQ][idx % E::NQ];
+  } else if constexpr (KIND == OX_KIND_CONV) {
     const double *src = &ct<GDIM, DEG>().t[0][0][0];
     constexpr int NT = ND * NCB * ND, PER = (NT + 63) / 64;  // loads per thread of a 64-thread block
     double tv[PER];
@@ -579,7 +653,7 @@ static int launch_row_blocks(int degree, const ox_cells *cells, const int32_t *c
     if (pw != P) OX_FAIL("assemble: adj_pos stride %d, expected %d", pw, P);                                          \
     return launch_row_blocks_t<GD, DG, KIND, P>(cells, cell_dofs, adj, adj_pos, A, F, n_blocks, blk_ptr, lds_entries, st); \
   }
-  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16)
+  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16) OX_ROWS_CASE(3, 3, 32)
 #undef OX_ROWS_CASE
   OX_FAIL("assemble: unsupported gdim=%d degree=%d", g, degree);
 }
@@ -596,7 +670,7 @@ static int launch_rows(int degree, const ox_cells *cells, const int32_t *cell_do
     return launch_rows_t<GD, DG, KIND, P>(cells, cell_dofs, adj, adj_pos, A, F, n_bins, bin_ptr, \
                                           bin_slices, bin_width, st);                         \
   }
-  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16)
+  OX_ROWS_CASE(2, 1, 4) OX_ROWS_CASE(2, 2, 8) OX_ROWS_CASE(3, 1, 4) OX_ROWS_CASE(3, 2, 16) OX_ROWS_CASE(2, 3, 16) OX_ROWS_CASE(3, 3, 32)
 #undef OX_ROWS_CASE
   OX_FAIL("assemble: unsupported gdim=%d degree=%d", g, degree);
 }
@@ -736,7 +810,7 @@ extern "C" int ox_assemble_weights(int degree, const ox_cells *cells, const ox_a
     OX_LAUNCH_CHECK();                                                                             \
     return 0;                                                                                      \
   }
-  OX_W_CASE(2, 1) OX_W_CASE(2, 2) OX_W_CASE(3, 1) OX_W_CASE(3, 2) OX_W_CASE(2, 3)
+  OX_W_CASE(2, 1) OX_W_CASE(2, 2) OX_W_CASE(3, 1) OX_W_CASE(3, 2) OX_W_CASE(2, 3) OX_W_CASE(3, 3)
 #undef OX_W_CASE
   OX_FAIL("ox_assemble_weights: unsupported gdim=%d degree=%d", g, degree);
 }
@@ -972,7 +1046,7 @@ extern "C" int ox_assemble_grad_vector(int kind, int row_degree, int p_degree, c
   }
 #define OX_GV_ALL(GD) \
   OX_GV_CASE(GD, 1, 1, 0) OX_GV_CASE(GD, 1, 1, 1) OX_GV_CASE(GD, 2, 1, 0) OX_GV_CASE(GD, 2, 1, 1)
-  OX_GV_ALL(2) OX_GV_ALL(3) OX_GV_CASE(2, 3, 2, 0) OX_GV_CASE(2, 3, 2, 1)
+  OX_GV_ALL(2) OX_GV_ALL(3) OX_GV_CASE(2, 3, 2, 0) OX_GV_CASE(2, 3, 2, 1) OX_GV_CASE(3, 3, 2, 0) OX_GV_CASE(3, 3, 2, 1)
 #undef OX_GV_ALL
 #undef OX_GV_CASE
   OX_FAIL("ox_assemble_grad_vector: unsupported gdim=%d row_degree=%d p_degree=%d kind=%d", g,
@@ -1043,7 +1117,7 @@ extern "C" int ox_assemble_div_vector(int row_degree, int u_degree, const ox_cel
     OX_LAUNCH_CHECK();                                                                             \
     return 0;                                                                                      \
   }
-  OX_DV_CASE(2, 1, 1) OX_DV_CASE(2, 1, 2) OX_DV_CASE(3, 1, 1) OX_DV_CASE(3, 1, 2) OX_DV_CASE(2, 2, 3)
+  OX_DV_CASE(2, 1, 1) OX_DV_CASE(2, 1, 2) OX_DV_CASE(3, 1, 1) OX_DV_CASE(3, 1, 2) OX_DV_CASE(2, 2, 3) OX_DV_CASE(3, 2, 3)
 #undef OX_DV_CASE
   OX_FAIL("ox_assemble_div_vector: unsupported gdim=%d row_degree=%d u_degree=%d", g, row_degree,
           u_degree);
@@ -1145,6 +1219,7 @@ extern "C" int ox_assemble_rect(int family, int row_degree, int col_degree, cons
   OX_RECT_CASE(GD, 2, 1, 0, 4) OX_RECT_CASE(GD, 2, 1, 1, 4) OX_RECT_CASE(GD, 1, 2, 2, PV2)
   OX_RECT_DIM(2, 8) OX_RECT_DIM(3, 16)
   OX_RECT_CASE(2, 3, 2, 0, 8) OX_RECT_CASE(2, 3, 2, 1, 8) OX_RECT_CASE(2, 2, 3, 2, 16)  // P3-P2 on triangles
+  OX_RECT_CASE(3, 3, 2, 0, 16) OX_RECT_CASE(3, 3, 2, 1, 16) OX_RECT_CASE(3, 2, 3, 2, 32)  // P3-P2 on tetrahedra
 #undef OX_RECT_DIM
 #undef OX_RECT_CASE
   OX_FAIL("ox_assemble_rect: unsupported gdim=%d row_degree=%d col_degree=%d family=%d", g, row_degree,

@@ -249,6 +249,22 @@ __global__ __launch_bounds__(256) void k_edge_keys(const int32_t *__restrict__ c
   ids[i] = (int32_t)i;  // nc * ne < 2^31 is checked by the caller
 }
 
+// ---- P3 on tetrahedra: faces (one dof each), numbered by ascending sorted vertex triple ---------------------------
+__device__ __constant__ int FACE3[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};  // face f = the vertices other than f
+__global__ __launch_bounds__(256) void k_face_keys(const int32_t *__restrict__ cells, int64_t nc, int64_t nverts,
+                                                   uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nc * 4) return;
+  const int64_t c = i >> 2;
+  const int f = (int)(i & 3);
+  int64_t v0 = cells[c * 4 + FACE3[f][0]], v1 = cells[c * 4 + FACE3[f][1]], v2 = cells[c * 4 + FACE3[f][2]];
+  if (v0 > v1) { const int64_t t = v0; v0 = v1; v1 = t; }
+  if (v1 > v2) { const int64_t t = v1; v1 = v2; v2 = t; }
+  if (v0 > v1) { const int64_t t = v0; v0 = v1; v1 = t; }
+  keys[i] = ((uint64_t)v0 * (uint64_t)nverts + (uint64_t)v1) * (uint64_t)nverts + (uint64_t)v2;
+  ids[i] = (int32_t)i;
+}
+
 __global__ __launch_bounds__(256) void k_heads(const uint64_t *__restrict__ ks, int64_t n, int64_t *__restrict__ head) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) head[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1 : 0;
@@ -268,10 +284,25 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *__restrict
 
 __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, const int32_t *__restrict__ cell_edges,
                                              int64_t nc, int d, int degree, int64_t nverts, int64_t n_edges,
-                                             int32_t *__restrict__ cd0) {
+                                             int32_t *__restrict__ cd0, const int32_t *__restrict__ cell_faces = nullptr) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= nc) return;
   const int nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0;
+  if (degree == 3 && d == 3) {
+    // tetrahedra, 20 dofs: vertices; per local edge (a, b) the node nearer a, then the node nearer b (an edge's two dofs
+    // are numbered from its LOWER global vertex: nverts + 2 e + {0, 1}); the dofs of the four faces (face f = the
+    // vertices other than f): nverts + 2 n_edges + face id
+    const int nd = 20;
+    for (int a = 0; a < nv; ++a) cd0[c * nd + a] = cells[c * nv + a];
+    for (int e = 0; e < ne; ++e) {
+      const int flip = cells[c * nv + EDGE3[e][0]] > cells[c * nv + EDGE3[e][1]] ? 1 : 0;
+      const int64_t first = nverts + 2 * (int64_t)cell_edges[c * ne + e];
+      cd0[c * nd + nv + 2 * e] = (int32_t)(first + flip);
+      cd0[c * nd + nv + 2 * e + 1] = (int32_t)(first + 1 - flip);
+    }
+    for (int f = 0; f < 4; ++f) cd0[c * nd + 16 + f] = (int32_t)(nverts + 2 * n_edges + cell_faces[c * 4 + f]);
+    return;
+  }
   if (degree == 3) {
     // triangles, 10 dofs: vertices; per local edge (a, b) the node nearer a, then the node nearer b -- an edge's two
     // dofs are numbered from its LOWER global vertex to its higher one: nverts + 2 e + {0, 1}; the cell's own dof
@@ -293,7 +324,8 @@ __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, 
 
 __global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ coords, const uint64_t *__restrict__ edge_keys,
                                                     int64_t nverts, int64_t n, int d, double *__restrict__ x, int degree = 2,
-                                                    int64_t n_edges = 0, const int32_t *__restrict__ cells = nullptr) {
+                                                    int64_t n_edges = 0, const int32_t *__restrict__ cells = nullptr,
+                                                    const uint64_t *__restrict__ face_keys = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (i < nverts) {
@@ -307,6 +339,10 @@ __global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ c
       const uint64_t key = edge_keys[e];
       const int64_t a = (int64_t)(key / (uint64_t)nverts), b = (int64_t)(key % (uint64_t)nverts);
       for (int k = 0; k < d; ++k) x[i * d + k] = (1.0 - t) * coords[a * d + k] + t * coords[b * d + k];
+    } else if (d == 3) {  // the node of a face at its centroid
+      const uint64_t key = face_keys[i - nverts - 2 * n_edges], nv_ = (uint64_t)nverts;
+      const int64_t a = (int64_t)(key / (nv_ * nv_)), b = (int64_t)((key / nv_) % nv_), c = (int64_t)(key % nv_);
+      for (int k = 0; k < d; ++k) x[i * d + k] = (coords[a * d + k] + coords[b * d + k] + coords[c * d + k]) / 3.0;
     } else {
       const int64_t c = i - nverts - 2 * n_edges;
       for (int k = 0; k < d; ++k) {
@@ -602,11 +638,13 @@ struct ox_space {
   const ox_mesh *mesh = nullptr;
   int degree = 0, nd = 0, pw = 0, window = 0;
   int64_t n = 0, n_edges = 0, npairs = 0;  // dofs, edges, padded adjacency pairs
+  int64_t n_faces = 0;  // P3 on tetrahedra: faces (one dof each)
   int64_t n_rows = 0;   // rows of the space's patterns: n, or the owned dofs of a mesh-partitioned space (they come first)
   DevBuf cell_dofs;     // [nc][nd] int32, final numbering
   DevBuf x;             // [n][gdim]
   DevBuf rank_initial;  // [n] int32: initial dof (vertex id, or nv + edge id) -> final dof
   DevBuf edge_keys;     // [n_edges] uint64: min_vertex * nv + max_vertex, ascending (edge id = position)
+  DevBuf face_keys;     // [n_faces] uint64: (v0 * nv + v1) * nv + v2 of the sorted vertex triple, ascending (P3 tetrahedra)
   DevBuf start, pair;   // pairs grouped by final dof (kept for rectangular patterns)
   DevBuf adj_ptr, adj_cell, adj_loc, adj_pos, adj_count;
   ox_pattern_store P;
@@ -1002,8 +1040,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
                              int64_t n_dofs_whole, ox_space **out, int brick = 0) {
   if (!M || !out) OX_FAIL("ox_space_create: null argument");
   if (degree < 1 || degree > 3) OX_FAIL("ox_space_create: Lagrange degree %d (1, 2 and -- on triangles -- 3 are built)", degree);
-  if (degree == 3 && (M->gdim != 2 || owner))
-    OX_FAIL("ox_space_create: Lagrange degree 3 is built on triangles, one GPU (gdim %d)", M->gdim);
+  if (degree == 3 && owner) OX_FAIL("ox_space_create_part: Lagrange degree 3 spaces are built on one GPU");
   if (window < SLICE) window = 4096;
   hipStream_t st = nullptr;
   ox_space *V = new ox_space();
@@ -1011,10 +1048,10 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
     ox_space *v;
     ~Guard() { delete v; }
   } guard{V};
-  const int d = M->gdim, nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0, nd = degree == 3 ? 10 : nv + ne;
+  const int d = M->gdim, nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0, nd = degree == 3 ? (d == 2 ? 10 : 20) : nv + ne;
   const int64_t nc = M->nc;
   V->mesh = M, V->degree = degree, V->nd = nd, V->window = window;
-  V->pw = nd <= 4 ? 4 : (nd <= 8 ? 8 : 16);
+  V->pw = nd <= 4 ? 4 : (nd <= 8 ? 8 : (nd <= 16 ? 16 : 32));
   // ---- 1. initial dof ids: vertices, then edges numbered by ascending (min, max) vertex pair -------
   DevBuf cd0;
   OX_TRY(cd0.alloc(sizeof(int32_t) * (size_t)nc * nd));
@@ -1050,12 +1087,44 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
       OX_LAUNCH_CHECK();
       OX_HIP(hipStreamSynchronize(st));
     }
+    DevBuf cell_faces;
+    if (degree == 3 && d == 3) {  // faces of the tetrahedra, like the edges: sorted keys, heads, scan, scatter
+      if ((long double)M->nv * M->nv * M->nv >= 9.0e18L) OX_FAIL("ox_space_create: face keys of %lld vertices overflow 64 bits", (long long)M->nv);
+      const int64_t nk = nc * 4;
+      if (nk >= ((int64_t)1 << 31)) OX_FAIL("ox_space_create: %lld cell faces exceed int32", (long long)nk);
+      DevBuf k_in, k_out, v_in, v_out, head, excl;
+      OX_TRY(k_in.alloc(sizeof(uint64_t) * (size_t)nk));
+      OX_TRY(k_out.alloc(sizeof(uint64_t) * (size_t)nk));
+      OX_TRY(v_in.alloc(sizeof(int32_t) * (size_t)nk));
+      OX_TRY(v_out.alloc(sizeof(int32_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_face_keys, dim3(nblk(nk)), dim3(256), 0, st, M->cells.as<int32_t>(), nc, M->nv, k_in.as<uint64_t>(),
+                         v_in.as<int32_t>());
+      OX_LAUNCH_CHECK();
+      OX_TRY(sort_pairs(k_in.as<uint64_t>(), k_out.as<uint64_t>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nk, 64, st));
+      k_in.release();
+      v_in.release();
+      OX_TRY(head.alloc(sizeof(int64_t) * (size_t)nk));
+      OX_TRY(excl.alloc(sizeof(int64_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_heads, dim3(nblk(nk)), dim3(256), 0, st, k_out.as<uint64_t>(), nk, head.as<int64_t>());
+      OX_LAUNCH_CHECK();
+      OX_TRY(exclusive_scan_i64(head.as<int64_t>(), excl.as<int64_t>(), (size_t)nk, st));
+      int64_t last[2];
+      OX_HIP(hipMemcpy(&last[0], excl.as<int64_t>() + nk - 1, sizeof(int64_t), hipMemcpyDeviceToHost));
+      OX_HIP(hipMemcpy(&last[1], head.as<int64_t>() + nk - 1, sizeof(int64_t), hipMemcpyDeviceToHost));
+      V->n_faces = last[0] + last[1];
+      OX_TRY(V->face_keys.alloc(sizeof(uint64_t) * (size_t)V->n_faces));
+      OX_TRY(cell_faces.alloc(sizeof(int32_t) * (size_t)nk));
+      hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(nk)), dim3(256), 0, st, k_out.as<uint64_t>(), v_out.as<int32_t>(),
+                         head.as<int64_t>(), excl.as<int64_t>(), nk, cell_faces.as<int32_t>(), V->face_keys.as<uint64_t>());
+      OX_LAUNCH_CHECK();
+      OX_HIP(hipStreamSynchronize(st));
+    }
     hipLaunchKernelGGL(k_cd0, dim3(nblk(nc)), dim3(256), 0, st, M->cells.as<int32_t>(), cell_edges.as<int32_t>(), nc, d, degree,
-                       M->nv, V->n_edges, cd0.as<int32_t>());
+                       M->nv, V->n_edges, cd0.as<int32_t>(), cell_faces.as<int32_t>());
     OX_LAUNCH_CHECK();
     OX_HIP(hipStreamSynchronize(st));
   }
-  const int64_t n = degree == 3 ? M->nv + 2 * V->n_edges + nc : M->nv + V->n_edges;
+  const int64_t n = degree == 3 ? M->nv + 2 * V->n_edges + (d == 3 ? V->n_faces : nc) : M->nv + V->n_edges;
   if (n >= ((int64_t)1 << 31) - 64) OX_FAIL("ox_space_create: %lld dofs exceed int32", (long long)n);
   V->n = n;
   if (owner && n != n_initial)
@@ -1074,7 +1143,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
   DevBuf xL, rank1;
   OX_TRY(xL.alloc(sizeof(double) * (size_t)n * d));
   hipLaunchKernelGGL(k_dof_coords, dim3(nblk(n)), dim3(256), 0, st, M->coords.as<double>(), V->edge_keys.as<uint64_t>(), M->nv, n,
-                     d, xL.as<double>(), degree, V->n_edges, M->cells.as<int32_t>());
+                     d, xL.as<double>(), degree, V->n_edges, M->cells.as<int32_t>(), V->face_keys.as<uint64_t>());
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {
@@ -1239,6 +1308,7 @@ extern "C" int ox_space_view(const ox_space *V, ox_space_info *v) {
   v->x = V->x.as<double>();
   v->rank_initial = V->rank_initial.as<int32_t>();
   v->edge_keys = V->edge_keys.as<uint64_t>();
+  v->n_faces = V->n_faces, v->face_keys = V->face_keys.as<uint64_t>();
   v->adj.n_slices = (int32_t)V->P.n_slices, v->adj.nd = V->nd;
   v->adj.adj_ptr = V->adj_ptr.as<int64_t>(), v->adj.adj_cell = V->adj_cell.as<int32_t>(), v->adj.adj_loc = V->adj_loc.as<uint8_t>();
   v->adj_pos = V->adj_pos.as<uint8_t>();
@@ -1635,7 +1705,7 @@ extern "C" int ox_rect_create(const ox_space *R, const ox_space *C, ox_rect **ou
     ~Guard() { delete q; }
   } guard{Q};
   Q->R = R, Q->C = C;
-  Q->pw = C->nd <= 4 ? 4 : (C->nd <= 8 ? 8 : 16);
+  Q->pw = C->nd <= 4 ? 4 : (C->nd <= 8 ? 8 : (C->nd <= 16 ? 16 : 32));
   ox_pattern_store &P = Q->P;
   P.n_rows = R->n_rows, P.n_cols = C->n;  // (a mesh-partitioned row space: its owned dofs)
   DevBuf err;

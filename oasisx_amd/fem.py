@@ -509,8 +509,8 @@ class FunctionSpace:
                  block_pairs: int = 1 << 24, block_nnz: int = 1 << 27, brick: bool | None = None):
         if degree not in (1, 2, 3):
             raise ValueError("oasisx_amd supports Lagrange degree 1, 2 and (on triangles) 3")
-        if degree == 3 and (mesh.gdim != 2 or part is not None):
-            raise NotImplementedError("Lagrange degree 3: triangles on one GPU")
+        if degree == 3 and part is not None:
+            raise NotImplementedError("Lagrange degree 3: one GPU (triangles and, since round 5, tetrahedra)")
         # brick order of the numbering (lattice meshes, one GPU): what the LDS-window SpMV needs, a loss for the
         # lane = row kernels -- only together with ``build_windows`` (FractionalStep_AB_CN options["spmv_windows"]);
         # OX_BRICK=1 forces it for tuning runs
@@ -767,6 +767,8 @@ class FunctionSpace:
             self._gl = None
             self._edge_keys = (N.dev_tensor(v.edge_keys, (int(v.n_edges),), torch.int64, own, dev)
                                if self.degree >= 2 else None)
+            self._face_keys = (N.dev_tensor(v.face_keys, (int(v.n_faces),), torch.int64, own, dev)
+                               if (self.degree == 3 and d == 3) else None)
         else:
             self.local_cells = sub.cells_global[ns.nmesh.cell_perm.to(torch.int64)]  # global cell ids, kernel order
             self.n_owned, self.n_local = int(v.pattern.sell.n_rows), n
@@ -1006,7 +1008,17 @@ class FunctionSpace:
                 else:  # degree 3: two dofs per edge
                     gids.append((nv + 2 * pos)[hit])
                     gids.append((nv + 2 * pos + 1)[hit])
-        if self.degree == 3 and dim == mesh.gdim:  # the cells' own dofs: initial id = nv + 2 n_edges + kernel cell index
+        if self.degree == 3 and mesh.gdim == 3:
+            # tetrahedra: one dof per face, initial id = nv + 2 n_edges + face id (faces by ascending sorted vertex triple)
+            if verts.shape[1] >= 3:
+                fk, nv = self._face_keys, mesh.num_vertices
+                for combo in itertools.combinations(range(verts.shape[1]), 3):
+                    tri = np.sort(verts[:, list(combo)], axis=1).astype(np.int64)
+                    key = torch.from_numpy((tri[:, 0] * nv + tri[:, 1]) * nv + tri[:, 2]).to(dev)
+                    pos = torch.searchsorted(fk, key).clamp_max(max(int(fk.shape[0]) - 1, 0))
+                    hit = fk[pos] == key
+                    gids.append((nv + 2 * int(self._edge_keys.shape[0]) + pos)[hit])
+        elif self.degree == 3 and dim == mesh.gdim:  # the cells' own dofs: initial id = nv + 2 n_edges + kernel cell index
             kc = torch.from_numpy(self.kernel_cell_index(np.asarray(entities, dtype=np.int64)).astype(np.int64)).to(dev)
             gids.append(mesh.num_vertices + 2 * int(self._edge_keys.shape[0]) + kc)
         loc = self.global_to_local(torch.cat(gids))
@@ -1509,7 +1521,6 @@ def _simplex_rule(d: int, n: int):
 
 
 GLL3 = (0.5 - 0.5 / np.sqrt(5.0), 0.5 + 0.5 / np.sqrt(5.0))  # interior edge nodes of the gll_warped P3 element
-_P3_COEF = None
 
 
 def lagrange_basis(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
@@ -1523,25 +1534,56 @@ def lagrange_basis(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
         cols = [bary[:, a] * (2 * bary[:, a] - 1) for a in range(nv)]
         cols += [4 * bary[:, a] * bary[:, b] for a, b in local_edges(d)]
         return np.stack(cols, axis=1)
-    if degree == 3 and d == 2:
-        global _P3_COEF
-        ex = [(i, j) for i in range(4) for j in range(4 - i)]
-
-        def mono(x, y):
-            return np.stack([x ** i * y ** j for i, j in ex], axis=1)
-
-        if _P3_COEF is None:
-            nodes = [np.eye(3)[a] for a in range(3)]
-            for a, b in local_edges(2):
-                for t in GLL3:
-                    v = np.zeros(3)
-                    v[a], v[b] = 1.0 - t, t
-                    nodes.append(v)
-            nodes.append(np.full(3, 1.0 / 3.0))
-            nodes = np.array(nodes)
-            _P3_COEF = np.linalg.inv(mono(nodes[:, 1], nodes[:, 2]))
-        return mono(bary[:, 1], bary[:, 2]) @ _P3_COEF
+    if degree == 3:
+        return _p3_mono(d, bary)[0] @ _p3_coef(d)
     raise NotImplementedError(f"Lagrange degree {degree} on a {d}-simplex")
+
+
+_P3_COEFS = {}
+
+
+def _p3_mono(d: int, bary: np.ndarray):
+    """The monomials of degree <= 3 in (lambda_1, ..., lambda_d) at barycentric points and their partial derivatives:
+    (m, dm_1, ..., dm_d), each (npts, 10 | 20)."""
+    xs = [bary[:, a] for a in range(1, d + 1)]
+    ex = ([(i, j) for i in range(4) for j in range(4 - i)] if d == 2 else
+          [(i, j, k) for i in range(4) for j in range(4 - i) for k in range(4 - i - j)])
+
+    def mono(e, skip=None):
+        out = np.ones_like(xs[0])
+        for v in range(d):
+            out = out * xs[v] ** max(e[v] - (1 if v == skip else 0), 0)
+        return out
+    m = np.stack([mono(e) for e in ex], axis=1)
+    ders = [np.stack([e[v] * mono(e, v) if e[v] > 0 else np.zeros_like(xs[0]) for e in ex], axis=1) for v in range(d)]
+    return (m, *ders)
+
+
+def p3_nodes(d: int) -> np.ndarray:
+    """Barycentric coordinates of the ``gll_warped`` P3 nodes in the order of csrc/fe_tables_h.h / fe_tables_h3.h:
+    vertices, per local edge the node nearer its first vertex then the one nearer its second, then the centroid
+    (triangles) or the centroids of the four faces (tetrahedra: face f = the vertices other than f)."""
+    nv = d + 1
+    nodes = [np.eye(nv)[a] for a in range(nv)]
+    for a, b in local_edges(d):
+        for t in GLL3:
+            v = np.zeros(nv)
+            v[a], v[b] = 1.0 - t, t
+            nodes.append(v)
+    if d == 2:
+        nodes.append(np.full(3, 1.0 / 3.0))
+    else:
+        for f in range(4):
+            v = np.full(4, 1.0 / 3.0)
+            v[f] = 0.0
+            nodes.append(v)
+    return np.array(nodes)
+
+
+def _p3_coef(d: int) -> np.ndarray:
+    if d not in _P3_COEFS:
+        _P3_COEFS[d] = np.linalg.inv(_p3_mono(d, p3_nodes(d))[0])  # column i: monomial coefficients of phi_i
+    return _P3_COEFS[d]
 
 
 def lagrange_basis_derivs(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
@@ -1561,15 +1603,11 @@ def lagrange_basis_derivs(d: int, degree: int, bary: np.ndarray) -> np.ndarray:
             out[:, nv + e, a] = 4 * bary[:, b]
             out[:, nv + e, b] = 4 * bary[:, a]
         return out
-    if degree == 3 and d == 2:
-        lagrange_basis(2, 3, bary[:1])  # (fills the coefficient cache)
-        ex = [(i, j) for i in range(4) for j in range(4 - i)]
-        x, y = bary[:, 1], bary[:, 2]
-        mx = np.stack([i * x ** max(i - 1, 0) * y ** j if i > 0 else np.zeros_like(x) for i, j in ex], axis=1)
-        my = np.stack([j * x ** i * y ** max(j - 1, 0) if j > 0 else np.zeros_like(x) for i, j in ex], axis=1)
-        out = np.zeros((n, 10, 3))
-        out[:, :, 1] = mx @ _P3_COEF
-        out[:, :, 2] = my @ _P3_COEF
+    if degree == 3:
+        tabs, Cf = _p3_mono(d, bary), _p3_coef(d)
+        out = np.zeros((n, Cf.shape[0], nv))
+        for b in range(1, nv):
+            out[:, :, b] = tabs[b] @ Cf
         return out
     raise NotImplementedError(f"Lagrange degree {degree} on a {d}-simplex")
 

@@ -27,8 +27,11 @@ _VTK_PERM = {(2, 1): [0, 1, 2], (3, 1): [0, 1, 2, 3],
              (2, 2): [0, 1, 2, 5, 3, 4],  # e01, e12, e20
              (3, 2): [0, 1, 2, 3, 9, 6, 8, 7, 5, 4],  # e01, e12, e02, e03, e13, e23
              # P3 triangle -> VTK_LAGRANGE_TRIANGLE: e01 (from 0 to 1), e12 (1 to 2), e20 (2 to 0), interior
-             (2, 3): [0, 1, 2, 7, 8, 3, 4, 6, 5, 9]}
-_VTK_TYPE = {(2, 1): 5, (3, 1): 10, (2, 2): 22, (3, 2): 24, (2, 3): 69}
+             (2, 3): [0, 1, 2, 7, 8, 3, 4, 6, 5, 9],
+             # P3 tetrahedron -> VTK_LAGRANGE_TETRAHEDRON: e01, e12, e20 (from 2 to 0), e03, e13, e23, then the faces
+             # (0,1,3), (1,2,3), (0,2,3), (0,1,2) -- DOLFINx's own permutation for this element (io/cells.cpp)
+             (3, 3): [0, 1, 2, 3, 14, 15, 8, 9, 13, 12, 10, 11, 6, 7, 4, 5, 18, 16, 17, 19]}
+_VTK_TYPE = {(2, 1): 5, (3, 1): 10, (2, 2): 22, (3, 2): 24, (2, 3): 69, (3, 3): 71}
 
 
 def _b64(a: np.ndarray) -> str:

@@ -565,12 +565,22 @@ def locate_entities_boundary(mesh: Mesh, dim: int, marker) -> np.ndarray:
     ext = mesh.exterior_facets()
     if dim == mesh.gdim - 1:
         return _marked_entities(mesh, dim, marker, candidates=ext)
-    # sub-entities of exterior facets
+    # sub-entities of exterior facets (DOLFINx: entities ATTACHED to a boundary facet -- an interior edge of a tetrahedral
+    # mesh whose two end points happen to lie on the boundary is not one of them)
+    import itertools
+
     fv, _ = mesh._entities(mesh.gdim - 1)
     ev, _ = mesh._entities(dim)
-    bverts = np.zeros(mesh.num_vertices, dtype=bool)
-    bverts[fv[ext].ravel()] = True
-    cand = np.nonzero(bverts[ev].all(axis=1))[0]
+    nv = np.int64(mesh.num_vertices)
+
+    def keys(v):
+        v = np.sort(np.asarray(v, dtype=np.int64), axis=1)
+        k = np.zeros(v.shape[0], dtype=np.int64)
+        for c in range(v.shape[1]):
+            k = k * nv + v[:, c]
+        return k
+    sub = np.concatenate([keys(fv[ext][:, list(combo)]) for combo in itertools.combinations(range(fv.shape[1]), dim + 1)])
+    cand = np.nonzero(np.isin(keys(ev), np.unique(sub)))[0]
     return _marked_entities(mesh, dim, marker, candidates=cand)
 
 

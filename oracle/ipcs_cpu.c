@@ -204,7 +204,7 @@ static inline int64_t csr_find(const int64_t *rp, const int32_t *ci, int64_t r, 
 }
 
 /* geom[c]: (d+1) x d barycentric gradients then |detJ|  (stride (d+1)*d+1) */
-#define MAXND 10
+#define MAXND 20 /* Lagrange P3 on tetrahedra: 4 + 12 + 4 */
 #define MAXV 4
 
 /* C = assemble_matrix(inner(dot(uab, nabla_grad(u)), v)*dx), cell loop + scatter-add

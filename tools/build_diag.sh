@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../oasisx_amd/csrc"
 out=../../tools/liboasisx_hip_diag.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DOX_DIAG -o "$out" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fconstexpr-steps=50000000 -shared -DOX_DIAG -o "$out" \
   ox_spmv.hip ox_ksp.hip ox_assemble.hip ox_dist.hip ox_setup.hip -L"${ROCM_PATH:-/opt/rocm}/lib" -lrccl \
   -Wl,-rpath,"${ROCM_PATH:-/opt/rocm}/lib"
 echo "built $out"
