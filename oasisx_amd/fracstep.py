@@ -110,10 +110,10 @@ class FractionalStep_AB_CN:
         self._gdim = gdim
         dev = mesh.device
         u_deg, p_deg = _degree(u_element), _degree(p_element)
-        # Taylor-Hood pairs P2-P1 (every BASELINE configuration) and, on triangles, P3-P2 (the reference demo's -u 3 -p 2:
-        # demo/taylor_green.py:82-83,111); equal order P1-P1 (BASELINE configs[1])
+        # Taylor-Hood pairs P2-P1 (every BASELINE configuration) and P3-P2 on triangles and tetrahedra (the reference demo's
+        # -u 3 -p 2: demo/taylor_green.py:82-83,111; one GPU); equal order P1-P1 (BASELINE configs[1])
         if (u_deg, p_deg) not in ((1, 1), (2, 1), (3, 2)):
-            raise NotImplementedError(f"Lagrange P{u_deg}-P{p_deg}: the built pairs are P1-P1, P2-P1 and (triangles) P3-P2")
+            raise NotImplementedError(f"Lagrange P{u_deg}-P{p_deg}: the built pairs are P1-P1, P2-P1 and P3-P2")
         window = int((options or {}).get("sell_window", 4096))
 
         # ---- spaces (reference fracstep.py:186-216) ----------------------------------------
