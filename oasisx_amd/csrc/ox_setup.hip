@@ -1040,7 +1040,6 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
                              int64_t n_dofs_whole, ox_space **out, int brick = 0) {
   if (!M || !out) OX_FAIL("ox_space_create: null argument");
   if (degree < 1 || degree > 3) OX_FAIL("ox_space_create: Lagrange degree %d (1, 2 and -- on triangles -- 3 are built)", degree);
-  if (degree == 3 && owner) OX_FAIL("ox_space_create_part: Lagrange degree 3 spaces are built on one GPU");
   if (window < SLICE) window = 4096;
   hipStream_t st = nullptr;
   ox_space *V = new ox_space();

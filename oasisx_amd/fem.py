@@ -510,7 +510,13 @@ class FunctionSpace:
         if degree not in (1, 2, 3):
             raise ValueError("oasisx_amd supports Lagrange degree 1, 2 and (on triangles) 3")
         if degree == 3 and part is not None:
-            raise NotImplementedError("Lagrange degree 3: one GPU (triangles and, since round 5, tetrahedra)")
+            if mesh.device.type != "cuda" or _os.environ.get("OX_SETUP", "native") == "torch":
+                raise NotImplementedError("Lagrange degree 3 on a mesh partition: built by the library (GPU hosts)")
+            if mesh.gdim == 2:
+                # (the cells' own dofs are numbered in kernel cell order on every rank: sender and receiver would list them
+                # in different orders; tetrahedra have no such dofs)
+                raise NotImplementedError("Lagrange degree 3 on a PARTITIONED triangular mesh (tetrahedra and one-GPU "
+                                          "triangles are built)")
         # brick order of the numbering (lattice meshes, one GPU): what the LDS-window SpMV needs, a loss for the
         # lane = row kernels -- only together with ``build_windows`` (FractionalStep_AB_CN options["spmv_windows"]);
         # OX_BRICK=1 forces it for tuning runs
@@ -750,6 +756,23 @@ class FunctionSpace:
             if self.degree == 2:
                 uniq_e = torch.unique(part.cell_edges_of(sub.cells_global).reshape(-1))  # window edge indices, ascending
                 gl = torch.cat([sub.verts, nverts + uniq_e])
+            elif self.degree == 3:
+                # the library's initial ids of the part: its vertices, two dofs per edge (ascending key), then one per face
+                # (ascending key: tetrahedra) or per cell (KERNEL cell order: triangles); here in the window numbering of
+                # parallel.MeshPartition.owner0(3)
+                uniq_e = torch.unique(part.cell_edges_of(sub.cells_global).reshape(-1))
+                ne_w = int(part.edge_keys.shape[0])
+                e2 = (nverts + 2 * uniq_e).repeat_interleave(2) + torch.arange(2, device=dev).repeat(int(uniq_e.shape[0]))
+                if d == 3:
+                    if part.face_keys is None:
+                        raise ValueError("a degree-3 space on a partitioned tetrahedral mesh needs MeshPartition(faces=True)")
+                    last = nverts + 2 * ne_w + torch.unique(part.cell_faces_of(sub.cells_global).reshape(-1))
+                else:
+                    if not part.cells_own_dofs:
+                        raise ValueError("a degree-3 space on a partitioned triangular mesh needs MeshPartition(faces=True)")
+                    kernel_cells = sub.cells_global[sub.cell_perm.to(torch.int64)]
+                    last = nverts + 2 * ne_w + part._win_pos(kernel_cells)  # (NOT ascending: see global_to_local)
+                gl = torch.cat([sub.verts, e2, last])
             else:
                 gl = sub.verts
             owner = part.owner0(self.degree)[gl].to(torch.int32).contiguous()
@@ -774,7 +797,12 @@ class FunctionSpace:
             self.n_owned, self.n_local = int(v.pattern.sell.n_rows), n
             self.num_dofs = n  # DOLFINx convention: local arrays hold owned dofs, then ghosts
             self._gl = gl
-            self._edge_keys = part.edge_keys if self.degree == 2 else None
+            self._gl_order = None
+            if gl.numel() > 1 and not bool((gl[1:] > gl[:-1]).all()):  # (degree 3 on triangles: cells in kernel order)
+                self._gl_order = torch.argsort(gl)
+                self._gl = gl[self._gl_order]
+            self._edge_keys = part.edge_keys if self.degree >= 2 else None
+            self._face_keys = part.face_keys if (self.degree == 3 and d == 3) else None
         self.cell_dofs = N.dev_tensor(v.cell_dofs, (nc, self.nd), torch.int32, own, dev)
         self.x = N.dev_tensor(v.x, (n, d), torch.float64, own, dev)
         self._x3 = None
@@ -802,6 +830,8 @@ class FunctionSpace:
             return self._rank_initial[gids]
         pos = torch.searchsorted(self._gl, gids).clamp_max(self._gl.shape[0] - 1)
         ok = self._gl[pos] == gids
+        if getattr(self, "_gl_order", None) is not None:  # (_gl sorted; the library's initial id is the ORIGINAL position)
+            pos = self._gl_order[pos]
         return torch.where(ok, self._rank_initial[pos], torch.full_like(pos, -1))
 
     def _build_halo(self, part, ghost_owner, cd0g):
@@ -820,7 +850,15 @@ class FunctionSpace:
             # the cells both ranks keep: qr's ghosts that this rank owns are dofs of exactly these cells
             cm = part.cells_shared_with(qr)
             cq = self.mesh.cells[cm]
-            ids = cq if self.degree == 1 else torch.cat([cq, nverts + part.cell_edges_of(cm)], dim=1)
+            if self.degree == 1:
+                ids = cq
+            elif self.degree == 2:
+                ids = torch.cat([cq, nverts + part.cell_edges_of(cm)], dim=1)
+            else:  # degree 3, window numbering of owner0(3): two dofs per edge, then faces (tetrahedra) / cells (triangles)
+                ce = part.cell_edges_of(cm)
+                ne_w = int(part.edge_keys.shape[0])
+                last = (part.cell_faces_of(cm) if self.mesh.gdim == 3 else part._win_pos(cm).unsqueeze(1))
+                ids = torch.cat([cq, nverts + 2 * ce, nverts + 2 * ce + 1, nverts + 2 * ne_w + last], dim=1)
             ids = torch.unique(ids.reshape(-1))
             ids = ids[owner0[ids] == part.rank]  # ascending id (vertices, then edges by key) = the receiver's order
             if nrecv == 0 and ids.shape[0] == 0:

@@ -123,7 +123,7 @@ class FractionalStep_AB_CN:
         if comm is not None and getattr(comm, "size", 1) > 1:
             from .parallel import MeshPartition
 
-            part = MeshPartition(mesh, comm.rank, comm.size, comm)
+            part = MeshPartition(mesh, comm.rank, comm.size, comm, faces=(u_deg == 3))  # (P3: face / cell dofs have owners)
         self._part = part
         # options["spmv_windows"]: the LDS-window stream of the velocity pattern (k_spmv_win).  Default: ON for meshes
         # that are not lattices (Z-order numbering as it is: the mat-vecs of a refined Delaunay mesh run 1.3-1.9 x

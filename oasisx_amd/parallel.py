@@ -455,8 +455,13 @@ class MeshPartition:
     differ from rank to rank, their ORDER does not -- and the halo plan only needs both sides to list the
     shared dofs in the same order (vertices by id, then edges by key)."""
 
-    def __init__(self, mesh: Mesh, rank: int, nparts: int, comm=None):
+    def __init__(self, mesh: Mesh, rank: int, nparts: int, comm=None, faces: bool = False):
+        """``faces``: the job carries a degree-3 space on tetrahedra (one dof per face, owned by the lowest rank among the
+        face's cells): the faces of the window are enumerated too, and a cell that touches nothing but an owned FACE dof
+        is a local cell as well -- for EVERY space of the job (the velocity and pressure spaces share one cell set)."""
         self.mesh, self.rank, self.nparts = mesh, int(rank), int(nparts)
+        self.with_faces = bool(faces) and mesh.gdim == 3
+        self.cells_own_dofs = bool(faces) and mesh.gdim == 2  # (degree 3 on triangles: one dof inside every cell)
         self.comm = comm if comm is not None else getattr(mesh, "comm", None)
         dev = mesh.device
         d = mesh.gdim
@@ -502,8 +507,23 @@ class MeshPartition:
         self.eown = bige.scatter_reduce(0, self._win_cell_edges.reshape(-1), wrank.repeat_interleave(ne), reduce="amin")
         del bige
         self._own2 = None
-        # ---- local cells: those that touch a vertex or an edge this rank owns -----------------------------
+        self._own3 = None
+        # ---- faces of the window (degree 3 on tetrahedra): keys of the sorted vertex triples, owners ------------
+        self.face_keys = self.fown = self._win_cell_faces = None
+        if self.with_faces:
+            if float(nverts) ** 3 >= 2.0 ** 62:
+                raise ValueError("MeshPartition: face keys overflow int64")
+            tri = torch.stack([torch.sort(wc[:, [a for a in range(4) if a != f]], dim=1).values for f in range(4)], dim=1)
+            fkey = (tri[:, :, 0] * nverts + tri[:, :, 1]) * nverts + tri[:, :, 2]
+            self.face_keys, finv = torch.unique(fkey.reshape(-1), return_inverse=True)
+            self._win_cell_faces = finv.reshape(wc.shape[0], 4)
+            bigf = torch.full((int(self.face_keys.shape[0]),), nparts, dtype=torch.int64, device=dev)
+            self.fown = bigf.scatter_reduce(0, self._win_cell_faces.reshape(-1), wrank.repeat_interleave(4), reduce="amin")
+            del tri, fkey, finv, bigf
+        # ---- local cells: those that touch a vertex or an edge (or, with_faces, a face) this rank owns -------------
         self._win_local = (self.vown[wc] == self.rank).any(dim=1) | (self.eown[self._win_cell_edges] == self.rank).any(dim=1)
+        if self.with_faces:
+            self._win_local |= (self.fown[self._win_cell_faces] == self.rank).any(dim=1)
         self.local_cells = self.win_cells[self._win_local]
         self._n_edges_global = None
 
@@ -520,25 +540,48 @@ class MeshPartition:
         """Window edge indices (into ``edge_keys``) of the edges of the given (global) cells of the window."""
         return self._win_cell_edges[self._win_pos(cell_ids)]
 
+    def cell_faces_of(self, cell_ids: torch.Tensor) -> torch.Tensor:
+        """Window face indices (into ``face_keys``) of the four faces (face f = the vertices other than f) of the given
+        (global) cells of the window."""
+        return self._win_cell_faces[self._win_pos(cell_ids)]
+
     def owner0(self, degree: int) -> torch.Tensor:
-        """Owner rank of every initial dof id of this rank's window (vertices, then window edges for degree 2)."""
+        """Owner rank of every initial dof id of this rank's window: vertices, then window edges (degree 2), or -- degree
+        3 -- two dofs per window edge, then one per window face (tetrahedra) or per window cell (triangles: the cell's
+        own dof belongs to the cell's rank)."""
         if degree == 1:
             return self.vown
-        if self._own2 is None:
-            self._own2 = torch.cat([self.vown, self.eown])
-        return self._own2
+        if degree == 2:
+            if self._own2 is None:
+                self._own2 = torch.cat([self.vown, self.eown])
+            return self._own2
+        if self._own3 is None:
+            last = self.fown if self.mesh.gdim == 3 else self.cell_rank[self.win_cells]
+            if last is None:
+                raise ValueError("MeshPartition: a degree-3 space on tetrahedra needs faces=True")
+            self._own3 = torch.cat([self.vown, self.eown.repeat_interleave(2), last])
+        return self._own3
 
     def cells_shared_with(self, q: int) -> torch.Tensor:
         """This rank's local cells (global ids) that also touch a dof owned by rank ``q``: exactly the cells both
         ranks keep, i.e. where ``q``'s ghosts owned by this rank live."""
         wc = self.mesh.cells[self.win_cells]
-        m = self._win_local & ((self.vown[wc] == q).any(dim=1) | (self.eown[self._win_cell_edges] == q).any(dim=1))
-        return self.win_cells[m]
+        hit = (self.vown[wc] == q).any(dim=1) | (self.eown[self._win_cell_edges] == q).any(dim=1)
+        if self.with_faces:
+            hit |= (self.fown[self._win_cell_faces] == q).any(dim=1)
+        if self.cells_own_dofs:  # (degree 3 on triangles: the cell's own dof belongs to the cell's rank)
+            hit |= self.cell_rank[self.win_cells] == q
+        return self.win_cells[self._win_local & hit]
 
     def peers(self):
         """Ranks this rank shares a cell with."""
         wc = self.mesh.cells[self.local_cells]
-        own = torch.cat([self.vown[wc].reshape(-1), self.eown[self.cell_edges_of(self.local_cells)].reshape(-1)])
+        own = [self.vown[wc].reshape(-1), self.eown[self.cell_edges_of(self.local_cells)].reshape(-1)]
+        if self.with_faces:
+            own.append(self.fown[self.cell_faces_of(self.local_cells)].reshape(-1))
+        if self.cells_own_dofs:
+            own.append(self.cell_rank[self.local_cells])
+        own = torch.cat(own)
         return [int(q) for q in torch.unique(own).tolist() if int(q) != self.rank and int(q) < self.nparts]
 
     def n_edges_global(self) -> int:
@@ -565,5 +608,14 @@ class MeshPartition:
                 self._n_edges_global = total
         return self._n_edges_global
 
+    def n_faces_global(self) -> int:
+        """Faces of the whole tetrahedral mesh: 4 per cell, interior faces counted twice (exterior ones once)."""
+        if getattr(self, "_n_faces_global", None) is None:
+            self._n_faces_global = (4 * self.mesh.num_cells + int(self.mesh.exterior_facets().shape[0])) // 2
+        return self._n_faces_global
+
     def num_dofs_global(self, degree: int) -> int:
+        if degree == 3:
+            last = self.n_faces_global() if self.mesh.gdim == 3 else self.mesh.num_cells
+            return self.mesh.num_vertices + 2 * self.n_edges_global() + last
         return self.mesh.num_vertices + (self.n_edges_global() if degree == 2 else 0)
