@@ -19,7 +19,7 @@ def _facet_pairs(F, mesh, facets):
     return fcell, opp[fslot]
 
 
-@pytest.mark.parametrize("dim,P", [(2, 1), (2, 2), (3, 1), (3, 2), (2, 3)])
+@pytest.mark.parametrize("dim,P", [(2, 1), (2, 2), (3, 1), (3, 2), (2, 3), (3, 3)])
 @pytest.mark.parametrize("kind", ["const", "callable"])
 def test_pressure_condition(hip, dim, P, kind):
     """PressureBC.rhs(i) assembles int h n_i dv/dx_i ds; .bc holds the tagged pressure dofs.  (2, 3): the reference's
