@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *__restrict
 
 __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, const int32_t *__restrict__ cell_edges,
                                              int64_t nc, int d, int degree, int64_t nverts, int64_t n_edges,
-                                             int32_t *__restrict__ cd0, const int32_t *__restrict__ cell_faces = nullptr) {
+                                             int32_t *__restrict__ cd0, const int32_t *__restrict__ cell_faces = nullptr,
+                                             const int32_t *__restrict__ cell_perm = nullptr) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= nc) return;
   const int nv = d + 1, ne = degree >= 2 ? (d == 2 ? 3 : 6) : 0;
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, 
   }
   if (degree == 3) {
     // triangles, 10 dofs: vertices; per local edge (a, b) the node nearer a, then the node nearer b -- an edge's two
-    // dofs are numbered from its LOWER global vertex to its higher one: nverts + 2 e + {0, 1}; the cell's own dof
+    // dofs are numbered from its LOWER global vertex to its higher one: nverts + 2 e + {0, 1}; the cell's own dof:
+    // nverts + 2 n_edges + the caller's index of the cell
     const int nd = 10;
     for (int a = 0; a < nv; ++a) cd0[c * nd + a] = cells[c * nv + a];
     for (int e = 0; e < ne; ++e) {
@@ -314,7 +316,9 @@ __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, 
       cd0[c * nd + nv + 2 * e] = (int32_t)(first + flip);
       cd0[c * nd + nv + 2 * e + 1] = (int32_t)(first + 1 - flip);
     }
-    cd0[c * nd + 9] = (int32_t)(nverts + 2 * n_edges + c);
+    // (the CALLER's cell index, not the kernel order's: the same on every rank of a partitioned mesh, whose parts list
+    // their cells in ascending global id -- sender and receiver then order these dofs alike)
+    cd0[c * nd + 9] = (int32_t)(nverts + 2 * n_edges + (cell_perm ? cell_perm[c] : c));
     return;
   }
   const int nd = nv + ne;
@@ -325,7 +329,8 @@ __global__ __launch_bounds__(256) void k_cd0(const int32_t *__restrict__ cells, 
 __global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ coords, const uint64_t *__restrict__ edge_keys,
                                                     int64_t nverts, int64_t n, int d, double *__restrict__ x, int degree = 2,
                                                     int64_t n_edges = 0, const int32_t *__restrict__ cells = nullptr,
-                                                    const uint64_t *__restrict__ face_keys = nullptr) {
+                                                    const uint64_t *__restrict__ face_keys = nullptr,
+                                                    const int32_t *__restrict__ cell_kernel_index = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (i < nverts) {
@@ -344,7 +349,8 @@ __global__ __launch_bounds__(256) void k_dof_coords(const double *__restrict__ c
       const int64_t a = (int64_t)(key / (nv_ * nv_)), b = (int64_t)((key / nv_) % nv_), c = (int64_t)(key % nv_);
       for (int k = 0; k < d; ++k) x[i * d + k] = (coords[a * d + k] + coords[b * d + k] + coords[c * d + k]) / 3.0;
     } else {
-      const int64_t c = i - nverts - 2 * n_edges;
+      const int64_t cc = i - nverts - 2 * n_edges;  // caller's cell index -> kernel cell index
+      const int64_t c = cell_kernel_index ? cell_kernel_index[cc] : cc;
       for (int k = 0; k < d; ++k) {
         double v = 0.0;
         for (int a = 0; a <= d; ++a) v += coords[(int64_t)cells[c * (d + 1) + a] * d + k];
@@ -1119,7 +1125,7 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
       OX_HIP(hipStreamSynchronize(st));
     }
     hipLaunchKernelGGL(k_cd0, dim3(nblk(nc)), dim3(256), 0, st, M->cells.as<int32_t>(), cell_edges.as<int32_t>(), nc, d, degree,
-                       M->nv, V->n_edges, cd0.as<int32_t>(), cell_faces.as<int32_t>());
+                       M->nv, V->n_edges, cd0.as<int32_t>(), cell_faces.as<int32_t>(), M->cell_perm.as<int32_t>());
     OX_LAUNCH_CHECK();
     OX_HIP(hipStreamSynchronize(st));
   }
@@ -1141,8 +1147,17 @@ static int space_create_impl(const ox_mesh *M, int degree, int window, const int
   // ---- 2. dof coordinates, tiled spatial order ------------------------------------------------------
   DevBuf xL, rank1;
   OX_TRY(xL.alloc(sizeof(double) * (size_t)n * d));
+  DevBuf cell_kidx;  // degree 3 on triangles: caller's cell index -> kernel cell index (the cell dofs' coordinates)
+  if (degree == 3 && d == 2) {
+    OX_TRY(cell_kidx.alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nc, 1)));
+    hipLaunchKernelGGL(k_invert, dim3(nblk(nc)), dim3(256), 0, st, M->cell_perm.as<int32_t>(), nc, cell_kidx.as<int32_t>());
+    OX_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_dof_coords, dim3(nblk(n)), dim3(256), 0, st, M->coords.as<double>(), V->edge_keys.as<uint64_t>(), M->nv, n,
-                     d, xL.as<double>(), degree, V->n_edges, M->cells.as<int32_t>(), V->face_keys.as<uint64_t>());
+                     d, xL.as<double>(), degree, V->n_edges, M->cells.as<int32_t>(), V->face_keys.as<uint64_t>(),
+                     cell_kidx.as<int32_t>());
+  OX_LAUNCH_CHECK();
+  OX_HIP(hipStreamSynchronize(st));  // (cell_kidx is released at the end of this scope's caller: finish the launch first)
   OX_LAUNCH_CHECK();
   OX_TRY(rank1.alloc(sizeof(int32_t) * (size_t)n));
   {

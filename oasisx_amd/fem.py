@@ -512,11 +512,7 @@ class FunctionSpace:
         if degree == 3 and part is not None:
             if mesh.device.type != "cuda" or _os.environ.get("OX_SETUP", "native") == "torch":
                 raise NotImplementedError("Lagrange degree 3 on a mesh partition: built by the library (GPU hosts)")
-            if mesh.gdim == 2:
-                # (the cells' own dofs are numbered in kernel cell order on every rank: sender and receiver would list them
-                # in different orders; tetrahedra have no such dofs)
-                raise NotImplementedError("Lagrange degree 3 on a PARTITIONED triangular mesh (tetrahedra and one-GPU "
-                                          "triangles are built)")
+
         # brick order of the numbering (lattice meshes, one GPU): what the LDS-window SpMV needs, a loss for the
         # lane = row kernels -- only together with ``build_windows`` (FractionalStep_AB_CN options["spmv_windows"]);
         # OX_BRICK=1 forces it for tuning runs
@@ -770,8 +766,7 @@ class FunctionSpace:
                 else:
                     if not part.cells_own_dofs:
                         raise ValueError("a degree-3 space on a partitioned triangular mesh needs MeshPartition(faces=True)")
-                    kernel_cells = sub.cells_global[sub.cell_perm.to(torch.int64)]
-                    last = nverts + 2 * ne_w + part._win_pos(kernel_cells)  # (NOT ascending: see global_to_local)
+                    last = nverts + 2 * ne_w + part._win_pos(sub.cells_global)  # (the part's cells: ascending global id)
                 gl = torch.cat([sub.verts, e2, last])
             else:
                 gl = sub.verts
@@ -1056,9 +1051,13 @@ class FunctionSpace:
                     pos = torch.searchsorted(fk, key).clamp_max(max(int(fk.shape[0]) - 1, 0))
                     hit = fk[pos] == key
                     gids.append((nv + 2 * int(self._edge_keys.shape[0]) + pos)[hit])
-        elif self.degree == 3 and dim == mesh.gdim:  # the cells' own dofs: initial id = nv + 2 n_edges + kernel cell index
-            kc = torch.from_numpy(self.kernel_cell_index(np.asarray(entities, dtype=np.int64)).astype(np.int64)).to(dev)
-            gids.append(mesh.num_vertices + 2 * int(self._edge_keys.shape[0]) + kc)
+        elif self.degree == 3 and dim == mesh.gdim:
+            # the cells' own dofs: initial id = nv + 2 n_edges + the cell's index as the library was handed it (its global
+            # id on one GPU, its position in the rank's window -- ascending global id -- on a partition)
+            ce = torch.from_numpy(np.asarray(entities, dtype=np.int64)).to(dev)
+            if self.part is not None:
+                ce = self.part._win_pos(ce)
+            gids.append(mesh.num_vertices + 2 * int(self._edge_keys.shape[0]) + ce)
         loc = self.global_to_local(torch.cat(gids))
         loc = loc[loc >= 0]
         return np.unique(loc.cpu().numpy()).astype(np.int32)

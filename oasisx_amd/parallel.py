@@ -524,6 +524,8 @@ class MeshPartition:
         self._win_local = (self.vown[wc] == self.rank).any(dim=1) | (self.eown[self._win_cell_edges] == self.rank).any(dim=1)
         if self.with_faces:
             self._win_local |= (self.fown[self._win_cell_faces] == self.rank).any(dim=1)
+        if self.cells_own_dofs:  # (an own cell all of whose vertices and edges belong to lower ranks still owns its cell dof)
+            self._win_local |= wrank == self.rank
         self.local_cells = self.win_cells[self._win_local]
         self._n_edges_global = None
 

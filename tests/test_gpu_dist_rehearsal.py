@@ -75,7 +75,7 @@ def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
 
         comm = init_comm()
         assert comm.size == world and comm.handle is None
-        p_deg = 2 if deg == 3 else 1  # (P3-P2 Taylor-Hood on tetrahedra, round 5: face dofs have owners and halo entries)
+        p_deg = 2 if deg == 3 else 1  # (P3-P2 Taylor-Hood, round 5: face / cell dofs have owners and halo entries)
         S, diffs = _run(dim, N, deg, comm, steps=2, low_memory=low_memory, p_deg=p_deg)
         G, gdiffs = _run(dim, N, deg, None, steps=2, low_memory=low_memory, p_deg=p_deg)
         Vi, Q = S._Vi[0][0], S._Q
@@ -110,7 +110,7 @@ def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
 @pytest.mark.parametrize("transport", ["p2p", "host"])
 @pytest.mark.parametrize("dim,N,deg,world,low_memory", [(3, 6, 2, 2, True), (2, 12, 2, 3, True), (3, 6, 1, 2, True),
                                                         (3, 6, 2, 2, False), (3, -5, 2, 2, True), (2, -14, 2, 3, False),
-                                                        (3, 4, 3, 2, True), (3, 3, 3, 3, False)])
+                                                        (3, 4, 3, 2, True), (3, 3, 3, 3, False), (2, 10, 3, 2, True), (2, 9, 3, 3, False)])
 def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory, transport):
     import torch.multiprocessing as mp
 
