@@ -98,7 +98,8 @@ class FractionalStep_AB_CN:
             to PETSc-style option dicts (see :mod:`oasisx_amd.ksp`)
         jit_options: accepted for compatibility, ignored (nothing is JIT compiled)
         options: ``"low_memory_version"`` accepted (see module docstring)
-        body_force: constant force per direction
+        body_force: per direction a constant, a callable ``f(x)``, a Function of the component space or a
+            :class:`oasisx_amd.function.Expression` of fields (assembled once, as in the reference)
     """
 
     def __init__(self, mesh, u_element, p_element, bcs_u, bcs_p, rotational: bool = False,
@@ -220,7 +221,9 @@ class FractionalStep_AB_CN:
             body_force = (0.0,) * gdim
         # per component: a float, a Constant, a spatial expression f(x) (x: (3, npts) -> (npts,)) or a Function on
         # the component space -- `force * v * dx` is assembled ONCE (reference fracstep.py:284-289,387-390)
-        self._body_force = [f if (callable(f) or isinstance(f, Function)) else float(f) for f in body_force]
+        from .function import Expression
+
+        self._body_force = [f if (callable(f) or isinstance(f, (Function, Expression))) else float(f) for f in body_force]
         if len(self._body_force) != gdim:
             raise ValueError(f"body_force: {gdim} components expected")
 
@@ -341,8 +344,10 @@ class FractionalStep_AB_CN:
                 tmp = torch.zeros(Vi.n_local, 1, dtype=torch.float64, device=dev)
                 self._M.mult(src, tmp, 1)
                 B0[: Vi.n_owned, i] = tmp[: Vi.n_owned, 0]
-            elif callable(f):  # a spatial expression: tabulated at quadrature points, summed by ox_assemble_load_vector
-                from .function import load_vector, metadata_points
+            elif not isinstance(f, float):
+                # a spatial expression (or a pointwise expression of fields, function.Expression): tabulated at quadrature
+                # points, summed by ox_assemble_load_vector
+                from .function import Expression, load_vector, metadata_points
 
                 q = metadata_points({"quadrature_degree": self._options.get("body_force_quadrature_degree")}, Vi.degree)
                 B0[: Vi.n_owned, i] = load_vector(Vi, f, self._geom, q)[: Vi.n_owned]
