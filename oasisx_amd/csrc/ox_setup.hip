@@ -98,11 +98,6 @@ int bits_for(uint64_t maxval) {
   return b;
 }
 
-__global__ __launch_bounds__(256) void k_iota32(int32_t *v, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) v[i] = (int32_t)i;
-}
-
 // per-dimension min / max of an [n][d] point set: per-block partials, finished on the host
 __global__ __launch_bounds__(256) void k_minmax(const double *__restrict__ x, int64_t n, int d, double *__restrict__ part) {
   __shared__ double lo_s[4][3], hi_s[4][3];

@@ -482,7 +482,6 @@ __global__ __launch_bounds__(256) void k_spmv_win(ox_sell A, const double *__res
       const int64_t base = A.slice_ptr[slice];
       const int npair = (int)((A.slice_ptr[slice + 1] - base) >> 7);
       typedef double v2d __attribute__((ext_vector_type(2)));
-      typedef unsigned short v2h __attribute__((ext_vector_type(2)));
       typedef int v2i __attribute__((ext_vector_type(2)));
       const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(A.vals + base) + lane;
       const unsigned short *__restrict__ vcp =
