@@ -516,12 +516,6 @@ int ox_ksp_solve_dc(int ksp_type, const ox_sell *A, const double *dinv, const do
  *   fold_blocks  one-column CG on one GPU: blocks of the folded update kernels; 0 = separate synchronisation points
  *                (five kernels per iteration), -1 = ox_ksp_default_fold_blocks()
  *   run_ahead    one-column solves queue one batch ahead of the state the host reads: 1 / 0, -1 = default (1)
- *   persistent   one-column standard CG on one GPU, on a matrix with a pair-slot stream whose rows fit the registers and
- *                the LDS of the chip (<= 144 slices per compute unit: 2.36 M rows on 256): the WHOLE solve in one launch,
- *                x, r, p, q resident in registers / LDS, three grid-wide synchronisation points per iteration inside the
- *                kernel (k_pcg_ps, csrc/ox_ksp.hip).  1 = wherever it applies, 0 = never, -1 = default (where it applies
- *                and every block owns at least one slice).  Same recurrences and per-row arithmetic as the other forms;
- *                a grid-wide wait that runs out (1 s) fails the call
  * ox_ksp_options_default fills in PETSc's defaults (rtol 1e-5, atol 1e-50, divtol 1e4, max_it 10000, zero guess). */
 typedef struct {
   double rtol, atol, divtol;
@@ -531,11 +525,9 @@ typedef struct {
   const uint8_t *dinv_code;  /* see ox_ksp_solve_dc                                       */
   const double *dinv_dict;
   int32_t n_dinv_dict;
-  int32_t persistent;
+  int32_t reserved;
 } ox_ksp_options;
 int ox_ksp_options_default(ox_ksp_options *opt);
-/* Blocks of the one-launch CG on this operator (one per compute unit), 0 where it does not apply. */
-int ox_ksp_persistent_blocks(const ox_sell *A, int partitioned);
 int ox_ksp_solve_opt(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x, int ncomp,
                      const ox_ksp_options *opt, void *work, size_t work_bytes, ox_ksp_result *result,
                      const ox_dist *dist, void *stream);

@@ -181,7 +181,7 @@ class ox_ksp_options(C.Structure):
         ("dinv_code", C.c_void_p),
         ("dinv_dict", C.c_void_p),
         ("n_dinv_dict", C.c_int32),
-        ("persistent", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -261,7 +261,6 @@ SIGNATURES = {
     "ox_window_retile": (_I, [C.POINTER(ox_sell), _P, _P, _I, _P, _P]),
     "ox_ksp_default_fold_blocks": (_I, []),
     "ox_ksp_kernels_per_iteration": (_I, [_I, C.POINTER(ox_sell), _I, _I, _I, _I]),
-    "ox_ksp_persistent_blocks": (_I, [C.POINTER(ox_sell), _I]),
     "ox_ksp_options_default": (_I, [C.POINTER(ox_ksp_options)]),
     "ox_ksp_solve_opt": (_I, [_I, C.POINTER(ox_sell), _P, _P, _P, _I, C.POINTER(ox_ksp_options), _P, C.c_size_t,
                               C.POINTER(ox_ksp_result), _P, _P]),

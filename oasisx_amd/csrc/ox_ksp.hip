@@ -10,7 +10,6 @@
 #include "ox_kernels.h"
 #include "ox_ksp_dev.h"
 #include "ox_p2p.h"
-#include "ox_ps_slice.h"
 #include <type_traits>
 
 // Fused: reduce per-block partials (fixed order) + scalar logic.  One wide block.
@@ -1363,344 +1362,6 @@ __global__ __launch_bounds__(OX_FOLD_T) void k_cgm_updatef(int64_t n, const KspS
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Persistent one-column CG on a pair-slot matrix (round 5).  The folded form above still streams r, x, p, q through
-// the caches twice per iteration (141.7 MB of the 264.7 MB a 128^3 pressure iteration moves: 26 of its 60 us).  Here ONE
-// launch runs the whole solve: one 1024-thread block per compute unit, all resident; block b owns a contiguous chunk of
-// slices (chunks dealt so that the blocks of one XCD hold neighbouring chunks), wave w of 16 the slices w, w + 16, ... of
-// it -- at most OX_PCG_MAXS each --, and every lane keeps ITS rows of x and p in registers and of r and q in LDS for the
-// whole solve.  Per iteration the only vector that touches memory is p: stored write-through by its owners, gathered by
-// the mat-vec.  Three grid-wide synchronisation points per iteration, inside the launch (tools/ubench/grid_sync.hip:
-// 14.1 us for all three on 256 CUs, against 26 us of update kernels and two kernel boundaries):
-//   R: all-reduce of {p.q}          -- block sums as tagged 8-byte granules ({epoch, half a double}: the data is the
-//   R: all-reduce of {r.z, z.z}        flag), one wave per block sweeps all blocks' granules and sums them in a fixed
-//                                      order: the same bits in every block, which then runs ksp_logic on its own copy
-//                                      of the state (as the folded kernels do);
-//   P: p published                  -- write-through stores, every wave drained, block barrier, one granule per block,
-//                                      the same sweep, ONE agent-scope acquire per block, then plain gathers.
-// (the hand-off forms of the CDNA4 guide: sc1 payload + flag, relaxed poll, one acquire).  Every spin is bounded: a
-// time-out raises the error word, every block leaves, the host call fails.  Same recurrences, same per-row arithmetic
-// and the same ksp_logic as the standard form; the dot products are summed in another order (rows are dealt to threads
-// differently), so the last bits of an iterate may differ from the folded form's -- as they do between any two of the
-// CG forms here.
-// ---------------------------------------------------------------------------------------
-#define OX_PCG_T 1024
-#define OX_PCG_MAXS 9     // slices per wave: 16 x 9 x 64 rows x (r, q) x 8 B = 144 KB of LDS
-#define OX_PCG_MAXB 320   // blocks (= compute units) the sweep is sized for
-typedef unsigned long long ox_u64;
-#define OX_AGENT __HIP_MEMORY_SCOPE_AGENT
-
-struct PcgSync {
-  ox_u64 *gran;  // [2][nb][4] tagged granules of the all-reduces
-  ox_u64 *bar;   // [2][nb]    tagged granules of the barriers
-  int *err;      // sticky: a bounded wait ran out
-  long long timeout_ticks;
-};
-
-// one wave: wait until the N granules of every block carry `epoch`; v[j][k] = the payloads of block lane + 64 j
-template <int N>
-__device__ __forceinline__ bool pcg_sweep(const ox_u64 *g, int nb, unsigned epoch, unsigned (&v)[OX_PCG_MAXB / 64][N],
-                                          const PcgSync &Y) {
-  const int lane = threadIdx.x & 63;
-  const long long t0 = wall_clock64();
-  for (;;) {
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < OX_PCG_MAXB / 64; ++j) {
-      const int b = lane + 64 * j;
-#pragma unroll
-      for (int k = 0; k < N; ++k) v[j][k] = 0u;
-      if (b < nb) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-          const ox_u64 w = __hip_atomic_load(g + (size_t)b * N + k, __ATOMIC_RELAXED, OX_AGENT);
-          v[j][k] = (unsigned)w;
-          ok &= (unsigned)(w >> 32) == epoch;
-        }
-      }
-    }
-    if (__all(ok)) return true;
-    if (__hip_atomic_load(Y.err, __ATOMIC_RELAXED, OX_AGENT)) return false;
-    if (wall_clock64() - t0 > Y.timeout_ticks) {
-      __hip_atomic_store(Y.err, 1, __ATOMIC_RELAXED, OX_AGENT);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-// sums[0..NV) (LDS, written by thread 0, a block barrier behind it) -> the sums over all blocks, in every thread's view
-template <int NV>
-__device__ __forceinline__ bool pcg_allreduce(double *sums, int *sh_ok, unsigned epoch, const PcgSync &Y) {
-  const int nb = gridDim.x;
-  ox_u64 *g = Y.gran + (size_t)(epoch & 1) * nb * 4;
-  if (threadIdx.x < 2 * NV) {
-    const ox_u64 bits = (ox_u64)__double_as_longlong(sums[threadIdx.x >> 1]);
-    const unsigned half = (threadIdx.x & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-    __hip_atomic_store(g + (size_t)blockIdx.x * 2 * NV + threadIdx.x, ((ox_u64)epoch << 32) | half, __ATOMIC_RELAXED, OX_AGENT);
-  }
-  if (threadIdx.x < 64) {
-    unsigned v[OX_PCG_MAXB / 64][2 * NV];
-    const bool ok = pcg_sweep<2 * NV>(g, nb, epoch, v, Y);
-    double t[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      t[i] = 0.0;
-#pragma unroll
-      for (int j = 0; j < OX_PCG_MAXB / 64; ++j)  // (blocks beyond the grid: +0.0)
-        t[i] += __longlong_as_double((long long)(((ox_u64)v[j][2 * i + 1] << 32) | v[j][2 * i]));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t[i] += __shfl_xor(t[i], o);  // a fixed butterfly: the same bits in every block
-    }
-    if (threadIdx.x == 0) {
-      *sh_ok = ok;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) sums[i] = t[i];
-    }
-  }
-  __syncthreads();
-  return *sh_ok != 0;
-}
-
-// every wave's write-through stores drained, then one granule per block, the sweep, one agent-scope acquire per block
-__device__ __forceinline__ bool pcg_barrier_acquire(int *sh_ok, unsigned epoch, const PcgSync &Y) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int nb = gridDim.x;
-  ox_u64 *g = Y.bar + (size_t)(epoch & 1) * nb;
-  if (threadIdx.x == 0) __hip_atomic_store(g + blockIdx.x, ((ox_u64)epoch << 32) | 1u, __ATOMIC_RELAXED, OX_AGENT);
-  if (threadIdx.x < 64) {
-    unsigned v[OX_PCG_MAXB / 64][1];
-    const bool ok = pcg_sweep<1>(g, nb, epoch, v, Y);
-    if (threadIdx.x == 0) {
-      *sh_ok = ok;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  return *sh_ok != 0;
-}
-
-constexpr size_t OX_PCG_LDS_VEC = (size_t)2 * OX_PCG_MAXS * OX_PCG_T * sizeof(double);
-constexpr size_t OX_PCG_LDS = OX_PCG_LDS_VEC + (256 + 256 + 32 + 4) * sizeof(double) + ((sizeof(KspState) + 15) & ~(size_t)15) + 16;
-
-#ifdef OX_DIAG
-// diagnostic build: wall-clock ticks (100 MHz) block 0 spends in each phase of k_pcg_ps, summed over the solve
-__device__ long long g_pcg_prof[8];
-extern "C" int ox_pcg_prof(long long *out8) {
-  OX_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pcg_prof), sizeof(long long) * 8));
-  long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  OX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pcg_prof), z, sizeof(z)));
-  return 0;
-}
-#define PCG_TICK(i)                                                     \
-  do {                                                                  \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                          \
-      const long long t_ = wall_clock64();                              \
-      g_pcg_prof[i] += t_ - tick_;                                      \
-      tick_ = t_;                                                       \
-    }                                                                   \
-  } while (0)
-#else
-#define PCG_TICK(i) do {} while (0)
-#endif
-
-template <bool CODE>
-__global__ __launch_bounds__(OX_PCG_T) void k_pcg_ps(ox_sell A, KspState *S, KspParams P, KspDinv D, double *x,
-                                                    const double *__restrict__ r0, double *p, PcgSync Y, int spb) {
-  // (every LDS word in the dynamic region, offsets multiples of 16: a static array in front would shift its base)
-  extern __shared__ __attribute__((aligned(16))) char pcg_smem[];
-  constexpr int T = OX_PCG_T, MS = OX_PCG_MAXS;
-  double *qs = reinterpret_cast<double *>(pcg_smem);  // [MS][T]: q = A p of this thread's rows
-  double *rs = qs + (size_t)MS * T;                    // [MS][T]: r
-  double *md = rs + (size_t)MS * T;                    // [256] value dictionary of the matrix
-  double *dd = md + 256;                               // [256] value dictionary of the Jacobi diagonal
-  double *red = dd + 256;                              // [32]
-  double *sums = red + 32;                             // [4]
-  KspState *sh = reinterpret_cast<KspState *>(sums + 4);
-  int *sh_ok = reinterpret_cast<int *>(reinterpret_cast<char *>(sh) + ((sizeof(KspState) + 15) & ~(size_t)15));
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = gridDim.x;
-  // consecutive chunks to the blocks of one XCD (blocks b and b + 8 share one): their gathers overlap in its L2
-  const int cid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  const int c0 = cid * spb, c1 = min(A.n_slices, c0 + spb);
-  for (int i = tid; i < A.n_dict; i += T) md[i] = A.vdict[i];
-  if (CODE)
-    for (int i = tid; i < D.n; i += T) dd[i] = D.dict[i];
-  ksp_state_load(sh, S);
-  double xk[MS];
-  unsigned ck[(MS + 3) / 4];  // the rows' diagonal codes, four to a register
-  unsigned vm = 0;            // bit k: row k of this thread exists
-#pragma unroll
-  for (int j = 0; j < (MS + 3) / 4; ++j) ck[j] = 0u;
-#pragma unroll
-  for (int k = 0; k < MS; ++k) {
-    const int s = c0 + k * 16 + wave;
-    const int64_t row = (int64_t)s * 64 + lane;
-    const bool ok = s < c1 && row < A.n_rows;
-    const int64_t rc = ok ? row : 0;
-    xk[k] = x[rc];
-    rs[k * T + tid] = r0[rc];
-    if (CODE) ck[k >> 2] |= (unsigned)D.code[rc] << (8 * (k & 3));
-    vm |= (unsigned)ok << k;
-  }
-  __syncthreads();
-  const int col = P.c0;
-  unsigned epoch = 0;
-  bool live = !sh->done;  // (uniform over the grid: every block reads the same state)
-#ifdef OX_DIAG
-  long long tick_ = wall_clock64();
-#endif
-  while (live) {
-    PCG_TICK(7);
-    // ---- q = A p, {p.q}
-    double spq = 0.0;
-    for (int k = 0; k < MS; ++k) {
-      const int s = c0 + k * 16 + wave;
-      if (s >= c1) break;  // (wave-uniform)
-      int64_t base = A.ps_ptr[s];
-      const int64_t next = A.ps_ptr[s + 1];
-      const bool wide = (base & 1) != 0;
-      const int last = (int)((base >> 1) & 7);
-      base &= ~(int64_t)255;
-      const int ng = (int)(((next & ~(int64_t)255) - base) >> 8);
-      double acc[1] = {0.0};
-      ox_ps_products<1>(A, p, md, s, lane, base, ng, wide, last, acc);
-      const int64_t row = (int64_t)s * 64 + lane;
-      if (row < A.n_rows) {
-        qs[k * T + tid] = acc[0];
-        spq = fma(p[row], acc[0], spq);
-      }
-    }
-    double v1[2] = {spq, 0.0};
-    ksp_block_sum_t<2>(v1, 1, red);
-    if (tid == 0) sums[0] = v1[0];
-    __syncthreads();
-    PCG_TICK(0);
-    if (!pcg_allreduce<1>(sums, sh_ok, ++epoch, Y)) break;
-    PCG_TICK(1);
-    if (tid == 0) {
-      ksp_logic<PH_CG_A>(sh, sums, 0, P);
-      ksp_finish(sh, P.nc_total);
-    }
-    __syncthreads();
-    const double alpha = sh->alpha[col];
-    // ---- r -= alpha q; z = D^-1 r (not stored); {r.z, z.z}
-    double s2[2] = {0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < MS; ++k) {
-      if ((vm >> k) & 1u) {
-        const double r = fma(-alpha, qs[k * T + tid], rs[k * T + tid]);
-        rs[k * T + tid] = r;
-        const double d = CODE ? dd[(ck[k >> 2] >> (8 * (k & 3))) & 0xffu] : D.v[(int64_t)(c0 + k * 16 + wave) * 64 + lane];
-        const double z = d * r;
-        s2[0] = fma(r, z, s2[0]);
-        s2[1] = fma(z, z, s2[1]);
-      }
-    }
-    ksp_block_sum_t<2>(s2, 2, red);
-    if (tid == 0) {
-      sums[0] = s2[0];
-      sums[1] = s2[1];
-    }
-    __syncthreads();
-    PCG_TICK(2);
-    if (!pcg_allreduce<2>(sums, sh_ok, ++epoch, Y)) break;
-    PCG_TICK(3);
-    if (tid == 0 && !sh->done) {
-      ksp_logic<PH_CG_B>(sh, sums, 0, P);
-      ksp_finish(sh, P.nc_total);
-    }
-    __syncthreads();
-    // ---- x += alpha p; p = z + beta p, published.  (p of this thread's rows comes back from memory -- its owner's own
-    // write-through stores of the iteration before, behind that iteration's acquire --: eighteen more registers through
-    // the mat-vec spilled.  x takes its update here, where p is at hand, as in k_cg_update2; the iteration that ends the
-    // solve updates x and leaves p alone.)
-    const bool done = sh->done != 0;
-    const double beta = sh->beta[col];
-#pragma unroll
-    for (int k = 0; k < MS; ++k) {
-      if ((vm >> k) & 1u) {
-        const int64_t row = (int64_t)(c0 + k * 16 + wave) * 64 + lane;
-        const double pk = p[row];
-        xk[k] = fma(alpha, pk, xk[k]);
-        if (!done) {
-          const double d = CODE ? dd[(ck[k >> 2] >> (8 * (k & 3))) & 0xffu] : D.v[row];
-          __hip_atomic_store(p + row, fma(beta, pk, d * rs[k * T + tid]), __ATOMIC_RELAXED, OX_AGENT);
-        }
-      }
-    }
-    if (done) break;
-    PCG_TICK(4);
-    if (!pcg_barrier_acquire(sh_ok, ++epoch, Y)) break;
-    PCG_TICK(5);
-  }
-#pragma unroll
-  for (int k = 0; k < MS; ++k) {
-    if ((vm >> k) & 1u) x[(int64_t)(c0 + k * 16 + wave) * 64 + lane] = xk[k];
-  }
-  if (blockIdx.x == 0) {
-    __syncthreads();
-    ksp_state_store(S, sh);
-    if (P.mirror) ksp_state_store(P.mirror, sh);
-  }
-}
-
-// the synchronisation words of the persistent kernel: one allocation per process (one solve at a time per process,
-// include/oasisx_hip.h), zeroed on the solve's stream before every launch
-static PcgSync g_pcg{nullptr, nullptr, nullptr, 0};
-static int g_pcg_cus = 0;
-static int pcg_setup() {
-  if (g_pcg.gran) return 0;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  OX_HIP(hipGetDevice(&dev));
-  OX_HIP(hipGetDeviceProperties(&prop, dev));
-  g_pcg_cus = prop.multiProcessorCount;
-  char *mem = nullptr;
-  // [2][MAXB][4] + [2][MAXB] granules, the error word: one block, zeroed whole
-  const size_t bytes = sizeof(ox_u64) * (2 * OX_PCG_MAXB * 4 + 2 * OX_PCG_MAXB) + 16;
-  OX_HIP(hipMalloc(&mem, bytes));
-  g_pcg.gran = reinterpret_cast<ox_u64 *>(mem);
-  g_pcg.bar = g_pcg.gran + 2 * OX_PCG_MAXB * 4;
-  g_pcg.err = reinterpret_cast<int *>(g_pcg.bar + 2 * OX_PCG_MAXB);
-  g_pcg.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz clock
-  OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pcg_ps<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)OX_PCG_LDS));
-  OX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pcg_ps<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)OX_PCG_LDS));
-  int occ = 0;
-  OX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pcg_ps<true>, OX_PCG_T, OX_PCG_LDS));
-  if (occ < 1) g_pcg_cus = 0;  // (never resident: the path stays off)
-  return 0;
-}
-// blocks and slices per block of the persistent form on this operator; 0: not applicable (no pair-slot stream, a
-// partitioned operator, more rows than the registers and the LDS of the chip hold, a device the sweep is not sized for)
-static int pcg_grid(const ox_sell *A, const ox_dist *dist, int *spb) {
-  if (!A || dist || !A->ps_ptr || !A->vdict || A->n_slices < 1) return 0;
-  if (pcg_setup() || g_pcg_cus < 8 || g_pcg_cus > OX_PCG_MAXB || (g_pcg_cus & 7)) return 0;
-  const int per = (A->n_slices + g_pcg_cus - 1) / g_pcg_cus;
-  if (per > 16 * OX_PCG_MAXS) return 0;
-  *spb = per;
-  return g_pcg_cus;
-}
-static int pcg_solve(const KspCtx &C, const KspVecs &V, const KspParams &P, int nb, int spb) {
-  const size_t bytes = sizeof(ox_u64) * (2 * OX_PCG_MAXB * 4 + 2 * OX_PCG_MAXB) + 16;
-  OX_HIP(hipMemsetAsync(g_pcg.gran, 0, bytes, C.st));
-  if (C.D.code)
-    hipLaunchKernelGGL(k_pcg_ps<true>, dim3(nb), dim3(OX_PCG_T), OX_PCG_LDS, C.st, *C.A, C.S, P, C.D, V.x, V.r, V.p, g_pcg, spb);
-  else
-    hipLaunchKernelGGL(k_pcg_ps<false>, dim3(nb), dim3(OX_PCG_T), OX_PCG_LDS, C.st, *C.A, C.S, P, C.D, V.x, V.r, V.p, g_pcg, spb);
-  OX_LAUNCH_CHECK();
-  int err = 0;
-  OX_HIP(hipMemcpyAsync(&err, g_pcg.err, sizeof(int), hipMemcpyDeviceToHost, C.st));
-  OX_HIP(hipStreamSynchronize(C.st));
-  if (err) OX_FAIL("ox_ksp_solve: a grid-wide wait of the persistent CG kernel timed out (is another kernel holding compute units?)");
-  return 0;
-}
-
 template <int NC>
 static int cgm_iterations(const KspCtx &C, const KspVecs &V, const KspParams &P, int count, bool first) {
   const int64_t n = C.A->n_rows;
@@ -1876,7 +1537,7 @@ template <int NC>
 static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const double *b, double *x,
                    const KspParams &P, int guess, int check_every, char *work,
                    ox_ksp_result *result, const ox_dist *dist, hipStream_t st, const double *ax0, const KspDinv &Dc,
-                   int fold_blocks, int run_ahead, int persistent) {
+                   int fold_blocks, int run_ahead) {
   const int64_t n = A->n_rows;
   const KspLayout L = ksp_layout(A->n_rows, A->n_cols, NC, ksp_type, ksp_grid_max(A));
   KspCtx C;
@@ -1945,22 +1606,9 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
   auto batch_of = [&](int every) { return every > 8 ? 8 : every; };
   int it = 0;  // iterations queued so far (the kernels stop by themselves at max_it)
   bool tail_done = false;  // the narrowed continuation applied the deferred updates of its column itself
-  // one column, standard CG, one GPU, a pair-slot matrix the chip holds in registers and LDS: the whole solve in ONE
-  // launch (k_pcg_ps); x is complete when it returns
-  bool pcg_done = false;
-  if (NC == 1 && cg && persistent) {
-    int spb = 0;
-    const int nbp = pcg_grid(A, dist, &spb);
-    if (nbp > 0) {
-      if (pcg_solve(C, V, P, nbp, spb)) return -1;
-      if (ksp_read_state(C)) return -1;
-      if (!g_state_host->done) OX_FAIL("ox_ksp_solve: the persistent CG kernel returned without completing the solve");
-      pcg_done = true;
-    }
-  }
   // The merged-reduction BiCGStab re-enters this loop when the STORED residual of a column fails the test its
   // recurrence norm passed (PH_BCGSM_FIN); every other method leaves it after one pass.
-  while (!pcg_done) {
+  for (;;) {
     tail_done = false;
     if (NC == 1 && run_ahead) {
       const int bsz = batch_of(check_every);
@@ -2067,7 +1715,7 @@ static int ksp_run(int ksp_type, const ox_sell *A, const double *dinv, const dou
     it = 0;
     for (int c = 0; c < NC; ++c) it = g_state_host->its[c] > it ? g_state_host->its[c] : it;
   }
-  if (cg && !tail_done && !pcg_done) {  // the last x += alpha p (see k_cg_update2)
+  if (cg && !tail_done) {  // the last x += alpha p (see k_cg_update2)
     hipLaunchKernelGGL((k_cg_update2<NC>), dim3(C.nb), dim3(256), 0, st, n, C.S, P.c0, V.x, V.r, C.D, V.p, 1);
     OX_LAUNCH_CHECK();
   }
@@ -2091,17 +1739,7 @@ extern "C" int ox_ksp_options_default(ox_ksp_options *o) {
   o->check_every = 1;
   o->fold_blocks = -1;
   o->run_ahead = -1;
-  o->persistent = -1;
   return 0;
-}
-
-extern "C" int ox_ksp_persistent_blocks(const ox_sell *A, int partitioned) {
-  // blocks of the one-launch CG (k_pcg_ps) on this operator, 0 where it does not apply (reporting, and the rule behind
-  // ox_ksp_options.persistent = -1: at least one slice per block)
-  int spb = 0;
-  if (partitioned) return 0;
-  const int nb = pcg_grid(A, nullptr, &spb);
-  return (nb > 0 && A->n_slices >= nb) ? nb : 0;
 }
 
 extern "C" int ox_ksp_default_fold_blocks(void) { return ksp_fold_blocks_default(); }
@@ -2159,14 +1797,10 @@ extern "C" int ox_ksp_solve_opt(int ksp_type, const ox_sell *A, const double *di
   const int fold = ksp_fold_blocks_of(opt->fold_blocks), ahead = opt->run_ahead < 0 ? 1 : (opt->run_ahead ? 1 : 0);
   const int guess = opt->nonzero_guess;
   const double *ax0 = opt->ax0;
-  // the one-launch CG: 1 = wherever it applies, 0 = never, -1 = where it applies and every block has a slice
-  int pers = 0;
-  if (ncomp == 1 && ksp_type == OX_KSP_CG && !dist && opt->persistent != 0)
-    pers = opt->persistent > 0 ? 1 : (ox_ksp_persistent_blocks(A, 0) > 0 ? 1 : 0);
   switch (ncomp) {
-    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead, pers);
-    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead, 0);
-    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead, 0);
+    case 1: return ksp_run<1>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
+    case 2: return ksp_run<2>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
+    default: return ksp_run<3>(ksp_type, A, dinv, b, x, P, guess, check_every, w, result, dist, st, ax0, D, fold, ahead);
   }
 }
 

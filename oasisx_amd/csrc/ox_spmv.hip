@@ -3,7 +3,6 @@
 // slice mapping.  No MFMA: the path is sparse and HBM-bound.
 #include "ox_common.h"
 #include "ox_kernels.h"
-#include "ox_ps_slice.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -215,6 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
                                                  const int *__restrict__ done_flag /* never null */,
                                                  const int32_t *__restrict__ slice_list, int n_list, OxEpiDinv ED) {
   constexpr int NV = (EPI == OX_EPI_NONE) ? 1 : ox_epi_nv(EPI, NC);
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-B load from an 8-B aligned address
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
   __shared__ double red[4 * NV];
   __shared__ double dict[4 * 256];
   const int lane = threadIdx.x & 63;
@@ -272,7 +273,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
     double acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-    ox_ps_products<NC>(A, x, md, slice, lane, base, ng, wide, last, acc);
+    const u4 *__restrict__ cp = reinterpret_cast<const u4 *>(A.ps_code + base) + lane;
+    const int2 *__restrict__ bp = reinterpret_cast<const int2 *>(A.ps_base) + (base >> 8);
+    // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B (NC = 1)
+    // one group: 4 slots = up to 8 entries of the row, 4 gathers of 16 B per component; the fused
+    // multiply-adds in the stored order of the entries
+    // NS: slots of the group in use (the rest is padding in every row of the slice: zero coefficients, no gather
+    // needed); a compile-time count keeps the group's gathers one straight-line batch
+    auto group = [&](auto ns_tag, const u4 code, const int2 b) {
+      constexpr int NS = decltype(ns_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const unsigned cj = code[j];
+        const int col = ((cj & 0x8000u) ? b.y : b.x) + (int)(cj & 0x7fffu);
+        const double va = md[(cj >> 16) & 0xffu], vb = md[cj >> 24];
+        const double *xp = x + (size_t)col * NC;
+        d2u xv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xv[c] = *reinterpret_cast<const d2u *>(xp + 2 * c);
+        // x[col][0..NC-1] then x[col+1][0..NC-1] are the 2*NC doubles of xv[0..NC-1]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma(va, (c & 1) ? xv[c >> 1].y : xv[c >> 1].x, acc[c]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma(vb, ((NC + c) & 1) ? xv[(NC + c) >> 1].y : xv[(NC + c) >> 1].x, acc[c]);
+      }
+    };
+    if (ng > 0) {
+      if (!wide) {
+        // ---- rounds B, C.  The code loads come from the Infinity Cache / HBM (the stream does not fit the L2s):
+        // ~2000 cycles a round, the longest link of the wave's chain.  The codes of the first THREE groups are
+        // therefore requested together (a P1 slice has 2 or 3): a 3-group slice saves a whole round.  Gathers
+        // stay two groups per turn (eight in flight per wave at 100 registers measured 25 % slower).
+        auto tail = [&](const u4 cc, const int2 bq) {  // the slice's last group
+          if (last == 1) group(std::integral_constant<int, 1>{}, cc, bq);
+          else if (last == 2) group(std::integral_constant<int, 2>{}, cc, bq);
+          else if (last == 3) group(std::integral_constant<int, 3>{}, cc, bq);
+          else group(std::integral_constant<int, 4>{}, cc, bq);
+        };
+        int q0 = 0;
+        if (ng <= 3) {
+          const u4 c0 = __builtin_nontemporal_load(cp);
+          const u4 c1 = __builtin_nontemporal_load(cp + (size_t)min(1, ng - 1) * 64);
+          const u4 c2 = __builtin_nontemporal_load(cp + (size_t)(ng - 1) * 64);
+          const int2 b0 = bp[0], b1 = bp[min(1, ng - 1)], b2 = bp[ng - 1];
+          if (ng == 1) {
+            tail(c0, b0);
+          } else {
+            group(std::integral_constant<int, 4>{}, c0, b0);
+            if (ng == 2) {
+              tail(c1, b1);
+            } else {
+              group(std::integral_constant<int, 4>{}, c1, b1);
+              tail(c2, b2);
+            }
+          }
+          q0 = ng;
+        }
+        for (int q = q0; q < ng; q += 2) {
+          const int q1 = min(q + 1, ng - 1);
+          const u4 ca = __builtin_nontemporal_load(cp + (size_t)q * 64);
+          const u4 cb2 = __builtin_nontemporal_load(cp + (size_t)q1 * 64);
+          const int2 ba = bp[q], bb = bp[q1];
+          if (q + 1 < ng) {
+            group(std::integral_constant<int, 4>{}, ca, ba);
+            if (q + 2 < ng) group(std::integral_constant<int, 4>{}, cb2, bb);
+            else tail(cb2, bb);
+          } else {
+            tail(ca, ba);
+          }
+        }
+      } else {  // this slice's pair columns did not fit two 15-bit windows (rare): entry stream
+        const int64_t eb = A.slice_ptr[slice];
+        const int npair = (int)((A.slice_ptr[slice + 1] - eb) >> 7);
+        const int2 *__restrict__ ecp = reinterpret_cast<const int2 *>(A.cols + eb) + lane;
+        const unsigned short *__restrict__ vcp = reinterpret_cast<const unsigned short *>(A.vcode + eb) + lane;
+        for (int k = 0; k < npair; ++k) {
+          const unsigned c2 = vcp[(size_t)k * 64];
+          const int2 c = ecp[(size_t)k * 64];
+          const double va = md[c2 & 0xff], vb = md[c2 >> 8];
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(va, x[(size_t)c.x * NC + cc], acc[cc]);
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) acc[cc] = fma(vb, x[(size_t)c.y * NC + cc], acc[cc]);
+        }
+      }
+    }
     if (row < A.n_rows) {
       if (EPI == OX_EPI_BCGS_V || EPI == OX_EPI_BCGS_T || EPI == OX_EPI_BCGS_T5) {
 #pragma unroll

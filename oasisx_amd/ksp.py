@@ -32,9 +32,6 @@ Option mapping (PETSc string keys, as the reference passes them):
             blocks of the folded one-column CG update kernels (0: five kernels per iteration; default: one per
             compute unit, or the environment's OX_CG_FOLD_BLOCKS read once by this module) and whether one-column
             solves queue one batch ahead of the state the host reads (default true; OX_KSP_RUN_AHEAD)
-  ksp_cg_persistent (extension): one-column standard CG on one GPU as ONE launch with x, r, p, q resident in registers and
-            LDS (csrc/ox_ksp.hip k_pcg_ps; matrices with a pair-slot stream of at most 144 slices per compute unit):
-            true / false; default: wherever it applies and every block owns a slice (OX_KSP_PERSISTENT=0/1 overrides)
   ksp_bcgs_restarts (extension): BiCGStab restarts allowed after a rho/omega breakdown; default 0
             for an explicit "bcgs" (PETSc's KSPBCGS stops with DIVERGED_BREAKDOWN), 5 when the
             method stands in for a direct solver, which cannot break down (e.g. a cold start with
@@ -84,8 +81,7 @@ CG_MERGED_MAX_ROWS = 1 << 20
 KRYLOV_TYPES = ("cg", "bcgs", "bicgstab", "ibcgs", "pipebcgs", "fbcgsr")
 HONOURED_KEYS = ("ksp_type", "pc_type", "ksp_rtol", "ksp_atol", "ksp_divtol", "ksp_max_it", "ksp_initial_guess_nonzero",
                  "ksp_error_if_not_converged", "ksp_cg_single_reduction", "ksp_cg_merged_reduction",
-                 "ksp_bcgs_merged_reduction", "ksp_bcgs_restarts", "ksp_cg_fold_blocks", "ksp_run_ahead",
-                 "ksp_cg_persistent")
+                 "ksp_bcgs_merged_reduction", "ksp_bcgs_restarts", "ksp_cg_fold_blocks", "ksp_run_ahead")
 # keys the reference itself sets next to a direct solver (fracstep.py:565-570): they configure MUMPS, which the Krylov
 # stand-in has no use for -- accepted silently with ksp_type=preonly
 DIRECT_ONLY_KEYS = ("pc_factor_mat_solver_type", "mat_mumps_icntl_24", "mat_mumps_icntl_25")
@@ -105,7 +101,6 @@ class KSPSolver:
         self._every = {}
         self._env_fold = _env_int("OX_CG_FOLD_BLOCKS", -1)
         self._env_ahead = _env_int("OX_KSP_RUN_AHEAD", -1)
-        self._env_persistent = _env_int("OX_KSP_PERSISTENT", -1)
         self.updateOptions({} if petsc_options is None else petsc_options)
 
     # -- reference surface --------------------------------------------------------------
@@ -244,19 +239,6 @@ class KSPSolver:
         v = self._options.get("ksp_run_ahead")
         return (1 if _truthy(v) else 0) if v is not None else self._env_ahead
 
-    def _persistent(self) -> int:
-        v = self._options.get("ksp_cg_persistent")
-        return (1 if _truthy(v) else 0) if v is not None else self._env_persistent
-
-    def _cg_persistent(self) -> bool:
-        """Whether the next one-column standard-CG solve on this operator runs as the one-launch kernel."""
-        if self._A is None or self._A.pattern.dist is not None or self._method()[0] != _lib.KSP_CG or self._cg_merged():
-            return False
-        if self._persistent() == 0:
-            return False
-        # (reporting only: a forced option also runs it on operators with fewer slices than compute units)
-        return int(_lib.load().ox_ksp_persistent_blocks(self._A.ref(), 0)) > 0
-
     def _cg_folded(self) -> bool:
         """One-column standard CG on one GPU: the iteration's two synchronisation points are folded into the update
         kernels (3 kernels per iteration: csrc/ox_ksp.hip k_cg_update1f / k_cg_update2f; option ``ksp_cg_fold_blocks``).
@@ -340,7 +322,6 @@ class KSPSolver:
         opt.divtol = float(self._options.get("ksp_divtol", 1e4))  # PETSc's default ("divergence=10000." in -ksp_view)
         opt.nonzero_guess, opt.check_every, opt.max_restarts = int(guess), int(every), restarts
         opt.fold_blocks, opt.run_ahead = self._fold_blocks(), self._run_ahead()
-        opt.persistent = self._persistent()
         opt.ax0 = ax0.ptr() if (ax0 is not None and guess) else None
         if dcode is not None:
             opt.dinv_code, opt.dinv_dict = _lib.ptr(dcode), _lib.ptr(self._ddict)

@@ -36,12 +36,5 @@ for rnd in range(int(os.environ.get("ROUNDS", "3"))):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ksp.solve_block(B, X)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        if hasattr(lib, "ox_pcg_prof") and not merged:  # diagnostic build (tools/build_diag.sh): phases of k_pcg_ps in block 0
-            t = (C.c_longlong * 8)()
-            lib.ox_pcg_prof(t)
-            its = max(ksp.iterations[0], 1) * 2  # (the warm-up solve ran too)
-            names = ["mat-vec + block sum", "all-reduce {p.q}", "r update + block sum", "all-reduce {r.z, z.z}",
-                     "x, p update + publish", "barrier + acquire", "", "loop head"]
-            print("   k_pcg_ps, us per iteration in block 0: " + ", ".join(f"{names[i]} {t[i] / 100.0 / its:.2f}" for i in (0, 1, 2, 3, 4, 5, 7)))
         print(f"N={N} merged={merged}: {1e6 * (t1 - t0) / max(ksp.iterations[0], 1):.1f} us per iteration ({ksp.iterations[0]} iterations, "
               f"reason {ksp.last_result.reason[0]}, |D^-1 r| {ksp.last_result.rnorm[0]:.3e})")
