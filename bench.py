@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)  # (the first steps after the start need more Krylov iterations)
     ap.add_argument("-N", type=int, default=128, help="cubes per direction")
     ap.add_argument("--udeg", type=int, default=2)
+    ap.add_argument("--pdeg", type=int, default=None, help="pressure degree (default 1; 2 with --udeg 3: Taylor-Hood P3-P2)")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--workload", default="tg", choices=["tg", "beltrami", "cavity"])
     ap.add_argument("--zero-guess", action="store_true",
@@ -105,7 +106,10 @@ def parse():
     ap.add_argument("--profile-every", type=int, default=32,
                     help="HIP-event pair around every n-th launch of a kernel tag inside the timed region")
     ap.add_argument("--verbose", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.pdeg is None:
+        a.pdeg = 2 if a.udeg >= 3 else 1
+    return a
 
 
 def host_cores():
@@ -144,7 +148,7 @@ def pmc_traffic(args, log):
             out = os.path.join(tmp, counter)
             mode = ["--kernel-trace"] if counter == "KERNEL_TRACE" else ["--pmc", counter]
             cmd = [exe, *mode, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child", "-N", str(args.N), "--udeg", str(args.udeg),
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "-N", str(args.N), "--udeg", str(args.udeg), "--pdeg", str(args.pdeg),
                    "--workload", args.workload, "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol)]
             for flag, on in (("--zero-guess", args.zero_guess), ("--matrix-free", args.matrix_free),
                              ("--no-dictionary", args.no_dictionary)):
@@ -383,7 +387,7 @@ def main():
         if args.cg_fold_blocks is not None:
             for k in ("pressure", "scalar", "tentative"):
                 so[k]["ksp_cg_fold_blocks"] = int(args.cg_fold_blocks)
-        S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", 1), bcs_u=bcs_u, bcs_p=[],
+        S_ = ox.FractionalStep_AB_CN(mesh, ("Lagrange", udeg), ("Lagrange", args.pdeg), bcs_u=bcs_u, bcs_p=[],
                                      solver_options=so, options=opts)
         return mesh, S_
 
@@ -427,7 +431,7 @@ def main():
         if wname == "cavity":
             tent["ksp_bcgs_restarts"] = 5  # a start from rest: see build()
         S2 = ox.FractionalStep_AB_CN(
-            m2, ("Lagrange", args.udeg), ("Lagrange", 1),
+            m2, ("Lagrange", args.udeg), ("Lagrange", args.pdeg),
             bcs_u=[[ox.DirichletBC(bcv(f), ox.LocatorMethod.GEOMETRICAL, on_bnd)] for f in W2["fns"]], bcs_p=[],
             solver_options={"tentative": tent, "pressure": dict(ksp, ksp_type="cg"), "scalar": dict(ksp, ksp_type="cg")},
             options=options)
@@ -460,7 +464,7 @@ def main():
                     f"Delaunay mesh of a jittered {delaunay[0] + 1}^3 lattice refined uniformly {delaunay[1]}x "
                     f"({m2.num_cells} tets, {S2._Vi[0][0].num_dofs_global} P2 dofs per component)")
         res = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
-               "workload": f"{W2['desc']}, {mesh_txt} P{args.udeg}-P1, nu={W2['nu']}, dt={W2['dt']:g}",
+               "workload": f"{W2['desc']}, {mesh_txt} P{args.udeg}-P{args.pdeg}, nu={W2['nu']}, dt={W2['dt']:g}",
                "krylov_iterations_per_step": mean_iterations(its2), "krylov_iterations_series": iteration_series(its2),
                "setup_s": t_set, "mesh_generation_s": t_mesh,
                "kernels": {k: {a: b for a, b in v.items() if a in ("launches", "avg_us", "bytes_moved", "gbs", "frac_of_hbm_peak")}
@@ -859,7 +863,7 @@ def main():
         mean_its = mean_iterations(its)
         short = {"tg": "Taylor-Green", "beltrami": "Beltrami (Ethier-Steinman)", "cavity": "lid-driven cavity"}[args.workload]
         out = {
-            "metric": f"time-steps/sec, 3D {short} {N}^3 P{args.udeg}-P1 (with pressure-CG SpMV GB/s in roofline)",
+            "metric": f"time-steps/sec, 3D {short} {N}^3 P{args.udeg}-P{args.pdeg} (with pressure-CG SpMV GB/s in roofline)",
             "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -867,7 +871,7 @@ def main():
                                    + (f"{N}^3x6 tets" if args.mesh == "box" else
                                       f"Delaunay mesh of a jittered {N + 1}^3 lattice"
                                       + (f", uniformly refined {args.refine}x" if args.refine else "") + f" ({mesh.num_cells} tets)")
-                                   + f" P{args.udeg}-P1, nu={nu}, dt={dt:g}, "
+                                   + f" P{args.udeg}-P{args.pdeg}, nu={nu}, dt={dt:g}, "
                                    f"bcgs+jacobi / cg+jacobi rtol={args.rtol:g} atol=1e-14 "
                                    f"initial_guess_nonzero={not args.zero_guess}, max_iter=1, "
                                    f"low_memory_version={args.matrix_free}, value_dictionary={not args.no_dictionary}",
