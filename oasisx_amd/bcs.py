@@ -166,7 +166,7 @@ class PressureBC:
     def create_bcs(self, V, Q):
         import itertools
 
-        from .fem import build_sell, local_edges
+        from .fem import build_sell
         from .la import SellMatrix
 
         mesh = V.mesh

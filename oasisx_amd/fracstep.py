@@ -347,7 +347,7 @@ class FractionalStep_AB_CN:
             elif not isinstance(f, float):
                 # a spatial expression (or a pointwise expression of fields, function.Expression): tabulated at quadrature
                 # points, summed by ox_assemble_load_vector
-                from .function import Expression, load_vector, metadata_points
+                from .function import load_vector, metadata_points
 
                 q = metadata_points({"quadrature_degree": self._options.get("body_force_quadrature_degree")}, Vi.degree)
                 B0[: Vi.n_owned, i] = load_vector(Vi, f, self._geom, q)[: Vi.n_owned]

@@ -25,8 +25,8 @@ from . import _lib
 import numpy as np
 import torch
 
-from .fem import (SLICE, DGSpace, FieldStorage, Function, FunctionSpace, VectorFunctionSpace, _simplex_rule, cell_geometry,
-                  lagrange_basis, lagrange_basis_derivs, local_edges)
+from .fem import (DGSpace, FieldStorage, Function, FunctionSpace, VectorFunctionSpace, _simplex_rule, cell_geometry,
+                  lagrange_basis, lagrange_basis_derivs)
 from .ksp import KSPSolver
 from .la import SellMatrix
 
