@@ -41,13 +41,7 @@ from oasisx_amd.fem import FieldStorage
 from oasisx_amd.ksp import KSPSolver
 from oasisx_amd.parallel import SelfLoopComm
 
-ASSUMED = {
-    "what": "link-side costs no one-GPU run can measure; everything else in this file is measured",
-    "xgmi_link_GBps_per_direction": 76.8,  # 153.6 GB/s bidirectional per link (7 links per GPU, point to point)
-    "link_efficiency": 0.7,
-    "exchange_latency_us": 12.0,           # grouped ncclSend/ncclRecv between two GPUs over what the self-loop already pays
-    "allreduce_extra_latency_us": {"1": 0.0, "2": 8.0, "4": 12.0, "8": 17.0},  # small-message ncclAllReduce, over the 1-rank launch
-}
+from scaling_model import ASSUMED, predict  # noqa: E402  (tools/scaling_model.py)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=128)
@@ -238,34 +232,6 @@ def real_run():
     el = time.perf_counter() - t0
     profile = {k: float(np.mean([p_[k] for p_ in prof])) for k in prof[0]}
     return m, profile, 1e3 * el / args.steps
-
-
-def predict(m, profile, P):
-    """Step time (ms) of one rank from its measured costs, the iteration profile and the modelled link costs."""
-    bw = ASSUMED["xgmi_link_GBps_per_direction"] * ASSUMED["link_efficiency"] * 1e9
-    lat = ASSUMED["exchange_latency_us"] * 1e-3 if P > 1 else 0.0
-    ar = ASSUMED["allreduce_extra_latency_us"][str(P)] * 1e-3 if P > 1 else 0.0
-
-    def xch(nvals, ncomp):  # ms the link adds to one halo exchange (the slower of this rank's send and receive sides)
-        return 0.0 if P == 1 else lat + 1e3 * 8.0 * ncomp * nvals / bw
-    xu3 = xch(max(m.get("send_max_u", 0), m.get("recv_max_u", 0)), 3)
-    xu1 = xch(max(m.get("send_max_u", 0), m.get("recv_max_u", 0)), 1)
-    xp1 = xch(max(m.get("send_max_p", 0), m.get("recv_max_p", 0)), 1)
-    # exchanges / all-reduces per iteration of the partitioned defaults: merged BiCGStab 2 mat-vecs + 2 points,
-    # single-reduction or merged CG 1 mat-vec + 1 point
-    ph = {}
-    ph["assemble_first"] = m["assemble_first_ms"]
-    ph["velocity_tentative_assemble"] = m["tentative_assemble_ms"] + (xp1 if P > 1 else 0.0) * 0  # (ps ghosts are current)
-    ph["velocity_tentative_solve"] = (m["bcgs3"]["fixed_ms"] + profile["tent3"] * (m["bcgs3"]["iter_ms"] + 2 * xu3 + 2 * ar)
-                                      + profile["tent1"] * (m["bcgs1"]["iter_ms"] + 2 * xu1 + 2 * ar)
-                                      + (m["bcgs1"]["fixed_ms"] if profile["tent1"] > 0 else 0.0) + xu3)
-    ph["pressure_assemble"] = m["pressure_assemble_ms"]
-    ph["pressure_solve"] = m["cgP1"]["fixed_ms"] + profile["pressure"] * (m["cgP1"]["iter_ms"] + xp1 + ar) + xp1 + 2 * ar
-    ph["velocity_update"] = (m["update_rhs_ms"] + m["cgM3"]["fixed_ms"] + profile["upd3"] * (m["cgM3"]["iter_ms"] + xu3 + ar)
-                             + profile["upd1"] * (m["cgM1"]["iter_ms"] + xu1 + ar)
-                             + (m["cgM1"]["fixed_ms"] if profile["upd1"] > 0 else 0.0) + xu3)
-    ph["step_vector_work"] = m["step_vector_work_ms"]
-    return ph
 
 
 def free(*objs):
