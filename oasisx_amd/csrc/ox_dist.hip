@@ -288,7 +288,13 @@ __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
     double *dst = r_stage[p * 2 + parity] + (r_off[p] + (k - send_off[p])) * nc + c;
     __hip_atomic_store(dst, v, __ATOMIC_RELAXED, OX_SYS);
   }
-  __threadfence_system();
+  // The payload stores are system-scope write-through stores into an uncached window: nothing of them sits in a cache.
+  // Every storing wave waits for its stores to be acknowledged, the block barrier orders them in front of thread 0's
+  // agent-scope acq_rel ticket, and the block that arrives last fences ONCE at system scope before it raises the flags.
+  // (Rounds 1-4 had every thread of every block run __threadfence_system() here: a write-back and an invalidate of the
+  // XCD's L2 per block -- 100 us for the 2.4 MB velocity halo of a 128^3 x 8 rank, and the mat-vec around it lost its
+  // cached operands; round 5, found by timing the self-loop plans: tools/predict_scaling.py --transport p2p.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

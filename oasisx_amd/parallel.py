@@ -331,7 +331,13 @@ class SelfLoopComm(Comm):
     collective = False
     self_loop = True
 
-    def __init__(self, rank: int, size: int):
+    def __init__(self, rank: int, size: int, device_transport: str = "rccl"):
+        """``device_transport``: "rccl" (the one-rank communicator) or "p2p" -- the plans push into and pull from THIS
+        rank's own xGMI window: the push / pull kernels and the single-kernel all-reduce of the window transport, with
+        no link under them."""
+        if device_transport not in ("rccl", "p2p"):
+            raise ValueError("SelfLoopComm: device_transport is 'rccl' or 'p2p'")
+        self.device_transport = device_transport
         lib = _lib.load()
         buf = C.create_string_buffer(128)
         _lib.check(lib.ox_comm_unique_id(buf), "ox_comm_unique_id")
@@ -359,6 +365,13 @@ class SelfLoopComm(Comm):
         _lib.check(lib.ox_dist_create(self.handle, 0, 1, int(peers.shape[0]), peers.ctypes.data_as(C.POINTER(C.c_int32)),
                                       off.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(send_idx),
                                       off.ctypes.data_as(C.POINTER(C.c_int64)), V.n_owned, ng, C.byref(out)), "ox_dist_create")
+        if self.device_transport == "p2p":  # the plan's only peer is this rank: its own window is the remote one
+            win, handle = C.c_void_p(), C.create_string_buffer(64)
+            _lib.check(lib.ox_p2p_window_create(lib.ox_p2p_window_bytes(1, ng), C.byref(win), handle), "ox_p2p_window_create")
+            wins = (C.c_void_p * 1)(win.value)
+            zero, png = np.zeros(1, dtype=np.int64), np.asarray([ng], dtype=np.int64)
+            _lib.check(lib.ox_dist_enable_p2p(out, win, wins, zero.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              png.ctypes.data_as(C.POINTER(C.c_int64)), 15.0), "ox_dist_enable_p2p")
         return out
 
     def allreduce(self, v, op=None):

@@ -41,7 +41,7 @@ from oasisx_amd.fem import FieldStorage
 from oasisx_amd.ksp import KSPSolver
 from oasisx_amd.parallel import SelfLoopComm
 
-from scaling_model import ASSUMED, predict  # noqa: E402  (tools/scaling_model.py)
+from scaling_model import ASSUMED, ASSUMED_P2P, predict as _predict  # noqa: E402  (tools/scaling_model.py)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=128)
@@ -51,7 +51,17 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--matrix-free", action="store_true")
 ap.add_argument("--out", default=None)
+ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p"],
+                help="device transport of the self-loop plans: the one-rank RCCL communicator, or the xGMI-window kernels")
 args = ap.parse_args()
+if args.transport == "p2p":
+    ASSUMED = ASSUMED_P2P
+
+
+def predict(m, profile, P):
+    return _predict(m, profile, P, ASSUMED)
+
+
 N, pi = args.N, math.pi
 nu, dt = 0.01, 0.005 * 32.0 / N
 box = ([-1.0] * 3, [1.0] * 3)
@@ -241,6 +251,8 @@ def free(*objs):
 
 
 out = {"label": "PREDICTION from one-GPU measurements -- NOT a measurement of a multi-GPU run", "assumed": ASSUMED,
+       "transport": {"rccl": "RCCL plans (the default of a job with an RCCL communicator), exchange-then-multiply",
+                     "p2p": "xGMI-window plans (OX_TRANSPORT=p2p): push / pull kernels, one-kernel all-reduce, overlapped mat-vecs"}[args.transport],
        "workload": f"3D Taylor-Green {N}^3 x 6 tets P2-P1 (BASELINE configs[2] / [4]), nu={nu}, dt={dt:g}, bcgs+jacobi / cg+jacobi "
                    f"rtol 1e-8, initial_guess_nonzero, low_memory_version={args.matrix_free}",
        "device": torch.cuda.get_device_name(0), "P": {}}
@@ -258,7 +270,7 @@ for P in [p_ for p_ in args.P if p_ > 1]:
     ranks = list(range(P)) if args.ranks == "all" else sorted({0, P - 1})
     per, phs = {}, {}
     for r in ranks:
-        comm = SelfLoopComm(r, P)
+        comm = SelfLoopComm(r, P, args.transport)
         mesh, S, m = measure_rank(comm)
         del mesh, S
         gc.collect()

@@ -11,7 +11,18 @@ ASSUMED = {
 }
 
 
-def predict(m, profile, P):
+# the xGMI-window transport (OX_TRANSPORT=p2p): the self-loop already pays the push and pull kernels and the one-kernel
+# all-reduce; what a real link adds is the one-way latency of uncached remote stores + flag (no library call, no launch)
+ASSUMED_P2P = {
+    "what": "link-side costs no one-GPU run can measure, for the xGMI-window transport; everything else is measured",
+    "xgmi_link_GBps_per_direction": 76.8,
+    "link_efficiency": 0.7,
+    "exchange_latency_us": 4.0,
+    "allreduce_extra_latency_us": {"1": 0.0, "2": 3.0, "4": 4.0, "8": 5.0},
+}
+
+
+def predict(m, profile, P, ASSUMED=ASSUMED):
     """Step time (ms) of one rank from its measured costs, the iteration profile and the modelled link costs."""
     bw = ASSUMED["xgmi_link_GBps_per_direction"] * ASSUMED["link_efficiency"] * 1e9
     lat = ASSUMED["exchange_latency_us"] * 1e-3 if P > 1 else 0.0
