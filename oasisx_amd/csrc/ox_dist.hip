@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELEASE, OX_SYS);
+      __threadfence_system();  // the one release of the launch; the flags behind it are relaxed stores
+      for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELAXED, OX_SYS);
     }
   }
 }

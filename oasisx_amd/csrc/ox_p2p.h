@@ -43,8 +43,9 @@ __device__ __forceinline__ void ox_p2p_allreduce_block(double *vals, int n, cons
     char *dst = a.r_slot[r * 2 + a.parity];
     for (int i = 0; i < n; ++i)
       __hip_atomic_store(reinterpret_cast<double *>(dst) + i, vals[i], __ATOMIC_RELAXED, OX_SYS);
+    // (ONE release: the fence; a release STORE behind it would write back and invalidate the L2 a second time)
     __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), a.seq, __ATOMIC_RELEASE, OX_SYS);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), a.seq, __ATOMIC_RELAXED, OX_SYS);
     const char *src = a.my_slots + ((size_t)a.parity * a.nranks + r) * OX_P2P_SLOT;
     ox_p2p_wait(reinterpret_cast<const unsigned long long *>(src + OX_P2P_SLOT - 8), a.seq, a.timeout_ticks, a.err);
     for (int i = 0; i < n; ++i)
