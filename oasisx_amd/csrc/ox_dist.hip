@@ -269,8 +269,27 @@ extern "C" int ox_dist_status(const ox_dist *d) {
   return 0;
 }
 
+// 16-byte system-scope accesses to a window (no builtin for them): write-through store, cache-bypassing load
+typedef unsigned ox_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ox_store16_sys(double *dst, double a, double b) {
+  ox_u4 v;
+  v.x = (unsigned)__double_as_longlong(a);
+  v.y = (unsigned)((unsigned long long)__double_as_longlong(a) >> 32);
+  v.z = (unsigned)__double_as_longlong(b);
+  v.w = (unsigned)((unsigned long long)__double_as_longlong(b) >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ox_load16_sys(const double *src, double &a, double &b) {
+  ox_u4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+  a = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+  b = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+}
+
 // gather the interface values and store them into the neighbours' windows; the last block to
-// finish raises this rank's flag in every neighbour's window
+// finish raises this rank's flag in every neighbour's window.  A thread moves TWO consecutive values of the flattened
+// [entry][component] list: one 16-byte store where both go to the same neighbour at a 16-byte aligned place (every
+// system-scope store into the uncached window is a fabric write of its own, whatever its width).
 __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
                                                    const int32_t *__restrict__ idx, int64_t ns, int nc,
                                                    const int64_t *__restrict__ send_off, int n_peers,
@@ -278,15 +297,26 @@ __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
                                                    const int64_t *__restrict__ r_off,
                                                    unsigned long long *const *__restrict__ r_hflag,
                                                    int parity, unsigned long long seq, unsigned *ticket) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < ns * nc) {
-    const int64_t k = i / nc;
-    const int c = (int)(i - k * nc);
-    int p = 0;
-    while (p + 1 < n_peers && k >= send_off[p + 1]) ++p;
-    const double v = x[(int64_t)idx[k] * nc + c];
-    double *dst = r_stage[p * 2 + parity] + (r_off[p] + (k - send_off[p])) * nc + c;
-    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, OX_SYS);
+  const int64_t e0 = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x), tot = ns * nc;
+  if (e0 < tot) {
+    double v[2];
+    double *dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t e = e0 + j < tot ? e0 + j : e0;  // (an odd total: the last thread's second value is its first again)
+      const int64_t k = e / nc;
+      const int c = (int)(e - k * nc);
+      int p = 0;
+      while (p + 1 < n_peers && k >= send_off[p + 1]) ++p;
+      v[j] = x[(int64_t)idx[k] * nc + c];
+      dst[j] = r_stage[p * 2 + parity] + (r_off[p] + (k - send_off[p])) * nc + c;
+    }
+    if (e0 + 1 < tot && dst[1] == dst[0] + 1 && (reinterpret_cast<size_t>(dst[0]) & 15) == 0) {
+      ox_store16_sys(dst[0], v[0], v[1]);
+    } else {
+      __hip_atomic_store(dst[0], v[0], __ATOMIC_RELAXED, OX_SYS);
+      if (e0 + 1 < tot) __hip_atomic_store(dst[1], v[1], __ATOMIC_RELAXED, OX_SYS);
+    }
   }
   // The payload stores are system-scope write-through stores into an uncached window: nothing of them sits in a cache.
   // Every storing wave waits for its stores to be acknowledged, the block barrier orders them in front of thread 0's
@@ -317,13 +347,18 @@ __global__ __launch_bounds__(256) void k_halo_pull(double *__restrict__ ghost, i
   if ((int)threadIdx.x < n_peers && !ox_p2p_wait(hflag + peers[threadIdx.x], seq, timeout_ticks, err)) failed = 1;
   __syncthreads();
   if (failed) return;  // a peer never delivered: leave the ghost block alone (the sticky flag fails the host call)
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-    ghost[i] = __hip_atomic_load(stage + i, __ATOMIC_RELAXED, OX_SYS);
+  const int64_t stride = (int64_t)gridDim.x * 256, n2 = n >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {  // (the staging area is 256-byte aligned)
+    double a, b;
+    ox_load16_sys(stage + 2 * i, a, b);
+    ghost[2 * i] = a;
+    ghost[2 * i + 1] = b;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) ghost[n - 1] = __hip_atomic_load(stage + n - 1, __ATOMIC_RELAXED, OX_SYS);
 }
 
 // all-reduce (sum) of n <= 15 doubles: thread r talks to rank r
-__global__ __launch_bounds__(64) void k_allreduce_p2p(double *buf, int n, ox_p2p_ar a) {
+__global__ __launch_bounds__(1024) void k_allreduce_p2p(double *buf, int n, ox_p2p_ar a) {
   __shared__ double stage[64][OX_P2P_MAXV + 1];
   __shared__ double vals[OX_P2P_MAXV + 1];
   if ((int)threadIdx.x < n) vals[threadIdx.x] = buf[threadIdx.x];
@@ -350,7 +385,7 @@ static int p2p_halo_push(const ox_dist *d, double *x, int ncomp, hipStream_t st)
   const unsigned long long seq = ++q->hseq;
   const int parity = (int)(seq & 1);
   const int64_t ns = d->send_off[d->n_peers];
-  const int64_t tot = ns * ncomp;
+  const int64_t tot = (ns * ncomp + 1) / 2;  // two values per thread
   const unsigned nblk = (unsigned)(tot > 0 ? (tot + 255) / 256 : 1);
   hipLaunchKernelGGL(k_halo_push, dim3(nblk), dim3(256), 0, st, x, d->send_idx, ns, ncomp, q->send_off_dev,
                      d->n_peers, q->r_stage, q->r_off, q->r_hflag, parity, seq, q->ticket);
@@ -381,7 +416,7 @@ static int p2p_halo_forward(const ox_dist *d, double *x, int ncomp, hipStream_t 
 }
 
 static int p2p_allreduce(const ox_dist *d, double *buf, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(64), 0, st, buf, n, ox_p2p_next_allreduce(d));
+  hipLaunchKernelGGL(k_allreduce_p2p, dim3(1), dim3(ox_p2p_ar_threads(d->nranks)), 0, st, buf, n, ox_p2p_next_allreduce(d));
   OX_LAUNCH_CHECK();
   return 0;
 }

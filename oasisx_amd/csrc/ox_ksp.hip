@@ -1080,7 +1080,7 @@ static int ksp_sync_point(KspState *S, double *partial, int nparts, int nv, doub
   if (ox_prof_on) ox_prof_start(OX_TAG_SYNC_POINT, st, nv + B.nv);
   if (dist->p2p && dist->nranks <= 64) {  // (one rank: the self-loop plans of tools/predict_scaling.py)
     int threads = ox_red_threads(nmax);
-    if (threads < 64) threads = 64;
+    if (threads < ox_p2p_ar_threads(dist->nranks)) threads = ox_p2p_ar_threads(dist->nranks);
     hipLaunchKernelGGL((k_ksp_scalar_p2p<PH>), dim3(1), dim3(threads), 0, st, S, partial, nparts, nv, P,
                        ox_p2p_next_allreduce(dist), B);
     if (ox_prof_on) ox_prof_stop(st);

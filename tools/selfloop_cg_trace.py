@@ -1,7 +1,7 @@
 """The partitioned pressure CG of rank 0 of a P-rank job at 128^3, alone on the GPU with self-loop plans
 (parallel.SelfLoopComm): 400 forced iterations, three times -- the command to put behind `rocprofv3 --kernel-trace --stats --`
 for the kernel budget of one partitioned iteration.
-    python tools/selfloop_cg_trace.py [p2p|rccl] [P]"""
+    python tools/selfloop_cg_trace.py [p2p|rccl] [P] [pressure|tentative|update]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,13 +20,17 @@ bcs = [[ox.DirichletBC(0.0, ox.LocatorMethod.GEOMETRICAL, on)] for _ in range(3)
 KSP = {"pc_type": "jacobi", "ksp_rtol": 1e-8, "ksp_atol": 1e-14, "ksp_max_it": 10000, "ksp_initial_guess_nonzero": True}
 S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, bcs_p=[],
                             solver_options={"tentative": dict(KSP, ksp_type="bcgs"), "pressure": dict(KSP, ksp_type="cg"), "scalar": dict(KSP, ksp_type="cg")})
-Q = S._Q
+what = sys.argv[3] if len(sys.argv) > 3 else "pressure"
+Q, A, nc, kind, its = {"pressure": (S._Q, S._Ap, 1, "cg", 400), "tentative": (S._Vi[0][0], S._A, 3, "bcgs", 40),
+                       "update": (S._Vi[0][0], S._M, 3, "cg", 60)}[what]
+if what == "tentative":
+    S.assemble_first(0.00125, 0.01)  # (A = M / dt + ... : a matrix BiCGStab can iterate on)
 n = Q.n_local
-B, X = FieldStorage(n, 1, "cuda"), FieldStorage(n, 1, "cuda")
-B.dev().copy_(torch.randn(n, 1, dtype=torch.float64, device="cuda"))
-ksp = KSPSolver(comm, {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 0.0, "ksp_atol": 0.0, "ksp_max_it": 400})
-ksp.setOperators(S._Ap)
+B, X = FieldStorage(n, nc, "cuda"), FieldStorage(n, nc, "cuda")
+B.dev().copy_(torch.randn(n, nc, dtype=torch.float64, device="cuda"))
+ksp = KSPSolver(comm, {"ksp_type": kind, "pc_type": "jacobi", "ksp_rtol": 0.0, "ksp_atol": 0.0, "ksp_max_it": its})
+ksp.setOperators(A)
 for rep in range(3):
     X.dev().zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
     ksp.solve_block(B, X); torch.cuda.synchronize()
-    print(f"{tr} P={P}: {1e6 * (time.perf_counter() - t0) / 400:.1f} us per iteration, rows {Q.n_owned} + {n - Q.n_owned} ghosts", flush=True)
+    print(f"{tr} P={P} {what}: {1e6 * (time.perf_counter() - t0) / its:.1f} us per iteration, {nc} column(s), rows {Q.n_owned} + {n - Q.n_owned} ghosts", flush=True)
