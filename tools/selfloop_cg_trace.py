@@ -1,7 +1,7 @@
 """The partitioned pressure CG of rank 0 of a P-rank job at 128^3, alone on the GPU with self-loop plans
 (parallel.SelfLoopComm): 400 forced iterations, three times -- the command to put behind `rocprofv3 --kernel-trace --stats --`
 for the kernel budget of one partitioned iteration.
-    python tools/selfloop_cg_trace.py [p2p|rccl] [P] [pressure|tentative|update]"""
+    python tools/selfloop_cg_trace.py [p2p|rccl] [P] [pressure|tentative|update|update1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,7 +22,7 @@ S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, b
                             solver_options={"tentative": dict(KSP, ksp_type="bcgs"), "pressure": dict(KSP, ksp_type="cg"), "scalar": dict(KSP, ksp_type="cg")})
 what = sys.argv[3] if len(sys.argv) > 3 else "pressure"
 Q, A, nc, kind, its = {"pressure": (S._Q, S._Ap, 1, "cg", 400), "tentative": (S._Vi[0][0], S._A, 3, "bcgs", 40),
-                       "update": (S._Vi[0][0], S._M, 3, "cg", 60)}[what]
+                       "update": (S._Vi[0][0], S._M, 3, "cg", 60), "update1": (S._Vi[0][0], S._M, 1, "cg", 120)}[what]
 if what == "tentative":
     S.assemble_first(0.00125, 0.01)  # (A = M / dt + ... : a matrix BiCGStab can iterate on)
 n = Q.n_local
