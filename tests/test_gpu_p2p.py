@@ -57,3 +57,52 @@ def test_absent_peer_times_out_and_is_reported(hip):
     assert lib.ox_dist_status(plan) != 0
     lib.ox_dist_destroy(plan)  # owns w0; w1 was never an IPC mapping
     lib.ox_p2p_window_free(w1)
+
+
+@pytest.mark.parametrize("nr,n", [(3, 15), (3, 5), (2, 1)])
+def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
+    """The in-block all-reduce of the window transport with ``nr`` ranks living in ONE process: every rank has its own
+    window, its plan maps all of them, the ``nr`` kernels run concurrently on ``nr`` streams and wait for each other's
+    flags.  Sixteen lanes per rank move the values; the sums are formed in rank order: the same bits on every rank, equal to
+    the host's left-to-right sum.  Twice, for both parities of the slots.  (At most three ranks: a process has four hardware
+    queues by default, one of them the null stream's; a fourth kernel waits behind one that waits for it.  Five ranks -- two waves of lanes -- run as
+    five processes in tests/test_gpu_dist_rehearsal.py.)"""
+    from oasisx_amd import _lib
+
+    lib = _lib.load()
+    ng = 0
+    nbytes = lib.ox_p2p_window_bytes(nr, ng)
+    wins_v, plans = [], []
+    h = C.create_string_buffer(64)
+    for r in range(nr):
+        w = C.c_void_p()
+        _lib.check(lib.ox_p2p_window_create(nbytes, C.byref(w), h), "window_create")
+        wins_v.append(w)
+    wins = (C.c_void_p * nr)(*[w.value for w in wins_v])
+    empty32, off1 = np.zeros(0, dtype=np.int32), np.zeros(1, dtype=np.int64)
+    idx = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for r in range(nr):
+        plan = C.c_void_p()
+        _lib.check(lib.ox_dist_create(None, r, nr, 0, empty32.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      off1.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(idx),
+                                      off1.ctypes.data_as(C.POINTER(C.c_int64)), 8, ng, C.byref(plan)), "ox_dist_create")
+        _lib.check(lib.ox_dist_enable_p2p(plan, wins_v[r], wins, off1.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          off1.ctypes.data_as(C.POINTER(C.c_int64)), 5.0), "ox_dist_enable_p2p")
+        plans.append(plan)
+    streams = [torch.cuda.Stream() for _ in range(nr)]
+    rng = np.random.default_rng(7)
+    for rnd in range(2):
+        vals = rng.standard_normal((nr, n)) * 10.0 ** rng.integers(-6, 6, size=(nr, n))  # (no sum order gives the same bits)
+        bufs = [torch.from_numpy(vals[r].copy()).cuda() for r in range(nr)]
+        torch.cuda.synchronize()
+        for r in range(nr):
+            _lib.check(lib.ox_allreduce_sum(plans[r], _lib.ptr(bufs[r]), n, C.c_void_p(streams[r].cuda_stream)), "ox_allreduce_sum")
+        torch.cuda.synchronize()
+        want = np.zeros(n)
+        for r in range(nr):
+            want = want + vals[r]
+        for r in range(nr):
+            _lib.check(lib.ox_dist_status(plans[r]), "ox_dist_status")
+            assert np.array_equal(bufs[r].cpu().numpy(), want), (rnd, r)
+    for r in range(nr):
+        lib.ox_dist_destroy(plans[r])  # (a plan owns its own window; the others were never IPC mappings)

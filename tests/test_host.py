@@ -296,3 +296,31 @@ def test_uniform_refinement_is_conforming(dim):
 def _delaunay_arrays(dim):
     m = M.create_delaunay_box(None, [[-1.0] * dim, [1.0] * dim], 4, device="cpu")
     return m.coords.numpy().copy(), m.cells.numpy().astype(np.int64)
+
+
+def test_scaling_model_reproduces_the_committed_prediction():
+    """tools/scaling_model.py (the step-time model of the predicted 1/2/4/8-GPU curves) applied to the per-rank costs and the
+    iteration profile stored in profiles/r05_predicted_scaling.json gives the ms/step stored beside them -- the model the
+    files were made with is the one in the tree -- and tools/predict_workloads.py runs on the CPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import scaling_model as sm
+    finally:
+        sys.path.pop(0)
+    d = json.loads(open(os.path.join(root, "profiles", "r05_predicted_scaling.json")).readline())
+    prof = d["iteration_profile_per_step"]
+    for P, e in d["P"].items():
+        ms = max(sum(sm.predict(m, prof, int(P)).values()) for m in e["ranks"].values())
+        assert abs(ms - e["ms_per_step"]) < 1e-9 * e["ms_per_step"], (P, ms, e["ms_per_step"])
+    assert d["label"].startswith("PREDICTION")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "predict_workloads.py")], capture_output=True, text=True,
+                         check=True).stdout
+    w = json.loads(out)
+    assert w["label"].startswith("PREDICTION") and len(w["workloads"]) == 2
+    for leg in w["workloads"].values():
+        assert abs(leg["model_error_vs_measured_P1"]) < 0.05 and set(leg["P"]) == {"1", "2", "4", "8"}
