@@ -106,3 +106,41 @@ def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
             assert np.array_equal(bufs[r].cpu().numpy(), want), (rnd, r)
     for r in range(nr):
         lib.ox_dist_destroy(plans[r])  # (a plan owns its own window; the others were never IPC mappings)
+
+
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_self_loop_plans_step_without_errors(hip, transport):
+    """``parallel.SelfLoopComm`` (tools/predict_scaling.py: one rank of a P-rank job alone on the device, its plans folded
+    onto itself): with both device transports the rank's spaces build, a whole time step runs through the partitioned
+    defaults of the Krylov solvers, and no bounded wait of the window transport runs out.  (The numbers are not the job's:
+    every ghost receives some owned value.  What is checked is that the code path the predictions time is alive.)"""
+    import oasisx_amd as ox
+    from oasisx_amd import _lib
+    from oasisx_amd import mesh as M
+    from oasisx_amd.parallel import SelfLoopComm
+
+    comm = SelfLoopComm(1, 3, transport)
+    mesh = M.create_unit_cube(comm, 6, 6, 6)
+    on = lambda x: np.isclose(x[0], 0.0) | np.isclose(x[0], 1.0)  # noqa: E731
+    bcs = [[ox.DirichletBC(0.0, ox.LocatorMethod.GEOMETRICAL, on)] for _ in range(3)]
+    ksp = {"pc_type": "jacobi", "ksp_rtol": 1e-6, "ksp_atol": 1e-12, "ksp_max_it": 50}
+    S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, bcs_p=[], body_force=(0.0, 0.0, -1.0),
+                                solver_options={"tentative": dict(ksp, ksp_type="bcgs"),
+                                                "pressure": dict(ksp, ksp_type="cg", ksp_error_if_not_converged=False),
+                                                "scalar": dict(ksp, ksp_type="cg")})
+    Vi, Q = S._Vi[0][0], S._Q
+    assert Vi.dist is not None and Vi.n_local > Vi.n_owned and comm.active == {2: "self-loop", 1: "self-loop"}
+    lib = _lib.load()
+    for _ in range(2):
+        S.assemble_first(0.01, 0.01)
+        S.velocity_tentative_assemble()
+        S.velocity_tentative_solve()
+        S.pressure_assemble(0.01)
+        S.pressure_solve()
+        S.velocity_update(0.01)
+    torch.cuda.synchronize()
+    for V in (Vi, Q):
+        _lib.check(lib.ox_dist_status(V.dist), "ox_dist_status")
+    t = comm.time_transports(Q, reps=5)
+    assert set(t) == {"self-loop"} and all(v > 0 for v in t["self-loop"].values())
+    assert np.isfinite(S._U1.rhost()).all()
