@@ -59,14 +59,11 @@ def test_absent_peer_times_out_and_is_reported(hip):
     lib.ox_p2p_window_free(w1)
 
 
-@pytest.mark.parametrize("nr,n", [(3, 15), (3, 5), (2, 1)])
-def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
+def _window_allreduce_ranks(nr, n):
     """The in-block all-reduce of the window transport with ``nr`` ranks living in ONE process: every rank has its own
     window, its plan maps all of them, the ``nr`` kernels run concurrently on ``nr`` streams and wait for each other's
     flags.  Sixteen lanes per rank move the values; the sums are formed in rank order: the same bits on every rank, equal to
-    the host's left-to-right sum.  Twice, for both parities of the slots.  (At most three ranks: a process has four hardware
-    queues by default, one of them the null stream's; a fourth kernel waits behind one that waits for it.  Five ranks -- two waves of lanes -- run as
-    five processes in tests/test_gpu_dist_rehearsal.py.)"""
+    the host's left-to-right sum.  Twice, for both parities of the slots."""
     from oasisx_amd import _lib
 
     lib = _lib.load()
@@ -106,6 +103,27 @@ def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
             assert np.array_equal(bufs[r].cpu().numpy(), want), (rnd, r)
     for r in range(nr):
         lib.ox_dist_destroy(plans[r])  # (a plan owns its own window; the others were never IPC mappings)
+
+
+@pytest.mark.parametrize("nr,n", [(3, 15), (3, 5), (2, 1)])
+def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
+    """(At most three ranks here: a process has four hardware queues by default, one of them the null stream's; a fourth
+    kernel would wait behind one that waits for it.)"""
+    _window_allreduce_ranks(nr, n)
+
+
+def test_window_allreduce_of_six_ranks_two_waves_of_lanes(hip):
+    """Six ranks -- 96 lanes, two waves, what an 8-GPU job runs -- need six kernels in flight: a child process with
+    GPU_MAX_HW_QUEUES=8 (the variable must be set before HIP starts)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_p2p as t; t._window_allreduce_ranks(6, 15); print('six ranks ok')"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "six ranks ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("transport", ["rccl", "p2p"])
