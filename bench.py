@@ -13,17 +13,22 @@ Other workloads: ``--workload beltrami`` (Ethier-Steinman, w != 0: SURVEY.md 8d'
 ``--workload cavity`` (BASELINE.json configs[3]: unit cube, lid u = (1,0,0) on z = 1, nu = 1e-3,
 dt = 1/N, from rest).
 
-Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
-  roofline      the pressure-Poisson CG SpMV: bytes the kernel really streams (its stored matrix +
-                vectors) / HIP-event time / 8 TB/s; `traffic` = HBM bytes per launch from two
-                rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same command, run as child
-                processes before the timed run; `csr_equivalent_gbs` = the metric's CSR-priced figure;
-                `past_cache` = the same kernel on the 256^3 pressure matrix (1.1 GB: beyond the 256 MB
-                Infinity Cache)
-  variants      the same timed steps with PETSc's default zero initial guess, and with the value
+Prints ONE compact JSON line (<= 8000 bytes) on rank 0's stdout -- the contract's keys, `roofline`, `cpu_baseline`,
+`headline_petsc_default` -- as soon as the headline, the counter passes and the CPU baseline exist, and NOTHING after it.
+The full record (kernel tables, Krylov series, variant legs, predictions) goes to ``gpurun_out/bench_full.json``
+(``--full-out``).  The heavy legs (Beltrami / cavity / Delaunay workloads with their host cross-checks, the one-core CPU
+repetition) run only with ``--extras``, after the line is out, and land in the side file.
+  roofline      the pressure-Poisson CG SpMV.  `traffic` = HBM bytes per launch from two rocprofv3 --pmc passes
+                (FETCH_SIZE x 2, WRITE_SIZE) of this same command, run as child processes before this process touches
+                the GPU; `avg_launch_us` = the same kernel's duration in a third child pass (--kernel-trace);
+                `achieved` = traffic / that time, `frac` = achieved / 8 TB/s.  `frac_algorithmic` prices the same
+                launch at SURVEY.md 8d's CSR bytes (12 B per nonzero); `hip_event` = the stored bytes over the HIP-event
+                time measured inside the timed region; `past_cache` = the same kernel on the 256^3 pressure matrix
+                (0.9 GB stored: beyond the 256 MB Infinity Cache), with its own counters from the same child passes
+  headline_petsc_default  the same timed steps with PETSc's default zero initial guess, and with the value
                 dictionaries off (what a mesh without bit-identical cells gets)
-  cpu_baseline  one step of the same workload on the host cores (oracle/ipcs_cpu.c), all cores and
-                one core, set up from the mesh definition alone
+  cpu_baseline  one step of the same workload on the host cores (oracle/ipcs_cpu.c), all cores (one core too with
+                --extras), set up from the mesh definition alone
 """
 from __future__ import annotations
 
@@ -70,7 +75,16 @@ def parse():
                     help="skip the 1-core repetition of the cpu_baseline step (about a minute at 128^3)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the variant legs (zero guess, dictionaries off) and the 256^3 past-cache SpMV")
+                    help="skip the cheap variant legs (steady state, zero guess, dictionaries off) and the 256^3 past-cache SpMV")
+    ap.add_argument("--extras", action="store_true",
+                    help="AFTER the JSON line is out: the Beltrami / cavity / refined-Delaunay workload legs with their host "
+                         "cross-checks and the one-core cpu_baseline repetition; results go to the --full-out side file only")
+    ap.add_argument("--full-out", default=None,
+                    help="path of the full record (default gpurun_out/bench_full.json under the repository root)")
+    ap.add_argument("--probe-transports", action="store_true",
+                    help="N > 1: AFTER the JSON line is out, time both device transports' halo exchanges (brings up the "
+                         "xGMI-window transport on a temporary plan); results go to stderr and the side file")
+    ap.add_argument("--pmc-leg", default=None, help=argparse.SUPPRESS)  # child of an --extras leg's counter passes
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cg-merged", default=None, choices=["true", "false"],
                     help="force the merged-reduction CG (OX_KSP_CG_MERGED: one synchronisation point, three kernels per "
@@ -124,15 +138,15 @@ def host_cores():
     return n
 
 
-# ---- HBM traffic of the pressure SpMV: rocprofv3 --pmc passes of this command ------------------
-def pmc_traffic(args, log):
-    """Run this same command (1 warm-up + 1 timed step, nothing else) twice under
-    ``rocprofv3 --pmc`` -- FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md's
-    HBM section prescribes -- and once under ``--kernel-trace``, and return the per-launch averages
-    for the pressure CG SpMV.
-    Must run BEFORE this process touches the GPU (the children are started as ordinary child
-    processes; nothing is exec'ed from a GPU-initialised process).  FETCH_SIZE counts 128-B requests
-    as 64 B on gfx950: a streamed read is 2 x FETCH_SIZE (same section)."""
+# ---- HBM traffic and kernel durations: rocprofv3 child passes of this command ---------------------
+def rocprof_passes(child_argv, log, label):
+    """Run ``bench.py --pmc-child <child_argv>`` (1 warm-up + 1 timed step, then -- box meshes -- the 256^3 pressure
+    SpMV) three times: under ``rocprofv3 --pmc FETCH_SIZE``, ``--pmc WRITE_SIZE`` (separate passes, as
+    MI355X_MICROARCH.md's HBM section prescribes) and ``--kernel-trace``.  Returns the per-(kernel, grid) averages of all
+    three and the child's own record (which names the pressure SpMV's kernel and grid).
+    Must run BEFORE this process touches the GPU (the children are ordinary child processes of a process that has
+    no HIP state; the interpreter after ``--`` is the real binary, so nothing re-execs behind the profiler's preloaded
+    library).  FETCH_SIZE counts 128-B requests as 64 B on gfx950: a streamed read is 2 x FETCH_SIZE (same section)."""
     import csv
     import glob
 
@@ -141,64 +155,99 @@ def pmc_traffic(args, log):
         return {"error": "rocprofv3 not found"}
     tmp = tempfile.mkdtemp(prefix="ox_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    res = {}
+    py = os.path.realpath(sys.executable)
+    table, child = {}, None
     t0 = time.perf_counter()
+
+    def key(name, grid):
+        return name.split("(")[0].replace(" ", ""), int(grid)
+
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "KERNEL_TRACE"):
             out = os.path.join(tmp, counter)
             mode = ["--kernel-trace"] if counter == "KERNEL_TRACE" else ["--pmc", counter]
-            cmd = [exe, *mode, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child", "-N", str(args.N), "--udeg", str(args.udeg), "--pdeg", str(args.pdeg),
-                   "--workload", args.workload, "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol)]
-            for flag, on in (("--zero-guess", args.zero_guess), ("--matrix-free", args.matrix_free),
-                             ("--no-dictionary", args.no_dictionary)):
-                if on:
-                    cmd.append(flag)
-            if args.window:
-                cmd += ["--window", str(args.window)]
-            if args.mesh != "box":
-                cmd += ["--mesh", args.mesh, "--refine", str(args.refine)]
+            cmd = [exe, *mode, "--output-format", "csv", "-d", out, "--", py, os.path.join(ROOT, "bench.py"), "--pmc-child",
+                   *child_argv]
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if p.returncode != 0:
-                return {"error": f"rocprofv3 --pmc {counter} pass failed (rc {p.returncode}): "
+                return {"error": f"rocprofv3 {counter} pass of {label} failed (rc {p.returncode}): "
                                  + p.stderr.decode(errors="replace")[-300:]}
-            child = None
             for line in p.stdout.decode(errors="replace").splitlines():
                 if line.startswith("{") and '"pmc_child"' in line:
                     child = json.loads(line)
             if child is None:
-                return {"error": f"rocprofv3 --pmc {counter}: the child printed no record"}
-            vals = []
-            if counter == "KERNEL_TRACE":  # the same kernel's duration as rocprofv3 sees it (no event bubbles)
+                return {"error": f"rocprofv3 {counter} pass of {label}: the child printed no record"}
+            acc = {}
+            if counter == "KERNEL_TRACE":
                 for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
-                        if (r["Kernel_Name"].replace(" ", "").startswith(child["kernel_prefix"])
-                                and int(r["Grid_Size_X"]) == child["grid_size"]):
-                            vals.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
-                if vals:
-                    res["KERNEL_TRACE"] = {"dispatches": len(vals), "avg_us": sum(vals) / len(vals)}
+                        acc.setdefault(key(r["Kernel_Name"], r["Grid_Size_X"]), []).append(
+                            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+                for k, v in acc.items():
+                    table.setdefault(k, {}).update({"dispatches": len(v), "avg_us": sum(v) / len(v)})
                 continue
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if (r["Counter_Name"] == counter and r["Kernel_Name"].replace(" ", "").startswith(child["kernel_prefix"])
-                            and int(r["Grid_Size"]) == child["grid_size"]):
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return {"error": f"rocprofv3 --pmc {counter}: no dispatch of {child['kernel_prefix']} grid {child['grid_size']}"}
-            res[counter] = {"dispatches": len(vals), "avg_KiB": sum(vals) / len(vals)}
-            res["kernel"] = child["kernel_prefix"]
+                    if r["Counter_Name"] == counter:
+                        acc.setdefault(key(r["Kernel_Name"], r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+            if not acc:
+                return {"error": f"rocprofv3 --pmc {counter} pass of {label}: no counter rows"}
+            for k, v in acc.items():
+                table.setdefault(k, {}).update({counter + "_KiB": sum(v) / len(v), "pmc_dispatches": len(v)})
     except Exception as e:  # the counters are a reported figure: never fail the bench for them
         return {"error": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    rd = 2.0 * res["FETCH_SIZE"]["avg_KiB"] * 1024.0
-    wr = res["WRITE_SIZE"]["avg_KiB"] * 1024.0
-    log(f"pmc passes: {time.perf_counter() - t0:.1f} s")
-    return {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel": res["kernel"],
-            "dispatches": res["FETCH_SIZE"]["dispatches"],
-            "rocprofv3_avg_launch_us": (res.get("KERNEL_TRACE") or {}).get("avg_us"),
-            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command "
-                      "(FETCH_SIZE x 2: gfx950 counts 128-B requests as 64 B)", "seconds": time.perf_counter() - t0}
+    for v in table.values():
+        if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+            v["read_bytes"] = 2.0 * v["FETCH_SIZE_KiB"] * 1024.0
+            v["write_bytes"] = v["WRITE_SIZE_KiB"] * 1024.0
+            v["traffic"] = v["read_bytes"] + v["write_bytes"]
+    log(f"rocprofv3 passes of {label}: {time.perf_counter() - t0:.1f} s")
+    return {"kernels": table, "child": child, "seconds": time.perf_counter() - t0,
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --kernel-trace child passes of this command "
+                      "(FETCH_SIZE x 2: gfx950 counts 128-B requests as 64 B)"}
+
+
+def child_argv_of(args):
+    """The flags that make a --pmc-child run the same workload as this command."""
+    av = ["-N", str(args.N), "--udeg", str(args.udeg), "--pdeg", str(args.pdeg), "--workload", args.workload,
+          "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol)]
+    for flag, on in (("--zero-guess", args.zero_guess), ("--matrix-free", args.matrix_free),
+                     ("--no-dictionary", args.no_dictionary), ("--no-extras", args.no_extras)):
+        if on:
+            av.append(flag)
+    if args.window:
+        av += ["--window", str(args.window)]
+    if args.spmv_windows:
+        av += ["--spmv-windows", args.spmv_windows]
+    if args.mesh != "box":
+        av += ["--mesh", args.mesh, "--refine", str(args.refine)]
+    return av
+
+
+def pick_kernel(passes, prefix, grid):
+    """The (kernel, grid) entry of a rocprof_passes() table whose demangled name starts with ``prefix``."""
+    if not passes or "error" in passes:
+        return None
+    for (name, g), v in passes["kernels"].items():
+        if g == grid and name.startswith(prefix) and "traffic" in v and "avg_us" in v:
+            return dict(v, kernel=name, grid=g)
+    return None
+
+
+def rocprof_kernel_table(passes, n=14):
+    """The n kernels of a rocprof_passes() table with the most time, with counter-derived fractions of the HBM peak."""
+    if not passes or "error" in passes:
+        return passes
+    rows = []
+    for (name, g), v in passes["kernels"].items():
+        if "avg_us" in v and "traffic" in v and ("k_spmv" in name or "k_assemble_rows" in name or "k_cg" in name or "k_bcgs" in name):
+            rows.append({"kernel": name.replace("void", "", 1), "grid": g, "dispatches": v["dispatches"], "avg_us": v["avg_us"],
+                         "traffic_MB": v["traffic"] / 1e6, "gbs": v["traffic"] / (1e3 * v["avg_us"]),
+                         "frac": v["traffic"] / (1e3 * v["avg_us"]) / HBM_PEAK_GBS})
+    rows.sort(key=lambda r: -r["avg_us"] * r["dispatches"])
+    return rows[:n]
 
 
 # ---- workloads ----------------------------------------------------------------------------------
@@ -249,6 +298,118 @@ def make_workload(name, N, np, torch):
         pres = None
         desc = "3D lid-driven cavity, unit cube, lid u = (1,0,0) on z = 1, Re = 1000, from rest"
     return {"nu": nu, "dt": dt, "box": box, "fns": fns, "p": pres, "desc": desc, "analytic": name != "cavity"}
+
+
+# ---- the line the driver reads -------------------------------------------------------------------
+COMPACT_LIMIT = 8000  # bytes: the whole line fits the driver's stdout tail
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+
+
+def _round(x, sig=6):
+    if isinstance(x, float):
+        return x if x == 0.0 or not math.isfinite(x) else float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, limit=COMPACT_LIMIT):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline`, `headline_petsc_default` and a few small
+    tables, from the full record -- a pure function of it (tests/test_bench_contract.py feeds it the committed full
+    records).  Optional blocks are dropped, last first, until the line is within ``limit`` bytes."""
+    out = {k: full[k] for k in CONTRACT_KEYS}
+    cfg = full["config"]
+    out["config"] = _pick(cfg, ("workload", "cells", "n_u_per_component", "n_p", "nnz_velocity", "nnz_pressure", "parallelism",
+                                "transport", "transport_check", "rccl_nranks", "launched_by", "krylov_sync_points_per_iteration"))
+    if cfg.get("ranks"):  # N > 1: every rank's share, without the communicator reports
+        out["config"]["ranks"] = [_pick(r, ("rank", "device", "cells", "velocity_rows", "velocity_ghosts", "pressure_rows",
+                                            "pressure_ghosts", "peers")) for r in cfg["ranks"]]
+    else:
+        out["config"]["ranks"] = None
+    r = full.get("roofline")
+    if r:
+        rr = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "basis", "avg_launch_us",
+                       "algorithmic_bytes_per_launch", "achieved_algorithmic", "frac_algorithmic", "frac_algorithmic_note",
+                       "stored_bytes_per_launch", "traffic_over_stored", "hip_event", "counters_error"))
+        if isinstance(r.get("past_cache"), dict):
+            rr["past_cache"] = _pick(r["past_cache"], ("workload", "achieved", "frac", "traffic", "basis", "avg_launch_us",
+                                                       "stored_bytes_per_launch", "algorithmic_bytes_per_launch",
+                                                       "frac_algorithmic", "hip_event", "error"))
+        out["roofline"] = rr
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        cc = _pick(c, ("value", "unit", "cores", "kind", "sample", "cpu_model", "seconds", "setup_seconds", "gpu_over_cpu",
+                       "gpu_vs_cpu_rel_l2_u", "gpu_vs_cpu_rel_l2_p", "gpu_vs_cpu_max_abs_u", "krylov_iterations", "error"))
+        if isinstance(c.get("one_core"), dict):
+            cc["one_core"] = _pick(c["one_core"], ("value", "seconds"))
+        if isinstance(cc.get("sample"), str) and len(cc["sample"]) > 300:
+            cc["sample"] = cc["sample"][:297] + "..."
+        out["cpu_baseline"] = cc
+    else:
+        out["cpu_baseline"] = None
+    optional = []  # (key, value): dropped from the END of this list first when the line is too long
+    if full.get("headline_petsc_default"):
+        optional.append(("headline_petsc_default", full["headline_petsc_default"]))
+    for k in ("cg_spmv_gbs", "krylov_iterations_per_step", "phase_ms_per_step", "phase_ms_per_step_max_over_ranks"):
+        if full.get(k) is not None:
+            optional.append((k, full[k]))
+    if full.get("pressure_cg_iteration"):
+        optional.append(("pressure_cg_iteration", _pick(full["pressure_cg_iteration"], (
+            "us", "bytes_moved", "stored_gbs", "frac_stored", "kernels_per_iteration", "recurrences"))))
+    if full.get("accuracy"):
+        optional.append(("accuracy", full["accuracy"]))
+    if full.get("steady_state"):
+        optional.append(("steady_state", _pick(full["steady_state"], ("value", "ms_per_step", "steps", "first_timed_step",
+                                                                      "krylov_iterations_per_step"))))
+    for k in ("setup_s", "hbm_gib", "full_record"):
+        if full.get(k) is not None:
+            optional.append((k, full[k]))
+    if full.get("kernels"):  # velocity-side mat-vecs and the assembly, four numbers each
+        optional.append(("kernels", {k: _pick(v, ("launches", "avg_us", "stored_gbs", "frac_stored"))
+                                     for k, v in full["kernels"].items()}))
+    if full.get("kernels_rocprofv3") and isinstance(full["kernels_rocprofv3"], list):
+        optional.append(("kernels_rocprofv3", [_pick(k, ("kernel", "avg_us", "traffic_MB", "frac"))
+                                               for k in full["kernels_rocprofv3"][:8]]))
+    if full.get("krylov_iterations_series"):
+        optional.append(("krylov_iterations_series", full["krylov_iterations_series"]))
+
+    def render(n):
+        d = dict(out)
+        for k, v in optional[:n]:
+            d[k] = v
+        d = {k: (v if k in ("value", "ms_per_step") else _round(v)) for k, v in d.items()}
+        return json.dumps(d, separators=(",", ":"))
+
+    n = len(optional)
+    line = render(n)
+    while len(line.encode()) > limit and n > 0:
+        n -= 1
+        line = render(n)
+    if len(line.encode()) > limit:  # (cannot happen with the key sets above; a bound is a bound)
+        raise RuntimeError(f"bench.py: the contract line is {len(line.encode())} bytes (> {limit})")
+    return line
+
+
+def write_full(path, full):
+    """The full record as one JSON line in the side file (rewritten whole: a later leg replaces the earlier copy)."""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path + ".tmp", "w") as f:
+            f.write(json.dumps(full) + "\n")
+        os.replace(path + ".tmp", path)
+        return path
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e!r}", file=sys.stderr, flush=True)
+        return None
 
 
 def predicted_line(args, world):
@@ -303,10 +464,18 @@ def main():
         if args.verbose and rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
-    # the PMC child passes come first: this process has not touched the GPU yet
-    traffic = None
+    # the rocprofv3 child passes come first: this process has not touched the GPU yet
+    passes = leg_passes = None
+    DELAUNAY_LEG = (32, 2)  # --extras: the unstructured leg's mesh (jittered 33^3 lattice, refined twice: 14.0 M tets)
+    extras_legs = (world == 1 and args.extras and not args.pmc_child and args.workload == "tg" and args.mesh == "box")
     if world == 1 and not args.no_pmc and not args.pmc_child:
-        traffic = pmc_traffic(args, log)
+        passes = rocprof_passes(child_argv_of(args), log, "the headline workload")
+        if extras_legs and args.udeg == 2 and args.N >= 96:
+            leg_passes = rocprof_passes(["-N", str(DELAUNAY_LEG[0]), "--mesh", "delaunay", "--refine", str(DELAUNAY_LEG[1]),
+                                         "--workload", "beltrami", "--udeg", str(args.udeg), "--pdeg", str(args.pdeg),
+                                         "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol), "--no-extras"],
+                                        log, "the unstructured leg")
+    full_path = args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
 
     os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))  # cpu_baseline leg (oracle/ipcs_cpu.c)
     import numpy as np
@@ -467,8 +636,12 @@ def main():
                "workload": f"{W2['desc']}, {mesh_txt} P{args.udeg}-P{args.pdeg}, nu={W2['nu']}, dt={W2['dt']:g}",
                "krylov_iterations_per_step": mean_iterations(its2), "krylov_iterations_series": iteration_series(its2),
                "setup_s": t_set, "mesh_generation_s": t_mesh,
-               "kernels": {k: {a: b for a, b in v.items() if a in ("launches", "avg_us", "bytes_moved", "gbs", "frac_of_hbm_peak")}
+               # stored bytes over the HIP-event time; the counter-derived fractions of the same workload are in
+               # kernels_rocprofv3 (unstructured leg: child passes run before this process touched the GPU)
+               "kernels": {k: {a: b for a, b in v.items() if a in ("launches", "avg_us", "bytes_moved", "stored_gbs", "frac_stored")}
                            for k, v in leg_kernels.items()}}
+        if delaunay is not None and leg_passes is not None:
+            res["kernels_rocprofv3"] = rocprof_kernel_table(leg_passes)
         if delaunay is not None:
             P2_ = S2._M.pattern
             res["storage"] = {"nnz_velocity": P2_.nnz, "slots": P2_.size, "padding": P2_.size / P2_.nnz - 1.0,
@@ -650,7 +823,7 @@ def main():
             vec = 8 * nq * 8 + 2 * nq * (1 if dcode else 8)
         spmv = stored_bytes(S._Ap)
         return {"us": us, "bytes_moved": int(spmv + vec), "spmv_bytes": int(spmv), "vector_bytes": int(vec),
-                "gbs": (spmv + vec) / (1e3 * us), "frac_of_hbm_peak": (spmv + vec) / (1e3 * us) / HBM_PEAK_GBS,
+                "stored_gbs": (spmv + vec) / (1e3 * us), "frac_stored": (spmv + vec) / (1e3 * us) / HBM_PEAK_GBS,
                 "kernels_per_iteration": int(S._solver_p._cg_kernels_per_iteration()),
                 "recurrences": "merged-reduction CG (OX_KSP_CG_MERGED)" if cg_merged else
                 ("standard CG, both synchronisation points folded into the update kernels (k_cg_update1f / 2f)"
@@ -700,50 +873,67 @@ def main():
                 k = {"launches": cnt, "avg_us": 1e3 * ms / cnt, "total_ms": ms}
                 if csr:
                     us = 1e3 * ms / cnt
-                    k.update({"bytes_moved": moved, "gbs": moved / (1e3 * us),
-                              "frac_of_hbm_peak": moved / (1e3 * us) / HBM_PEAK_GBS,
+                    # stored bytes (what the kernel's streams hold) over the HIP-event time: the counter-derived
+                    # fractions are in kernels_rocprofv3 / roofline
+                    k.update({"bytes_moved": moved, "stored_gbs": moved / (1e3 * us),
+                              "frac_stored": moved / (1e3 * us) / HBM_PEAK_GBS,
                               "csr_bytes": csr, "csr_equivalent_gbs": csr / (1e3 * us)})
                 kernels[name] = k
         return kernels
 
     kernels = kernel_table()
     cg = kernels.get("pressure_cg_spmv")
+
+    def spmv_kernel_id(A, epi):
+        """Demangled-name prefix (spaces removed) and grid size of the one-column SpMV launch of ``A`` (how the
+        rocprofv3 tables of the child passes are searched)."""
+        P = A.pattern
+        var = 7 if A.vcode is not None else (3 if P.frac16 > 0 else 1)
+        grid = 256 * ((((P.n_slices + 3) // 4) + 7) // 8 * 8)
+        return (f"voidk_spmv_ps<1,{epi}>" if A.ps_code is not None else f"voidk_spmv<1,{epi},{var}>"), grid
+
+    def roofline_of(stored, csr, ev_us, ev_launches, counters):
+        """The fractions of one kernel: counter-derived where the child passes found it (HBM traffic / rocprofv3 kernel
+        time), else the stored bytes over the HIP-event time -- `basis` says which."""
+        r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "stored_bytes_per_launch": stored,
+             "algorithmic_bytes_per_launch": csr,
+             "hip_event": {"avg_launch_us": ev_us, "launches": ev_launches, "achieved_stored": stored / (1e3 * ev_us),
+                           "frac_stored": stored / (1e3 * ev_us) / HBM_PEAK_GBS}}
+        if counters is not None:
+            us = counters["avg_us"]
+            r.update({"achieved": counters["traffic"] / (1e3 * us), "traffic": counters["traffic"], "avg_launch_us": us,
+                      "traffic_detail": _pick(counters, ("kernel", "grid", "dispatches", "pmc_dispatches", "read_bytes", "write_bytes")),
+                      "traffic_over_stored": counters["traffic"] / stored,
+                      "basis": "HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate child passes of "
+                               "this command) / the kernel's rocprofv3 --kernel-trace duration (third child pass)"})
+        else:
+            us = ev_us
+            r.update({"achieved": stored / (1e3 * us), "traffic": None, "avg_launch_us": us,
+                      "basis": "NO COUNTERS in this run: bytes the kernel's storage holds (matrix streams + x + y) / HIP-event time"})
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["achieved_algorithmic"] = csr / (1e3 * us)
+        r["frac_algorithmic"] = csr / (1e3 * us) / HBM_PEAK_GBS
+        return r
+
     roofline = None
     if cg:
         epi_name = "OX_EPI_CG_M2" if cg_merged else "OX_EPI_DOT"
+        kid = spmv_kernel_id(S._Ap, 5 if cg_merged else 1)
         roofline = {"kernel": (f"k_spmv_ps<1,{epi_name}> (pressure-Poisson CG SpMV, SELL-64 pair-slot stream, f64)"
                                if S._Ap.ps_code is not None else
-                               f"k_spmv<1,{epi_name},*> (pressure-Poisson CG SpMV, SELL-64, f64)"), "bound": "hbm",
-                    # bytes the kernel really streams per launch (its stored matrix + x + y) / HIP-event time
-                    "achieved": cg["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cg["frac_of_hbm_peak"],
-                    "traffic": None, "traffic_detail": None,
-                    "bytes_moved_per_launch": cg["bytes_moved"], "avg_launch_us": cg["avg_us"], "launches": cg["launches"],
-                    "csr_bytes_per_launch": b_p, "csr_equivalent_gbs": cg["csr_equivalent_gbs"],
-                    "cols16_fraction": Pp.frac16, "value_dictionary_entries": int(S._Ap._struct.n_dict),
-                    "pair_slots_per_row": (S._Ap.ps_code.numel() / 64 / max(Pp.n_slices, 1)) if S._Ap.ps_code is not None else None,
-                    "address_unit_note": "on compressed storage this kernel is bound by vector-memory instructions per "
-                                         "slice (16-20 cycles of the address unit each, any width), not by bytes: "
-                                         "tools/ubench/dispatch_rate.hip, DESIGN.md section 3.  Diagnostic builds at 128^3 "
-                                         "(profiles/r03_spmv_velocity_experiments.txt): 18.7 us of the 29.9 remain with every "
-                                         "gather and code load an L1 hit (instruction issue), the 80 MB code stream adds ~10 us "
-                                         "that do not overlap, the gather misses 2.5 us; an LDS-window form with a fifth of the "
-                                         "gathers is no faster",
-                    "note": "achieved = stored bytes (lossless 16-bit column codes and, with a dictionary, 1-byte value "
-                            "codes; f64 arithmetic) / time; csr_equivalent_gbs prices the same launch at the metric's "
-                            "12 B per nonzero and is NOT a fraction of anything.  At 128^3 the stored matrix fits the "
-                            "256 MB Infinity Cache between CG iterations: see past_cache for the HBM-resident size"}
-        if traffic is not None:
-            if "error" in traffic:
-                roofline["traffic_detail"] = traffic
-            else:
-                roofline["traffic"] = traffic["bytes_per_launch"]
-                roofline["traffic_detail"] = traffic
-                if traffic.get("rocprofv3_avg_launch_us"):
-                    # the HIP-event figure above contains the bubbles of its own event pair (~3 us on a 30 us
-                    # kernel); rocprofv3's kernel trace of the same command (a third child pass) does not
-                    us_r = traffic["rocprofv3_avg_launch_us"]
-                    roofline["rocprofv3"] = {"avg_launch_us": us_r, "achieved": cg["bytes_moved"] / (1e3 * us_r),
-                                             "frac": cg["bytes_moved"] / (1e3 * us_r) / HBM_PEAK_GBS}
+                               f"k_spmv<1,{epi_name},*> (pressure-Poisson CG SpMV, SELL-64, f64)")}
+        roofline.update(roofline_of(cg["bytes_moved"], b_p, cg["avg_us"], cg["launches"], pick_kernel(passes, *kid)))
+        if passes is not None and "error" in passes:
+            roofline["counters_error"] = passes["error"]
+        roofline.update({
+            "frac_algorithmic_note": "SURVEY.md 8d's CSR bytes (12 B per nonzero) over the same time; above 1 where the matrix is "
+                                     "stored smaller than CSR (16-bit column codes, 1-byte value codes: lossless, f64 arithmetic) "
+                                     "and fits the 256 MB Infinity Cache between CG iterations -- not a fraction of a roofline; "
+                                     "past_cache is the HBM-resident size",
+            "cols16_fraction": Pp.frac16, "value_dictionary_entries": int(S._Ap._struct.n_dict),
+            "pair_slots_per_row": (S._Ap.ps_code.numel() / 64 / max(Pp.n_slices, 1)) if S._Ap.ps_code is not None else None,
+            "address_unit_note": "on compressed storage this kernel is bound by dependent vector-memory rounds per slice, not "
+                                 "by bytes: tools/ubench/dispatch_rate.hip, DESIGN.md sections 3 and 9"})
 
     # ---- variant legs on the same solver (reported beside the headline, never instead of it) -------
     variants = {}
@@ -787,9 +977,12 @@ def main():
                 "same arithmetic, same results")
 
     # ---- the metric's kernel past the Infinity Cache: 256^3 pressure matrix -----------------------
-    if world == 1 and not args.no_extras and not args.pmc_child and roofline is not None:
+    # (also in the --pmc-child runs, so that the counter passes hold this launch too)
+    past_id = None
+    if world == 1 and not args.no_extras and args.mesh == "box" and (roofline is not None or args.pmc_child):
         try:
             t0 = time.perf_counter()
+            reps, warm = (20, 5) if args.pmc_child else (200, 20)
             m2 = M.create_box(None, [p0, p1], [256, 256, 256])
             bc2 = [[ox.DirichletBC(0.0, ox.LocatorMethod.GEOMETRICAL, on_boundary)] for _ in range(3)]
             S2 = ox.FractionalStep_AB_CN(m2, ("Lagrange", 1), ("Lagrange", 1), bcs_u=bc2, bcs_p=[],
@@ -798,44 +991,41 @@ def main():
             P2 = A2.pattern
             x2 = (torch.sin(torch.arange(P2.n_cols, device="cuda", dtype=torch.float64) * 1e-3) + 1).reshape(-1, 1)
             y2 = torch.zeros_like(x2)
-            for _ in range(20):
+            for _ in range(warm):
                 A2.mult(x2, y2, 1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(200):
+            for _ in range(reps):
                 A2.mult(x2, y2, 1)
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / 200
-            sb2 = stored_bytes(A2)
-            csr2 = spmv_bytes(P2.nnz, P2.n_rows, P2.n_cols)
-            roofline["past_cache"] = {
-                "workload": "pressure Laplacian of the 256^3 box mesh (P1, 16 974 593 rows, SURVEY.md 8 C5), "
-                            "x_j = sin(j*1e-3)+1, 200 launches after 20 warm-up (SURVEY.md 8d), plain y = A x",
-                "nnz": P2.nnz, "bytes_moved_per_launch": sb2, "avg_launch_us": us,
-                "achieved": sb2 / (1e3 * us), "frac": sb2 / (1e3 * us) / HBM_PEAK_GBS, "unit": "GB/s",
-                "csr_bytes_per_launch": csr2, "csr_equivalent_gbs": csr2 / (1e3 * us),
-                "value_dictionary_entries": int(A2._struct.n_dict), "seconds": time.perf_counter() - t0}
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            past_id = spmv_kernel_id(A2, 0)
+            if roofline is not None:
+                pc = {"workload": "pressure Laplacian of the 256^3 box mesh (P1, 16 974 593 rows, SURVEY.md 8 C5), "
+                                  "x_j = sin(j*1e-3)+1, 200 launches after 20 warm-up (SURVEY.md 8d), plain y = A x",
+                      "nnz": P2.nnz}
+                pc.update(roofline_of(stored_bytes(A2), spmv_bytes(P2.nnz, P2.n_rows, P2.n_cols), us, reps,
+                                      pick_kernel(passes, *past_id)))
+                pc.update({"value_dictionary_entries": int(A2._struct.n_dict), "seconds": time.perf_counter() - t0})
+                roofline["past_cache"] = pc
             del S2, A2, x2, y2, m2
             torch.cuda.empty_cache()
         except Exception as e:
-            roofline["past_cache"] = {"error": repr(e)}
+            if roofline is not None:
+                roofline["past_cache"] = {"error": repr(e)}
 
-    if args.pmc_child:  # what the parent needs to find this run's pressure SpMV in the counter CSV
-        var = 7 if S._Ap.vcode is not None else (3 if Pp.frac16 > 0 else 1)
-        grid = 256 * ((((Pp.n_slices + 3) // 4) + 7) // 8 * 8)
-        epi = 5 if cg_merged else 1
-        prefix = f"voidk_spmv_ps<1,{epi}>" if S._Ap.ps_code is not None else f"voidk_spmv<1,{epi},{var}>"
-        print(json.dumps({"pmc_child": True, "kernel_prefix": prefix, "grid_size": grid}), flush=True)
+    if args.pmc_child:  # what the parent needs to find this run's pressure SpMV in the rocprofv3 tables
+        prefix, grid = spmv_kernel_id(S._Ap, 5 if cg_merged else 1)
+        print(json.dumps({"pmc_child": True, "kernel_prefix": prefix, "grid_size": grid,
+                          "past_cache": list(past_id) if past_id else None}), flush=True)
         return
 
-    transport_check = transport_us = None
-    if world > 1:  # the transports once more after the timed steps: every ghost dof must still get its owner's value
+    transport_check = None
+    if world > 1:  # the transport once more after the timed steps: every ghost dof must still get its owner's value
         S._Vi[0][0].check_halo()
         S._Q.check_halo()
         transport_check = "halo self-test passed after the timed steps"
-        # both device transports' exchange times, measured here (collective)
-        transport_us = {"velocity_space": comm.time_transports(S._Vi[0][0]), "pressure_space": comm.time_transports(S._Q)}
     nnz_glob = [Pu.nnz, Pp.nnz]
     per_rank = None
     phase_ms_max = None
@@ -859,6 +1049,7 @@ def main():
                 "peers": [int(p_) for p_ in (Vu_.halo["peers"] if Vu_.halo is not None else [])], "comm": comm.info()}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
+    out = None
     if rank == 0:
         mean_its = mean_iterations(its)
         short = {"tg": "Taylor-Green", "beltrami": "Beltrami (Ethier-Steinman)", "cavity": "lid-driven cavity"}[args.workload]
@@ -882,7 +1073,7 @@ def main():
                                      "/".join(sorted(set(comm.active.values()))) or "none")
                        + ("" if args.backend == "nccl" or world == 1 else " (rehearsal: torch.distributed over gloo)")
                        if world > 1 else None,
-                       "transport_check": transport_check, "transport_exchange_us": transport_us,
+                       "transport_check": transport_check, "transport_exchange_us": None,
                        # N > 1: the rank count the library's RCCL communicator reports (ncclCommCount; None in a gloo
                        # rehearsal, which has none), and every rank's rows / ghosts / peers
                        "rccl_nranks": (None if world == 1 or not per_rank[0]["comm"]["rccl"] else
@@ -897,7 +1088,7 @@ def main():
                            {"pressure cg": 1 if (cg_merged or S._solver_p._method()[0] == _lib.KSP_CG_SINGLE) else 2,
                             "velocity bcgs": 2 if S._solver_u._method()[0] == _lib.KSP_BCGS_MERGED else 3,
                             "update cg": 1 if S._solver_c._method()[0] == _lib.KSP_CG_SINGLE else 2})},
-            "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # bytes really moved / time (see roofline)
+            "cg_spmv_gbs": roofline["achieved"] if roofline else None,  # the roofline's figure (see roofline.basis)
             "roofline": roofline,
             "krylov_iterations_per_step": mean_its,
             "krylov_iterations_series": iteration_series(its),  # per timed step (the warm start's transient shows here)
@@ -915,11 +1106,14 @@ def main():
             # whole Jacobi-CG iteration of the pressure solve (SpMV + vector kernels + scalar kernels)
             "pressure_cg_iteration": piter_line,
             "accuracy": {"max_nodal_error_u_vs_analytic": err_u, "max_abs_u": umax, "t_end": clock["t"]},
+            # HIP-event table (stored bytes / event time) and the counter-derived table of the child passes
             "kernels": kernels,
+            "kernels_rocprofv3": rocprof_kernel_table(passes),
             "variants": variants,
             "setup_s": t_setup,
             "hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
             "cpu_baseline": None,  # timed on rank 0 at N = 1 only (below)
+            "full_record": os.path.relpath(full_path, ROOT),
         }
         if variants:  # PETSc's own defaults in one place: zero initial guess, no value dictionaries
             zg = variants.get("initial_guess_nonzero=False")
@@ -930,23 +1124,56 @@ def main():
                 "zero_initial_guess_steps_per_s": zg["value"] if zg else None,
                 "no_value_dictionary_steps_per_s": (variants.get("value_dictionary=False") or {}).get("value"),
                 "headline_steps_per_s": out["value"]}
+        ksp_cpu = {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess}
+
+        def host_fields(X, t):
+            return np.stack([np.asarray(f(X, t), dtype=np.float64) for f in fns])
+
+        mesh_def = ((p0, p1, [N, N, N]) if args.mesh == "box" else
+                    {"coords": mesh.coords.cpu().numpy(), "cells": mesh.cells.cpu().numpy(), "lo": p0, "hi": p1})
         if not args.no_cpu and world == 1:
             try:
                 from oracle.cpu_baseline import run_cpu_baseline
 
-                ksp_cpu = {"rtol": args.rtol, "atol": 1e-14, "max_it": 10000, "guess": not args.zero_guess}
-                out["cpu_baseline"] = run_cpu_baseline(
-                    S, clock, dt, nu, ksp_cpu, lambda X, t: np.stack([np.asarray(f(X, t), dtype=np.float64) for f in fns]),
-                    gpu_step=step,
-                    mesh_def=((p0, p1, [N, N, N]) if args.mesh == "box" else
-                              {"coords": mesh.coords.cpu().numpy(), "cells": mesh.cells.cpu().numpy(), "lo": p0, "hi": p1}),
-                    threads_1=not args.no_cpu_one_core, reuse_setup=True)
+                out["cpu_baseline"] = run_cpu_baseline(S, clock, dt, nu, ksp_cpu, host_fields, gpu_step=step, mesh_def=mesh_def,
+                                                       threads_1=False, reuse_setup=True)
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
-        # ---- the other BASELINE workloads on the same mesh size, driver-timed beside the headline --------------
+        # ---- THE line: the full record to the side file first, then the one stdout line, then nothing on stdout ----
+        write_full(full_path, out)
+        sys.stderr.flush()
+        print(compact_line(out), flush=True)
+
+    # ================= everything below runs AFTER the line is out; results go to stderr and the side file =================
+    if world > 1 and args.probe_transports:
+        # both device transports' exchange times (collective; brings up the xGMI-window transport on a temporary plan)
+        try:
+            transport_us = {"velocity_space": comm.time_transports(S._Vi[0][0]), "pressure_space": comm.time_transports(S._Q)}
+        except Exception as e:
+            transport_us = {"error": repr(e)}
+        if rank == 0:
+            out["config"]["transport_exchange_us"] = transport_us
+            print("[bench] transport_exchange_us " + json.dumps(transport_us), file=sys.stderr, flush=True)
+            write_full(full_path, out)
+    if rank == 0 and world == 1 and args.extras:
+        def note(msg):
+            print("[bench] extras: " + msg, file=sys.stderr, flush=True)
+
+        if not args.no_cpu and isinstance(out["cpu_baseline"], dict) and "value" in out["cpu_baseline"]:
+            try:  # the same host step on ONE core (about a minute at 128^3)
+                from oracle.cpu_baseline import run_cpu_baseline
+
+                one = run_cpu_baseline(S, clock, dt, nu, ksp_cpu, host_fields, gpu_step=step, mesh_def=mesh_def,
+                                       threads_1=True, scipy_check=False, reuse_setup=True)
+                out["cpu_baseline"]["one_core"] = one.get("one_core")
+            except Exception as e:
+                out["cpu_baseline"]["one_core"] = {"error": repr(e)}
+            write_full(full_path, out)
+            note("one-core cpu_baseline done")
+        # the other BASELINE workloads on the same mesh size beside the headline
         # (Beltrami: w != 0, no round-off right-hand side; cavity: BASELINE.json configs[3]'s 1-GPU line)
-        if world == 1 and not args.no_extras and args.workload == "tg" and args.mesh == "box":
+        if extras_legs:
             import gc
 
             del S  # (the phase wrappers hold it in a cycle: collect before the next 49 GiB solver is built)
@@ -958,16 +1185,19 @@ def main():
                     out["variants"]["workload=" + wname] = workload_leg(wname)
                 except Exception as e:
                     out["variants"]["workload=" + wname] = {"error": repr(e)}
+                write_full(full_path, out)
+                note("workload=" + wname + " done")
             # what an UNSTRUCTURED mesh of the metric's size gets (north_star: "the unstructured mesh"): same fields,
             # same Krylov settings, a refined Delaunay mesh of 18.9 M P2 dofs per component
             if args.udeg == 2 and N >= 96:
                 try:
                     # (Beltrami: all three components live -- on this mesh the z-extruded field's w column, a round-off
                     # right-hand side, would add ~180 narrowed BiCGStab iterations per step to both sides of the check)
-                    out["variants"]["mesh=delaunay"] = workload_leg("beltrami", delaunay=(32, 2))
+                    out["variants"]["mesh=delaunay"] = workload_leg("beltrami", delaunay=DELAUNAY_LEG)
                 except Exception as e:
                     out["variants"]["mesh=delaunay"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+                write_full(full_path, out)
+                note("mesh=delaunay done")
     if world > 1:
         import torch.distributed as dist
 
