@@ -121,6 +121,9 @@ def main():
     ap.add_argument("-N", type=int, default=5)
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--split", default="slabs", choices=["slabs", "octants"],
+                    help="slabs along the last axis (equal counts), or -- 8 parts in 3-D -- the 2 x 2 x 2 octants of the box "
+                         "(what recursive coordinate bisection gives an 8-GPU job: peers that share a face, one edge line, one vertex)")
     args = ap.parse_args()
     L, lib = load_binding()
     dev = Dev(L, lib)
@@ -156,6 +159,10 @@ def main():
     order = np.lexsort((cen[:, 1], cen[:, 0], cen[:, d - 1]))  # slabs along the last axis, equal counts
     cell_rank = np.empty(nc, dtype=np.int64)
     cell_rank[order] = np.arange(nc) * P // nc
+    if args.split == "octants":
+        if d != 3 or P != 8:
+            raise SystemExit("--split octants: 3-D, 8 parts")
+        cell_rank = (4 * (cen[:, 2] > 0) + 2 * (cen[:, 1] > 0) + (cen[:, 0] > 0)).astype(np.int64)
     vown = np.full(nv, P, dtype=np.int64)
     np.minimum.at(vown, cells.ravel(), np.repeat(cell_rank, d + 1))
     pairs = list(itertools.combinations(range(d + 1), 2))

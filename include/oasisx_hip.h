@@ -15,11 +15,13 @@
  *     stream-ordered and only ox_ksp_solve blocks (it returns host-visible results);
  *   - all floating point data is float64, all indices int32, offsets int64;
  *   - multi-component vectors are interleaved: v[row*ncomp + comp];
- *   - process model: ONE process per GPU and ONE call at a time per process.  The library keeps
- *     per-process scratch (the reduction scratch of ox_dot / ox_remove_mean, the pinned copy of the
- *     Krylov state of ox_ksp_solve, the profiler's event
- *     list): two host threads calling in concurrently, or two solves in flight on different streams, would
- *     share it.  This is the reference's model too (one PETSc solve at a time per MPI rank);
+ *   - process model: ONE process per GPU and one call at a time per HOST THREAD.  The library keeps
+ *     per-thread scratch (the reduction scratch of ox_dot / ox_remove_mean, the pinned copy of the
+ *     Krylov state of ox_ksp_solve, the Jacobi-diagonal hook of the merged CG epilogue): two solves in flight from
+ *     ONE thread on different streams would share it; host threads that each drive their own handles (e.g. the ranks
+ *     of a partitioned job rehearsed inside one process, tests/test_gpu_threads_rehearsal.py) do not.  The profiler's
+ *     event list (ox_profile_*) is per process: profile from one thread.  The product runs one rank per process, the
+ *     reference's model (one PETSc solve at a time per MPI rank);
  *   - an x handed to ox_spmv / ox_ksp_solve on a matrix with a pair-slot stream (ps_*) must be FINITE in
  *     every owned and ghost column: a slot multiplies two adjacent columns and its second half may be the
  *     code of 0.0 (0 * Inf = NaN where the entry streams would not touch that column; -0.0 sums can come

@@ -1037,12 +1037,14 @@ extern "C" size_t ox_ksp_work_bytes_for(const ox_sell *A, int ncomp, int ksp_typ
   return ksp_layout(A->n_rows, A->n_cols, ncomp, ksp_type, ksp_grid_max(A)).total;
 }
 
-static KspState *g_state_host = nullptr;
+// (per host thread: several ranks of a job may be driven from threads of ONE process, each inside its own solve --
+// tests/test_gpu_threads_rehearsal.py; a thread's 1.2 KB of pinned memory and two events live as long as the process)
+static thread_local KspState *g_state_host = nullptr;
 // Where the last synchronisation point of the batch being queued writes the host's copy of the state (pinned, host
 // mapped: g_state_host[1 + slot]); nullptr outside ksp_run_ahead.  An in-stream copy of these 400 bytes is a blit
 // kernel of ~18 us plus ~6 us of stream bubble (rocprofv3, r03: 0.7 ms of a 16-ms pressure solve at 8 iterations a
 // batch); the kernel's own posted stores cost it ~1 us.
-static KspState *g_batch_mirror = nullptr;
+static thread_local KspState *g_batch_mirror = nullptr;
 static inline KspParams ksp_last_point(const KspParams &P, int k, int count) {
   KspParams Q = P;
   Q.mirror = (k + 1 == count) ? g_batch_mirror : nullptr;
@@ -1493,7 +1495,7 @@ static int ksp_read_state(const KspCtx &C) {
 // for, so the GPU never idles for the ~30 us of a read-back (the "host reads" of SURVEY section 7).  The
 // price is one batch of no-op kernels after convergence, hence small batches.  g_state_host[1], [2] are
 // the two copies in flight; the final state ends up in g_state_host[0].
-static hipEvent_t g_state_ev[2] = {nullptr, nullptr};
+static thread_local hipEvent_t g_state_ev[2] = {nullptr, nullptr};
 template <class Iterate>
 static int ksp_run_ahead(const KspCtx &C, Iterate &&iterate, int batch, int &it, int max_it) {
   for (int i = 0; i < 2; ++i)

@@ -648,7 +648,7 @@ static inline void spmv_window_range(const ox_sell *A, const int32_t *list, int 
 
 // the Jacobi diagonal of the OX_EPI_CG_M2 epilogue through its value dictionary (ox_ksp.hip sets it around its mat-vecs;
 // one call at a time per process: include/oasisx_hip.h)
-static OxEpiDinv g_epi_dinv{nullptr, nullptr};
+static thread_local OxEpiDinv g_epi_dinv{nullptr, nullptr};  // (set and read by the same host thread, around its mat-vecs)
 void ox_spmv_set_epilogue_dinv(const uint8_t *code, const double *dict) { g_epi_dinv = OxEpiDinv{code, dict}; }
 
 static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int ncomp, int epi,
@@ -1063,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_dot(int64_t n_rows, const double *__res
   }
 }
 
-static double *g_scratch = nullptr;       // device scratch for ox_dot / ox_remove_mean
-static double *g_scratch_host = nullptr;  // pinned
+static thread_local double *g_scratch = nullptr;       // device scratch for ox_dot / ox_remove_mean (per host thread)
+static thread_local double *g_scratch_host = nullptr;  // pinned
 static int ox_scratch_init() {
   if (!g_scratch) {
     OX_HIP(hipMalloc(&g_scratch, sizeof(double) * (OX_VEC_MAX_BLOCKS * 4 + 16)));

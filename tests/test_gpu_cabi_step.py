@@ -53,15 +53,16 @@ def test_ipcs_step_through_ctypes_only(hip, tmp_path, dim, N, udeg, compress, me
     assert abs(int(g["its_pressure"][0]) - int(np.max(np.atleast_1d(R.its["pressure"])))) <= 2
 
 
-@pytest.mark.parametrize("dim,N,deg,parts", [(3, 5, 2, 3), (2, 12, 2, 2), (3, 6, 1, 4)])
-def test_partitioned_space_through_ctypes_only(hip, dim, N, deg, parts):
+@pytest.mark.parametrize("dim,N,deg,parts,split", [(3, 5, 2, 3, "slabs"), (2, 12, 2, 2, "slabs"), (3, 6, 1, 4, "slabs"),
+                                                   (3, 8, 2, 8, "slabs"), (3, 6, 2, 8, "octants"), (3, 8, 1, 8, "octants")])
+def test_partitioned_space_through_ctypes_only(hip, dim, N, deg, parts, split):
     """ox_mesh_create_sub / ox_space_create_part driven with numpy + ctypes only (demo/cabi_partitioned_space.py, its
     own numpy partition): every rank's owned mass-matrix rows equal the whole mesh's through the dof coordinates, the
     owned dofs of the ranks tile the space, ghosts follow the owned dofs ordered by (owner, initial id)."""
     import json
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", "cabi_partitioned_space.py"), "--dim", str(dim), "-N", str(N),
-                        "--degree", str(deg), "--parts", str(parts)], capture_output=True, text=True, timeout=600)
+                        "--degree", str(deg), "--parts", str(parts), "--split", split], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert not rep["imported_package"] and not rep["imported_torch"]
