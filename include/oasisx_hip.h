@@ -128,6 +128,14 @@ typedef struct {
                                 which base, bits 16-23 code a, bits 24-31 code b                */
   const int32_t *ps_base;    /* device [ps_ptr[n_slices] / 256][2] column bases per group of 4
                                 slots x 64 lanes                                                */
+  int32_t ps_stride;         /* 0: slices packed back to back (ps_ptr is the only way to a slice's codes).  s > 0
+                                (ox_pair_stream_size_strided): EVERY slice owns exactly s groups -- ps_ptr[k] = k*s*256 --
+                                so a wave computes its code addresses from the slice number and requests the codes
+                                together with ps_ptr instead of one memory round after it; bits 4-7 of ps_ptr[k] then
+                                hold the groups of slice k that carry entries (the rest is padding)          */
+  int32_t ps_grid;           /* strided streams: blocks of the one-column mat-vec launch (a multiple of 8; 0 = one
+                                group of 4 slices per block).  Fewer blocks than groups = persistent waves that request
+                                the next slice's codes behind the current slice's gathers                     */
   /* optional LDS-window stream (ox_window_size / ox_window_fill; all NULL / 0 = not built).  The mat-vecs on the
    * velocity matrices are bound by their gather instructions, not by bytes (every x operand of a lane = row kernel
    * is one gather wave-instruction: DESIGN.md 3).  A WINDOW BLOCK = up to 8 slices (512 rows) whose rows lie close
@@ -331,6 +339,10 @@ int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *co
  * ps_ptr (bit 0) the slices whose columns do not fit two 15-bit windows per group -- they keep their
  * int32 columns -- and returns their number in *n_wide.  Then set A->ps_ptr / ps_code / ps_base. */
 int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, void *stream);
+/* The same with a FIXED number of groups per slice (ox_sell.ps_stride): *n_codes = n_slices * stride * 256 when no
+ * slice needs more than `stride` groups (P1 stiffness on tetrahedra: 3), else 0.  _fill is the same call. */
+int ox_pair_stream_size_strided(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, int stride,
+                                void *stream);
 /* Re-tile a per-slot array of A's pattern (elem_bytes = 1: vcode, 2: 16-bit codes) from the pair layout of
  * slice_ptr into the tile layout of wt_ptr (ox_sell.wt_ptr); unused entries of a slice's last tile are zeroed. */
 int ox_window_retile(const ox_sell *A, const int64_t *wt_ptr, const void *src, int elem_bytes, void *dst, void *stream);
@@ -613,6 +625,14 @@ int ox_dist_p2p_timeout(ox_dist *d, double timeout_s); /* change the bound of th
  * windows and the callback transports, off on RCCL plans until the side-stream send/recv has run between two real GPUs).
  * What DOLFINx/PETSc do inside MatMult (reference fracstep.py:453,497,632); never changes a result. */
 int ox_dist_set_overlap(ox_dist *d, int overlap);
+/* Release protocol of the xGMI-window transport of a plan (after ox_dist_enable_p2p).  conservative = 1 (the DEFAULT):
+ * every storing wave of the push kernel fences at system scope behind its payload stores and the flags -- halo and
+ * all-reduce -- are system-scope RELEASE stores.  conservative = 0: the fast form (the storing waves only wait for their
+ * write-through stores to be acknowledged, ONE system fence by the last block / per all-reduce wave, relaxed flag
+ * stores: 32 us instead of ~130 us for the 2.4 MB velocity halo of a 128^3 x 8 rank, 15 us per all-reduce -- figures
+ * measured with every rank on ONE device; the form has never crossed a link).  Keep the default until a run between two
+ * GPUs has passed the halo self-test, a bit-exact all-reduce and the rehearsal comparison with conservative = 0. */
+int ox_dist_set_p2p_release(ox_dist *d, int conservative);
 int ox_dist_disable_p2p(ox_dist *d);
 int ox_dist_status(const ox_dist *d);
 /* Same plan on a caller-supplied transport instead of RCCL (rehearsals on one GPU, other

@@ -45,6 +45,11 @@ struct ox_p2p {
   long long timeout_ticks;        // wall_clock64 ticks a kernel waits for a peer
   void **opened;         // host [n_opened]: IPC mappings to close
   int n_opened;
+  // release protocol of the push kernel and the all-reduce (ox_dist_set_p2p_release): 1 = CONSERVATIVE (default): every
+  // storing wave fences at system scope behind its payload stores and the flags are release stores; 0 = the round-5
+  // fast form (s_waitcnt vmcnt(0) per wave, one system fence by the last block / per wave, relaxed flag stores), which
+  // has only ever run with all ranks on ONE device
+  int conservative;
 };
 
 // Halo plan + RCCL communicator (ox_dist.hip).  NULL everywhere = single GPU.

@@ -244,6 +244,7 @@ extern "C" int ox_dist_enable_p2p(ox_dist *d, void *my_win, void *const *rank_wi
   OX_HIP(hipMalloc(&q->err_dev, sizeof(int)));  // device memory: the kernels poll it on every wait
   OX_HIP(hipMemset(q->err_dev, 0, sizeof(int)));
   q->timeout_ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 1e8);  // wall_clock64: 100 MHz
+  q->conservative = 1;  // (ox_dist_set_p2p_release(d, 0) selects the fast form)
   OX_HIP(hipDeviceSynchronize());
   d->p2p = q;
   return 0;
@@ -258,6 +259,13 @@ extern "C" int ox_dist_p2p_timeout(ox_dist *d, double timeout_s) {
 extern "C" int ox_dist_set_overlap(ox_dist *d, int overlap) {
   if (!d) OX_FAIL("ox_dist_set_overlap: null plan");
   d->overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
+  return 0;
+}
+
+extern "C" int ox_dist_set_p2p_release(ox_dist *d, int conservative) {
+  if (!d) OX_FAIL("ox_dist_set_p2p_release: null plan");
+  if (!d->p2p) OX_FAIL("ox_dist_set_p2p_release: the plan has no xGMI-window transport (ox_dist_enable_p2p first)");
+  d->p2p->conservative = conservative ? 1 : 0;
   return 0;
 }
 
@@ -277,11 +285,13 @@ __device__ __forceinline__ void ox_store16_sys(double *dst, double a, double b) 
   v.y = (unsigned)((unsigned long long)__double_as_longlong(a) >> 32);
   v.z = (unsigned)__double_as_longlong(b);
   v.w = (unsigned)((unsigned long long)__double_as_longlong(b) >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
+  // (s_nop 1: the compiler does not see a VMEM store inside inline asm, so it cannot place the wait states a store of
+  // more than 64 bits needs before its data registers are written again)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ox_load16_sys(const double *src, double &a, double &b) {
   ox_u4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
   a = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
   b = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
 }
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
                                                    double *const *__restrict__ r_stage,
                                                    const int64_t *__restrict__ r_off,
                                                    unsigned long long *const *__restrict__ r_hflag,
-                                                   int parity, unsigned long long seq, unsigned *ticket) {
+                                                   int parity, unsigned long long seq, unsigned *ticket, int conservative) {
   const int64_t e0 = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x), tot = ns * nc;
   if (e0 < tot) {
     double v[2];
@@ -324,14 +334,22 @@ __global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ x,
   // (Rounds 1-4 had every thread of every block run __threadfence_system() here: a write-back and an invalidate of the
   // XCD's L2 per block -- 100 us for the 2.4 MB velocity halo of a 128^3 x 8 rank, and the mat-vec around it lost its
   // cached operands; round 5, found by timing the self-loop plans: tools/predict_scaling.py --transport p2p.)
+  // That form has only ever run with every rank on ONE device.  CONSERVATIVE plans (ox_dist_set_p2p_release, the
+  // default until a run between two GPUs has passed the halo self-test and a bit-exact all-reduce) keep the per-thread
+  // system fence of rounds 1-4 behind the payload stores and raise the flags with system-scope RELEASE stores.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (conservative) __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();  // the one release of the launch; the flags behind it are relaxed stores
-      for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELAXED, OX_SYS);
+      __threadfence_system();  // the release of the launch
+      if (conservative) {
+        for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELEASE, OX_SYS);
+      } else {  // fast form: the flags behind the one fence are relaxed stores
+        for (int p = 0; p < n_peers; ++p) __hip_atomic_store(r_hflag[p * 2 + parity], seq, __ATOMIC_RELAXED, OX_SYS);
+      }
     }
   }
 }
@@ -377,6 +395,7 @@ ox_p2p_ar ox_p2p_next_allreduce(const ox_dist *d) {
   a.nranks = d->nranks;
   a.timeout_ticks = q->timeout_ticks;
   a.err = q->err_dev;
+  a.conservative = q->conservative;
   return a;
 }
 
@@ -388,7 +407,7 @@ static int p2p_halo_push(const ox_dist *d, double *x, int ncomp, hipStream_t st)
   const int64_t tot = (ns * ncomp + 1) / 2;  // two values per thread
   const unsigned nblk = (unsigned)(tot > 0 ? (tot + 255) / 256 : 1);
   hipLaunchKernelGGL(k_halo_push, dim3(nblk), dim3(256), 0, st, x, d->send_idx, ns, ncomp, q->send_off_dev,
-                     d->n_peers, q->r_stage, q->r_off, q->r_hflag, parity, seq, q->ticket);
+                     d->n_peers, q->r_stage, q->r_off, q->r_hflag, parity, seq, q->ticket, q->conservative);
   OX_LAUNCH_CHECK();
   return 0;
 }

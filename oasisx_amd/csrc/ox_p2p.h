@@ -16,6 +16,7 @@ struct ox_p2p_ar {
   unsigned long long seq;
   long long timeout_ticks;
   int *err;
+  int conservative;  // release-scope flag stores (ox_dist_set_p2p_release)
 };
 
 // wait until *flag >= seq; false on time-out (and the sticky error is raised)
@@ -55,7 +56,12 @@ __device__ __forceinline__ void ox_p2p_allreduce_block(double *vals, int n, cons
     __threadfence_system();                            // ... ONE release for all of them, then the flags (relaxed)
     const char *src = a.my_slots + ((size_t)a.parity * a.nranks + (live ? r : 0)) * OX_P2P_SLOT;
     if (live && i == 15) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), a.seq, __ATOMIC_RELAXED, OX_SYS);
+      // conservative plans (the default until the windows have crossed a link): the flag itself is a system-scope
+      // RELEASE store behind the wave's fence
+      if (a.conservative)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), a.seq, __ATOMIC_RELEASE, OX_SYS);
+      else
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + OX_P2P_SLOT - 8), a.seq, __ATOMIC_RELAXED, OX_SYS);
       ox_p2p_wait(reinterpret_cast<const unsigned long long *>(src + OX_P2P_SLOT - 8), a.seq, a.timeout_ticks, a.err);
     }
     // the wave reconverges behind the waits of its flag lanes: no load of a rank's values may be issued, or moved by

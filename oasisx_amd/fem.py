@@ -910,7 +910,7 @@ class FunctionSpace:
                                       self.n_local - self.n_owned, C.byref(out)), "ox_dist_create")
         if want in ("auto", "p2p") and comm.enable_p2p(self, out):
             self.dist = out
-            self._apply_plan_options()
+            self._apply_plan_options(comm_is_p2p=True)
             self.pattern.dist = out
             self.pattern.split_interior(self.n_owned)
             comm.active[self.degree] = "p2p"
@@ -930,12 +930,18 @@ class FunctionSpace:
         self.check_halo()
         comm.active[self.degree] = "rccl"
 
-    def _apply_plan_options(self):
+    def _apply_plan_options(self, comm_is_p2p: bool = False):
         """Schedule knobs of the halo plan from the environment, read by the host layer and set through the ABI
         (``OX_HALO_OVERLAP=0|1``: exchange-then-multiply / overlapped mat-vecs; unset: the transport's default)."""
         v = _os.environ.get("OX_HALO_OVERLAP")
         if v is not None and self.dist is not None:
             _lib.check(_lib.load().ox_dist_set_overlap(self.dist, 1 if v not in ("0", "false", "") else 0), "ox_dist_set_overlap")
+        # OX_P2P_RELEASE=fast: the round-5 release protocol of the xGMI windows (one fence per launch, relaxed flags);
+        # unset / "conservative": per-wave system fences and release-scope flags -- the library's default until the
+        # windows have crossed a link (include/oasisx_hip.h, ox_dist_set_p2p_release)
+        v = _os.environ.get("OX_P2P_RELEASE")
+        if v is not None and self.dist is not None and comm_is_p2p:
+            _lib.check(_lib.load().ox_dist_set_p2p_release(self.dist, 0 if v.lower() == "fast" else 1), "ox_dist_set_p2p_release")
 
     def check_halo(self):
         """Self-test of the attached halo plan + transport: exchange the dof coordinates and require

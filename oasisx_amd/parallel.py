@@ -372,6 +372,10 @@ class SelfLoopComm(Comm):
             zero, png = np.zeros(1, dtype=np.int64), np.asarray([ng], dtype=np.int64)
             _lib.check(lib.ox_dist_enable_p2p(out, win, wins, zero.ctypes.data_as(C.POINTER(C.c_int64)),
                                               png.ctypes.data_as(C.POINTER(C.c_int64)), 15.0), "ox_dist_enable_p2p")
+            import os
+
+            if os.environ.get("OX_P2P_RELEASE", "").lower() == "fast":  # (the library's default is the conservative form)
+                _lib.check(lib.ox_dist_set_p2p_release(out, 0), "ox_dist_set_p2p_release")
         return out
 
     def allreduce(self, v, op=None):

@@ -61,9 +61,11 @@ def _run(dim, N, deg, comm, steps, low_memory=True, p_deg=1):
     return S, diffs
 
 
-def _worker(rank, world, port, dim, N, deg, low_memory, transport, out):
+def _worker(rank, world, port, dim, N, deg, low_memory, transport, out, release=None):
     import torch.distributed as dist
 
+    if release is not None:
+        os.environ["OX_P2P_RELEASE"] = release
     os.environ["OX_TRANSPORT"] = transport
     os.environ["OX_P2P_TIMEOUT_S"] = "30"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -118,6 +120,19 @@ def test_partitioned_steps_match_serial(hip, dim, N, deg, world, low_memory, tra
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, low_memory, transport, out), nprocs=world, join=True)
+    assert len(out) == world, dict(out)
+
+
+@pytest.mark.parametrize("dim,N,deg,world", [(3, 6, 2, 2), (2, 12, 2, 3)])
+def test_partitioned_steps_with_the_fast_release_protocol(hip, dim, N, deg, world):
+    """The window transport's default is the CONSERVATIVE release protocol (per-wave system fences, release-scope flag
+    stores: ox_dist_set_p2p_release); OX_P2P_RELEASE=fast selects round 5's one-fence form.  Both must give the serial
+    run's fields -- here with every rank on one device, the only place either has run."""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), dim, N, deg, True, "p2p", out, "fast"), nprocs=world, join=True)
     assert len(out) == world, dict(out)
 
 

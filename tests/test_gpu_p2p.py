@@ -59,7 +59,7 @@ def test_absent_peer_times_out_and_is_reported(hip):
     lib.ox_p2p_window_free(w1)
 
 
-def _window_allreduce_ranks(nr, n):
+def _window_allreduce_ranks(nr, n, fast=False):
     """The in-block all-reduce of the window transport with ``nr`` ranks living in ONE process: every rank has its own
     window, its plan maps all of them, the ``nr`` kernels run concurrently on ``nr`` streams and wait for each other's
     flags.  Sixteen lanes per rank move the values; the sums are formed in rank order: the same bits on every rank, equal to
@@ -85,6 +85,8 @@ def _window_allreduce_ranks(nr, n):
                                       off1.ctypes.data_as(C.POINTER(C.c_int64)), 8, ng, C.byref(plan)), "ox_dist_create")
         _lib.check(lib.ox_dist_enable_p2p(plan, wins_v[r], wins, off1.ctypes.data_as(C.POINTER(C.c_int64)),
                                           off1.ctypes.data_as(C.POINTER(C.c_int64)), 5.0), "ox_dist_enable_p2p")
+        if fast:  # (the library's default is the conservative release protocol)
+            _lib.check(lib.ox_dist_set_p2p_release(plan, 0), "ox_dist_set_p2p_release")
         plans.append(plan)
     streams = [torch.cuda.Stream() for _ in range(nr)]
     rng = np.random.default_rng(7)
@@ -105,25 +107,29 @@ def _window_allreduce_ranks(nr, n):
         lib.ox_dist_destroy(plans[r])  # (a plan owns its own window; the others were never IPC mappings)
 
 
-@pytest.mark.parametrize("nr,n", [(3, 15), (3, 5), (2, 1)])
-def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n):
-    """(At most three ranks here: a process has four hardware queues by default, one of them the null stream's; a fourth
-    kernel would wait behind one that waits for it.)"""
-    _window_allreduce_ranks(nr, n)
-
-
-def test_window_allreduce_of_six_ranks_two_waves_of_lanes(hip):
-    """Six ranks -- 96 lanes, two waves, what an 8-GPU job runs -- need six kernels in flight: a child process with
-    GPU_MAX_HW_QUEUES=8 (the variable must be set before HIP starts)."""
+def _in_a_child_with_eight_queues(call):
+    """``nr`` mutually waiting kernels need ``nr`` hardware queues: a process has four by default (one of them the null
+    stream's) and two pool streams may share one -- the kernels would then serialise and run into their bounded waits.
+    Every in-process multi-rank case therefore runs in a child process with GPU_MAX_HW_QUEUES=8 (set before HIP starts)."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_p2p as t; t._window_allreduce_ranks(6, 15); print('six ranks ok')"],
+    r = subprocess.run([sys.executable, "-c", f"import tests.test_gpu_p2p as t; {call}; print('ranks ok')"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "six ranks ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ranks ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_window_allreduce_of_several_ranks_in_one_process(hip):
+    """Two and three ranks, 1 to 15 values, both release protocols (conservative = the default; fast = round 5's)."""
+    _in_a_child_with_eight_queues("[t._window_allreduce_ranks(nr, n, fast) for nr, n in ((3, 15), (3, 5), (2, 1)) for fast in (False, True)]")
+
+
+def test_window_allreduce_of_six_ranks_two_waves_of_lanes(hip):
+    """Six ranks -- 96 lanes, two waves, what an 8-GPU job runs -- need six kernels in flight."""
+    _in_a_child_with_eight_queues("t._window_allreduce_ranks(6, 15); t._window_allreduce_ranks(6, 15, True)")
 
 
 @pytest.mark.parametrize("transport", ["rccl", "p2p"])
