@@ -128,14 +128,6 @@ typedef struct {
                                 which base, bits 16-23 code a, bits 24-31 code b                */
   const int32_t *ps_base;    /* device [ps_ptr[n_slices] / 256][2] column bases per group of 4
                                 slots x 64 lanes                                                */
-  int32_t ps_stride;         /* 0: slices packed back to back (ps_ptr is the only way to a slice's codes).  s > 0
-                                (ox_pair_stream_size_strided): EVERY slice owns exactly s groups -- ps_ptr[k] = k*s*256 --
-                                so a wave computes its code addresses from the slice number and requests the codes
-                                together with ps_ptr instead of one memory round after it; bits 4-7 of ps_ptr[k] then
-                                hold the groups of slice k that carry entries (the rest is padding)          */
-  int32_t ps_grid;           /* strided streams: blocks of the one-column mat-vec launch (a multiple of 8; 0 = one
-                                group of 4 slices per block).  Fewer blocks than groups = persistent waves that request
-                                the next slice's codes behind the current slice's gathers                     */
   /* optional LDS-window stream (ox_window_size / ox_window_fill; all NULL / 0 = not built).  The mat-vecs on the
    * velocity matrices are bound by their gather instructions, not by bytes (every x operand of a lane = row kernel
    * is one gather wave-instruction: DESIGN.md 3).  A WINDOW BLOCK = up to 8 slices (512 rows) whose rows lie close
@@ -339,10 +331,6 @@ int ox_value_dictionary(const double *vals, int64_t n_slots, int ncomp, void *co
  * ps_ptr (bit 0) the slices whose columns do not fit two 15-bit windows per group -- they keep their
  * int32 columns -- and returns their number in *n_wide.  Then set A->ps_ptr / ps_code / ps_base. */
 int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, void *stream);
-/* The same with a FIXED number of groups per slice (ox_sell.ps_stride): *n_codes = n_slices * stride * 256 when no
- * slice needs more than `stride` groups (P1 stiffness on tetrahedra: 3), else 0.  _fill is the same call. */
-int ox_pair_stream_size_strided(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes, int stride,
-                                void *stream);
 /* Re-tile a per-slot array of A's pattern (elem_bytes = 1: vcode, 2: 16-bit codes) from the pair layout of
  * slice_ptr into the tile layout of wt_ptr (ox_sell.wt_ptr); unused entries of a slice's last tile are zeroed. */
 int ox_window_retile(const ox_sell *A, const int64_t *wt_ptr, const void *src, int elem_bytes, void *dst, void *stream);

@@ -41,8 +41,6 @@ class ox_sell(C.Structure):
         ("ps_ptr", C.c_void_p),
         ("ps_code", C.c_void_p),
         ("ps_base", C.c_void_p),
-        ("ps_stride", C.c_int32),
-        ("ps_grid", C.c_int32),
         ("wb_slices", C.c_void_p),
         ("wb_waves", C.c_void_p),
         ("wb_ptr", C.c_void_p),
@@ -214,7 +212,6 @@ SIGNATURES = {
     "ox_rect_destroy": (_I, [_P]),
     "ox_value_dictionary": (_I, [_P, _L, _I, _P, _P, C.POINTER(_I), _P]),
     "ox_pair_stream_size": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _P]),
-    "ox_pair_stream_size_strided": (_I, [C.POINTER(ox_sell), _P, _P, C.POINTER(_L), _I, _P]),
     "ox_pair_stream_fill": (_I, [C.POINTER(ox_sell), _P, _P, _P, _P, C.POINTER(_L), _P]),
     "ox_malloc": (_I, [C.c_size_t, C.POINTER(_P)]),
     "ox_free": (_I, [_P]),

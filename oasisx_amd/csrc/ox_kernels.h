@@ -42,16 +42,7 @@ static inline int ox_spmv_blocks_n(int n_slices) {
   const int g8 = (ngroups + 7) & ~7;
   return g8 > OX_SPMV_MAX_BLOCKS ? OX_SPMV_MAX_BLOCKS : g8;
 }
-// (a strided pair-slot stream may ask for a persistent launch: ox_sell.ps_grid blocks, a multiple of 8 -- one-column
-// launches on the whole operator only; every consumer of the partial sums sizes them through this function)
-static inline int ox_spmv_blocks(const ox_sell *A) {
-  const int full = ox_spmv_blocks_n(A->n_slices);
-  if (A->ps_stride > 0 && A->ps_grid >= 8 && A->ps_ptr && A->ps_code && A->ps_base) {
-    const int g = A->ps_grid & ~7;
-    return g < full ? g : full;
-  }
-  return full;
-}
+static inline int ox_spmv_blocks(const ox_sell *A) { return ox_spmv_blocks_n(A->n_slices); }
 
 static inline int ox_vec_blocks(int64_t n) {
   int64_t b = (n / 2 + 255) / 256;

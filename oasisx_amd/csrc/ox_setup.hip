@@ -1968,12 +1968,10 @@ __global__ __launch_bounds__(256) void k_pair_stream(ox_sell A, const int32_t *_
     }
     // slots of the LAST group that any row of the slice uses (1..4), in bits 1-3 of the offset: the SpMV issues
     // gathers for those only (a slice of interior P1 rows needs 9 slots and stores 12)
-    // (a strided stream stores `ngroups` = the stride for every slice: the groups that carry entries go into bits 4-7)
     const int m = ps_wave_max(used);
-    const int ng_true = ngroups > 0 ? min(ngroups, max(1, (m + 3) >> 2)) : 0;
-    const int last = ngroups > 0 ? min(4, max(1, m - 4 * (ng_true - 1))) : 0;
-    if (lane == 0 && ngroups > 0) {  // (with the offset: the kernel learns all of it without another round trip)
-      ps_ptr[slice] = pb | (ok ? 0 : 1) | ((int64_t)last << 1) | ((int64_t)min(ng_true, 15) << 4);
+    const int last = ngroups > 0 ? min(4, max(1, m - 4 * (ngroups - 1))) : 0;
+    if (lane == 0 && ngroups > 0) {  // (with the offset: the kernel learns both without another round trip)
+      ps_ptr[slice] = pb | (ok ? 0 : 1) | ((int64_t)last << 1);
       if (!ok) atomicAdd(n_wide, 1ull);
     }
   }
@@ -2011,50 +2009,6 @@ extern "C" int ox_pair_stream_size(const ox_sell *A, const int32_t *row_len, int
   OX_HIP(hipMemcpyAsync(&total, ps_ptr + A->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
   OX_HIP(hipStreamSynchronize(st));
   *n_codes = total;
-  return 0;
-}
-
-__global__ __launch_bounds__(256) void k_ps_max_len(const int64_t *__restrict__ len, int64_t n, unsigned long long *out) {
-  unsigned long long m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    m = max(m, (unsigned long long)len[i]);
-  if (m) atomicMax(out, m);
-}
-__global__ __launch_bounds__(256) void k_ps_fill_len(int64_t *__restrict__ len, int64_t n, int64_t v) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) len[i] = v;
-}
-
-extern "C" int ox_pair_stream_size_strided(const ox_sell *A, const int32_t *row_len, int64_t *ps_ptr, int64_t *n_codes,
-                                           int stride, void *stream) {
-  if (!A || !row_len || !ps_ptr || !n_codes) OX_FAIL("ox_pair_stream_size_strided: null argument");
-  if (stride < 1 || stride > 15) OX_FAIL("ox_pair_stream_size_strided: stride=%d (1..15 groups per slice)", stride);
-  hipStream_t st = ox_stream(stream);
-  *n_codes = 0;
-  if (!A->vcode || !A->cols || A->n_slices <= 0 || A->n_cols < 2 || A->n_rows < 2) return 0;
-  const int zc = ps_zero_code(A, st);
-  if (zc < 0) return 0;
-  DevBuf len, mx;
-  OX_TRY(len.alloc(sizeof(int64_t) * ((size_t)A->n_slices + 1)));
-  OX_TRY(mx.alloc(sizeof(unsigned long long)));
-  OX_HIP(hipMemsetAsync(len.p, 0, len.bytes, st));
-  OX_HIP(hipMemsetAsync(mx.p, 0, mx.bytes, st));
-  const unsigned nb = (unsigned)std::min<int64_t>(((int64_t)A->n_slices + 3) / 4, 1 << 20);
-  hipLaunchKernelGGL(k_pair_stream<false>, dim3(nb), dim3(256), 0, st, *A, row_len, zc, len.as<int64_t>(), nullptr, nullptr,
-                     nullptr, nullptr);
-  OX_LAUNCH_CHECK();
-  const unsigned nb2 = (unsigned)std::min<int64_t>(((int64_t)A->n_slices + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_ps_max_len, dim3(nb2), dim3(256), 0, st, len.as<int64_t>(), (int64_t)A->n_slices,
-                     mx.as<unsigned long long>());
-  OX_LAUNCH_CHECK();
-  unsigned long long h = 0;
-  OX_HIP(hipMemcpyAsync(&h, mx.p, sizeof(h), hipMemcpyDeviceToHost, st));
-  OX_HIP(hipStreamSynchronize(st));
-  if (h > (unsigned long long)stride * 256) return 0;  // a slice needs more groups than the stride: not available
-  hipLaunchKernelGGL(k_ps_fill_len, dim3(nb2), dim3(256), 0, st, len.as<int64_t>(), (int64_t)A->n_slices, (int64_t)stride * 256);
-  OX_LAUNCH_CHECK();
-  OX_TRY(exclusive_scan_i64(len.as<int64_t>(), ps_ptr, (size_t)A->n_slices + 1, st));
-  OX_HIP(hipStreamSynchronize(st));
-  *n_codes = (int64_t)A->n_slices * stride * 256;
   return 0;
 }
 

@@ -187,11 +187,7 @@ __global__ __launch_bounds__(256) void k_spmv(ox_sell A, const double *__restric
 // copy (no block barrier).
 // ---------------------------------------------------------------------------------------
 // (the one-column OX_EPI_CG_M2 form sits at 81 registers: held to 80 = 6 waves per SIMD, where the OX_EPI_DOT form runs)
-// STRIDE > 0 (ox_sell.ps_stride, one-column launches): every slice owns STRIDE groups, so the wave computes its code
-// addresses from the slice number -- the codes are requested in round A together with ps_ptr (which then only carries
-// the slice's flags), one dependent round fewer -- and a wave that owns several slices (ox_sell.ps_grid: fewer blocks
-// than slice groups) requests the NEXT slice's codes before it issues the current slice's gathers.
-template <int NC, int EPI, int STRIDE = 0>
+template <int NC, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 && EPI == OX_EPI_CG_M2) ? 6 : 1, 8))) void k_spmv_ps(ox_sell A, const double *__restrict__ x,
                                                  double *__restrict__ y,
                                                  const double *__restrict__ dinv,
@@ -218,20 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
   int li = g * 4 + wave;
   bool valid = g < g_end && li < n_sl;
   int slice = valid ? (slice_list ? slice_list[li] : li) : 0;
-  int64_t base = A.ps_ptr[slice], next = STRIDE ? 0 : A.ps_ptr[slice + 1];  // bit 0: slice kept in the entry stream
-  static_assert(STRIDE == 0 || STRIDE == 3, "k_spmv_ps: strided streams of 3 groups per slice");
-  constexpr int SG = STRIDE ? STRIDE : 1;
-  u4 pc[SG];    // STRIDE: the codes and bases of the slice in hand, requested with its ps_ptr
-  int2 pbs[SG];
-  if (STRIDE) {
-    const u4 *__restrict__ cps = reinterpret_cast<const u4 *>(A.ps_code) + (size_t)slice * (STRIDE * 64) + lane;
-    const int2 *__restrict__ bps = reinterpret_cast<const int2 *>(A.ps_base) + (size_t)slice * STRIDE;
-#pragma unroll
-    for (int q = 0; q < SG; ++q) {
-      pc[q] = __builtin_nontemporal_load(cps + (size_t)q * 64);
-      pbs[q] = bps[q];
-    }
-  }
+  int64_t base = A.ps_ptr[slice], next = A.ps_ptr[slice + 1];  // bit 0: slice kept in the entry stream
   const int nd = A.n_dict;
   double *md = dict + wave * 256;
   {
@@ -252,27 +235,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
   while (valid) {
     const bool wide = (base & 1) != 0;
     const int last = (int)((base >> 1) & 7);  // slots of the last group that any row uses (0: a stream without the hint)
-    const int ng_bits = (int)((base >> 4) & 15);  // groups that carry entries (strided streams pad every slice to STRIDE)
     base &= ~(int64_t)255;
-    const int ng = STRIDE ? ng_bits : (int)(((next & ~(int64_t)255) - base) >> 8);  // groups of 4 slots x 64 lanes
-    // STRIDE: the next slice of this wave -- its codes are requested NOW, in front of the gathers below
-    int g_n = g + per, li_n = g_n * 4 + wave;
-    const bool valid_n = STRIDE && g_n < g_end && li_n < n_sl;
-    int slice_n = 0;
-    int64_t base_n = 0;
-    u4 pcn[SG];
-    int2 pbn[SG];
-    if (STRIDE && valid_n) {
-      slice_n = slice_list ? slice_list[li_n] : li_n;
-      base_n = A.ps_ptr[slice_n];
-      const u4 *__restrict__ cps = reinterpret_cast<const u4 *>(A.ps_code) + (size_t)slice_n * (STRIDE * 64) + lane;
-      const int2 *__restrict__ bps = reinterpret_cast<const int2 *>(A.ps_base) + (size_t)slice_n * STRIDE;
-#pragma unroll
-      for (int q = 0; q < SG; ++q) {
-        pcn[q] = __builtin_nontemporal_load(cps + (size_t)q * 64);
-        pbn[q] = bps[q];
-      }
-    }
+    const int ng = (int)(((next & ~(int64_t)255) - base) >> 8);  // groups of 4 slots x 64 lanes
     const int64_t row = (int64_t)slice * 64 + lane;
     const int64_t rowc = min(row, A.n_rows - 1);
     double xe[NC], ae[NC], de = 1.0;  // epilogue operands: requested now, used after the products
@@ -329,20 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
           else group(std::integral_constant<int, 4>{}, cc, bq);
         };
         int q0 = 0;
-        if (STRIDE) {  // (STRIDE == 3) the codes are in hand
-          if (ng == 1) {
-            tail(pc[0], pbs[0]);
-          } else {
-            group(std::integral_constant<int, 4>{}, pc[0], pbs[0]);
-            if (ng == 2) {
-              tail(pc[SG > 1 ? 1 : 0], pbs[SG > 1 ? 1 : 0]);
-            } else {
-              group(std::integral_constant<int, 4>{}, pc[SG > 1 ? 1 : 0], pbs[SG > 1 ? 1 : 0]);
-              tail(pc[SG > 2 ? 2 : 0], pbs[SG > 2 ? 2 : 0]);
-            }
-          }
-          q0 = ng;
-        } else if (ng <= 3) {
+        if (ng <= 3) {
           const u4 c0 = __builtin_nontemporal_load(cp);
           const u4 c1 = __builtin_nontemporal_load(cp + (size_t)min(1, ng - 1) * 64);
           const u4 c2 = __builtin_nontemporal_load(cp + (size_t)(ng - 1) * 64);
@@ -420,15 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NC == 1 &&
     g += per;
     li = g * 4 + wave;
     valid = g < g_end && li < n_sl;
-    if (STRIDE) {
-      slice = slice_n;
-      base = base_n;
-#pragma unroll
-      for (int q = 0; q < SG; ++q) {
-        pc[q] = pcn[q];
-        pbs[q] = pbn[q];
-      }
-    } else if (valid) {
+    if (valid) {
       slice = slice_list ? slice_list[li] : li;
       base = A.ps_ptr[slice];
       next = A.ps_ptr[slice + 1];
@@ -739,10 +682,7 @@ static int spmv_launch_list(const ox_sell *A, const double *x, double *y, int nc
     if (var == 7 && pairs) {                                                                    \
       const int *dz = done ? done : ox_zero_flag(st);                                             \
       if (!dz) OX_FAIL("ox_spmv: no device flag");                                              \
-      if (NC == 1 && A->ps_stride == 3)                                                            \
-        hipLaunchKernelGGL((k_spmv_ps<NC, E, (NC == 1 ? 3 : 0)>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list, g_epi_dinv); \
-      else                                                                                        \
-        hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list, g_epi_dinv); \
+      hipLaunchKernelGGL((k_spmv_ps<NC, E>), dim3(nblk), dim3(256), 0, st, *A, x, y, dinv, aux, partial, dz, list, n_list, g_epi_dinv); \
     } else if (var == 7) OX_SPMV_LAUNCH(NC, E, 7);                                              \
     else if (var == 3) OX_SPMV_LAUNCH(NC, E, 3);                                                \
     else if (var == 2) OX_SPMV_LAUNCH(NC, E, 2);                                                \

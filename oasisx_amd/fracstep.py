@@ -319,12 +319,7 @@ class FractionalStep_AB_CN:
             # M and Ap never change again: 1-byte value codes where <= 256 distinct values (la.freeze)
             self._M.freeze()
             self._K.freeze(pairs="never")  # read by the fused assemble_first only: never multiplied
-            # pressure matrix: the pair-slot stream with a fixed number of groups per slice where it exists
-            # (options["pressure_ps_stride"] / ["pressure_ps_grid"]; la.SellMatrix.freeze)
-            import os as _os
-
-            self._Ap.freeze(ps_stride=int(self._options.get("pressure_ps_stride", _os.environ.get("OX_PS_STRIDE", "0"))),
-                            ps_grid=int(self._options.get("pressure_ps_grid", _os.environ.get("OX_PS_GRID", "0"))))
+            self._Ap.freeze()
         if not self._low_memory:  # the rectangular operators (:392-404)
             for fam, Mat, R_, C_, adj_, pos_, pw_ in ((0, self._p_vdxi_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),
                                                     (1, self._grad_p_Mat, Vi, Q, self._adj_u, self._pos_vq, self._pw_vq),

@@ -69,11 +69,10 @@ class SellMatrix:
         self._struct.n_dict = 0
         self.ps_ptr = self.ps_code = self.ps_base = None
         self._struct.ps_ptr = self._struct.ps_code = self._struct.ps_base = None
-        self._struct.ps_stride = self._struct.ps_grid = 0
         self.wvcode = None
         self._struct.wvcode = None
 
-    def freeze(self, block: int = 1 << 27, pairs: str = "auto", ps_stride: int = 0, ps_grid: int = 0) -> bool:
+    def freeze(self, block: int = 1 << 27, pairs: str = "auto") -> bool:
         """Value dictionary for a matrix whose values will not change any more (M, Ap: assembled
         once, reference fracstep.py:373-380): if the stored values take at most 256 distinct bit
         patterns -- mass and stiffness matrices on meshes of congruent cells do: 49 / 14 on the box
@@ -81,10 +80,7 @@ class SellMatrix:
         value up in an LDS copy of the dictionary.  Same values, same order of sums: bit-identical
         results.  Returns whether a dictionary was built (False: nothing changes).
         ``pairs``: "auto" builds the pair-slot stream where it stores at most 0.72 slots per entry slot (P1
-        patterns: 0.64; P2: 0.87, where it is slower), "always" / "never" force it.
-        ``ps_stride`` > 0: the pair-slot stream with that many groups for EVERY slice where no slice needs more
-        (``ox_pair_stream_size_strided``: code addresses computable from the slice number), the packed stream
-        otherwise; ``ps_grid``: blocks of its one-column launches (0: one slice group per block)."""
+        patterns: 0.64; P2: 0.87, where it is slower), "always" / "never" force it."""
         P = self.pattern
         if P.device.type != "cuda" or P.cols16 is None or P.size == 0:
             return False
@@ -100,7 +96,7 @@ class SellMatrix:
         self._struct.vcode, self._struct.vdict = self.vcode.data_ptr(), self.vdict.data_ptr()
         self._struct.n_dict = int(nd.value)
         if pairs != "never":
-            self._build_pair_stream(force=pairs == "always", stride=ps_stride, grid=ps_grid)
+            self._build_pair_stream(force=pairs == "always")
         if getattr(P, "wt_ptr", None) is not None and self.ps_code is None:
             # the pattern carries an LDS-window stream: the value codes once more in its tile layout (4 codes of a
             # lane per 4-byte load)
@@ -110,24 +106,17 @@ class SellMatrix:
             self._struct.wvcode = self.wvcode.data_ptr()
         return True
 
-    def _build_pair_stream(self, force: bool = False, stride: int = 0, grid: int = 0):
+    def _build_pair_stream(self, force: bool = False):
         """Pair-slot stream of the frozen matrix (``ox_sell.ps_*``): entries in adjacent columns share
         one 16-byte gather.  The SpMV on dictionary matrices is bound by the number of vector-memory
         instructions, not by bytes; bit-identical results."""
         P, lib = self.pattern, _lib.load()
         ps_ptr = torch.empty(P.n_slices + 1, dtype=torch.int64, device=P.device)
         n = C.c_int64(0)
-        self._struct.ps_stride = self._struct.ps_grid = 0
-        if stride > 0:
-            _lib.check(lib.ox_pair_stream_size_strided(C.byref(self._struct), _lib.ptr(P.row_len), _lib.ptr(ps_ptr), C.byref(n),
-                                                       int(stride), _lib.current_stream()), "ox_pair_stream_size_strided")
-            if n.value == 0 or (not force and n.value > 0.80 * P.size):
-                stride = 0  # a slice needs more groups (or the padding outweighs the saved round): the packed stream
-        if stride <= 0:
-            _lib.check(lib.ox_pair_stream_size(C.byref(self._struct), _lib.ptr(P.row_len), _lib.ptr(ps_ptr), C.byref(n),
-                                               _lib.current_stream()), "ox_pair_stream_size")
-            if n.value == 0 or (not force and n.value > 0.72 * P.size):
-                return
+        _lib.check(lib.ox_pair_stream_size(C.byref(self._struct), _lib.ptr(P.row_len), _lib.ptr(ps_ptr), C.byref(n),
+                                           _lib.current_stream()), "ox_pair_stream_size")
+        if n.value == 0 or (not force and n.value > 0.72 * P.size):
+            return
         code = torch.empty(n.value, dtype=torch.int32, device=P.device)
         base = torch.empty(2 * (n.value // 256), dtype=torch.int32, device=P.device)
         wide = C.c_int64(0)
@@ -135,9 +124,6 @@ class SellMatrix:
                                            _lib.ptr(base), C.byref(wide), _lib.current_stream()), "ox_pair_stream_fill")
         self.ps_ptr, self.ps_code, self.ps_base, self.ps_wide = ps_ptr, code, base, int(wide.value)
         self._struct.ps_ptr, self._struct.ps_code, self._struct.ps_base = ps_ptr.data_ptr(), code.data_ptr(), base.data_ptr()
-        self.ps_stride = int(stride) if stride > 0 else 0
-        self._struct.ps_stride = self.ps_stride
-        self._struct.ps_grid = int(grid) & ~7 if self.ps_stride else 0
 
     def getSize(self):
         return (self.pattern.n_rows, self.pattern.n_cols)

@@ -28,12 +28,12 @@ if real:
                                        C.byref(adj), _lib.ptr(V.adj.adj_pos), V.adj.pw, A.ref(), nb, bptr, bsl, bw,
                                        _lib.current_stream()), "ox_assemble_matrix")
     A.version += 1
-    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto"), ps_stride=int(os.environ.get("STRIDE", "0")), ps_grid=int(os.environ.get("GRID", "0"))), "entries", A._struct.n_dict, "ps_stride", A._struct.ps_stride, "ps_grid", A._struct.ps_grid)
+    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto")), "entries", A._struct.n_dict)
 npal = int(os.environ.get("PALETTE", "0"))  # > 0: values drawn from that many distinct numbers (mass /
 if npal:                                   # stiffness matrices on box meshes have 49 / 14)
     pal = torch.rand(npal, device="cuda", dtype=torch.float64) + 0.5
     A.vals.copy_(pal[torch.randint(0, npal, (A.vals.numel(),), device="cuda")])
-    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto"), ps_stride=int(os.environ.get("STRIDE", "0")), ps_grid=int(os.environ.get("GRID", "0"))), "entries", A._struct.n_dict, "ps_stride", A._struct.ps_stride, "ps_grid", A._struct.ps_grid)
+    print("value dictionary built:", A.freeze(pairs=os.environ.get("PAIRS", "auto")), "entries", A._struct.n_dict)
 P = V.pattern
 x = (torch.sin(torch.arange(P.n_cols*nc, device="cuda", dtype=torch.float64)*1e-3)+1).reshape(P.n_cols, nc).contiguous()
 y = torch.zeros_like(x)
