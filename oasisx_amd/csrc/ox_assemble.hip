@@ -226,11 +226,6 @@ struct FirstArgs {
   const uint8_t *Mc, *Kc;
   const double *Md, *Kd;
   int nMd, nKd;
-#ifdef OX_DIAG_W
-  const double *W;  // DIAGNOSTIC BUILDS ONLY (-DOX_DIAG -DOX_DIAG_W): per-cell record [42] = gam[10][4], adet, pad -- what a
-                    // cell-centric pre-pass G . u_ab would store; the pair loop reads it INSTEAD of geometry, cell dofs and
-                    // the coefficient gathers (zeros here: wrong results, the access pattern of the real thing)
-#endif
 #ifdef OX_DIAG
   int dbg;  // DIAGNOSTIC BUILDS ONLY (-DOX_DIAG, tools/build_diag.sh; never the product .so): OX_AF_DBG bit 0 skips the
             // pair loop, bit 1 the epilogue -- wrong results, for timing the two halves
@@ -300,23 +295,6 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
     }
     double G[U][GDIM + 1][GDIM], adet[U];
     int32_t dd[U][KIND == OX_KIND_CONV ? ND : 1];
-#ifdef OX_DIAG_W
-    double gw[U][KIND == OX_KIND_CONV ? ND : 1][GDIM + 1];
-    constexpr bool WPATH = KIND == OX_KIND_CONV && !QUAD && GDIM == 3 && ND == 10;
-    if constexpr (WPATH) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double2 *__restrict__ wp = reinterpret_cast<const double2 *>(F.W + (size_t)e[u] * 42);
-#pragma unroll
-        for (int k = 0; k < ND; ++k) {
-          const double2 a = wp[2 * k], b = wp[2 * k + 1];
-          gw[u][k][0] = a.x, gw[u][k][1] = a.y, gw[u][k][2] = b.x, gw[u][k][3] = b.y;
-        }
-        adet[u] = wp[20].x;
-      }
-    }
-    if constexpr (!WPATH)
-#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #ifdef OX_DIAG
@@ -340,11 +318,7 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
       }
     }
     double uc[U][KIND == OX_KIND_CONV ? ND : 1][GDIM];
-#ifdef OX_DIAG_W
-    if constexpr (KIND == OX_KIND_CONV && !WPATH) {
-#else
     if constexpr (KIND == OX_KIND_CONV) {
-#endif
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -436,12 +410,6 @@ __device__ __forceinline__ void assemble_slice(const ox_cells &cells, const int3
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
           double gam[GDIM + 1];
-#ifdef OX_DIAG_W
-          if constexpr (WPATH) {
-#pragma unroll
-            for (int b = 0; b <= GDIM; ++b) gam[b] = gw[u][k][b];
-          } else
-#endif
 #pragma unroll
           for (int b = 0; b <= GDIM; ++b) {
             double v = 0.0;
@@ -744,20 +712,6 @@ extern "C" int ox_assemble_first_au(int degree, const ox_cells *cells, const int
     F.dbg = e ? atoi(e) : 0;
   }
 #endif
-#ifdef OX_DIAG_W
-  {
-    static double *wbuf = nullptr;
-    static size_t wn = 0;
-    const size_t need = (size_t)cells->n_cells * 42;
-    if (need > wn) {
-      if (wbuf) (void)hipFree(wbuf);
-      OX_HIP(hipMalloc(&wbuf, need * sizeof(double)));
-      OX_HIP(hipMemset(wbuf, 0, need * sizeof(double)));
-      wn = need;
-    }
-    F.W = wbuf;
-  }
-#endif
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));
   const int rc = launch_rows<OX_KIND_CONV>(degree, cells, cell_dofs, adj, adj_pos, pw, A, F, n_bins,
                                            bin_ptr_host, bin_slices, bin_width_host, ox_stream(stream));
@@ -806,20 +760,6 @@ extern "C" int ox_assemble_first_blocks(int degree, const ox_cells *cells, const
   {
     const char *e = getenv("OX_AF_DBG");
     F.dbg = e ? atoi(e) : 0;
-  }
-#endif
-#ifdef OX_DIAG_W
-  {
-    static double *wbuf = nullptr;
-    static size_t wn = 0;
-    const size_t need = (size_t)cells->n_cells * 42;
-    if (need > wn) {
-      if (wbuf) (void)hipFree(wbuf);
-      OX_HIP(hipMalloc(&wbuf, need * sizeof(double)));
-      OX_HIP(hipMemset(wbuf, 0, need * sizeof(double)));
-      wn = need;
-    }
-    F.W = wbuf;
   }
 #endif
   if (ox_prof_on) ox_prof_start(OX_TAG_ASSEMBLE_FIRST, ox_stream(stream));

@@ -1,5 +1,6 @@
 # Pricing of a cell-centric pre-pass for assemble_first on the UNSTRUCTURED bench mesh (jittered 33^3 lattice, Delaunay,
 # refined twice: 14.0 M tets, 18.9 M P2 rows), row-block launch.  Diagnostic builds only (wrong results, timing).
+# The two diagW lines need the -DOX_DIAG_W code of commit b947ab9 (removed after the measurement: profiles/r06_assemble_first_delaunay_pricing.txt).
 set -e
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/price_af_delaunay.txt
