@@ -122,14 +122,19 @@ def _in_a_child_with_eight_queues(call):
     assert r.returncode == 0 and "ranks ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-def test_window_allreduce_of_several_ranks_in_one_process(hip):
-    """Two and three ranks, 1 to 15 values, both release protocols (conservative = the default; fast = round 5's)."""
-    _in_a_child_with_eight_queues("[t._window_allreduce_ranks(nr, n, fast) for nr, n in ((3, 15), (3, 5), (2, 1)) for fast in (False, True)]")
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("nr,n", [(3, 15), (3, 5), (2, 1)])
+def test_window_allreduce_of_several_ranks_in_one_process(hip, nr, n, fast):
+    """Two and three ranks, 1 to 15 values, both release protocols (conservative = the default; fast = round 5's).  ONE
+    configuration per child process: the first streams a process takes from the pool land on distinct hardware queues;
+    later ones need not (a second configuration in the same process was seen to share a queue and time out)."""
+    _in_a_child_with_eight_queues(f"t._window_allreduce_ranks({nr}, {n}, {fast})")
 
 
-def test_window_allreduce_of_six_ranks_two_waves_of_lanes(hip):
+@pytest.mark.parametrize("fast", [False, True])
+def test_window_allreduce_of_six_ranks_two_waves_of_lanes(hip, fast):
     """Six ranks -- 96 lanes, two waves, what an 8-GPU job runs -- need six kernels in flight."""
-    _in_a_child_with_eight_queues("t._window_allreduce_ranks(6, 15); t._window_allreduce_ranks(6, 15, True)")
+    _in_a_child_with_eight_queues(f"t._window_allreduce_ranks(6, 15, {fast})")
 
 
 @pytest.mark.parametrize("transport", ["rccl", "p2p"])
