@@ -168,7 +168,7 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
-def test_bench_under_the_driver_launch_line_with_two_ranks():
+def test_bench_under_the_driver_launch_line_with_two_ranks(tmp_path):
     """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), rehearsed with 2 ranks on the
     one GPU of the box: torch.distributed over gloo (RCCL refuses two ranks on one device), the
@@ -182,7 +182,8 @@ def test_bench_under_the_driver_launch_line_with_two_ranks():
     env = dict(os.environ, OX_P2P_TIMEOUT_S="60")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "-N", "16", "--backend", "gloo"]
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "-N", "16", "--backend", "gloo",
+           "--probe-transports", "--full-out", str(tmp_path / "full.json")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip().startswith("{")]
@@ -190,6 +191,10 @@ def test_bench_under_the_driver_launch_line_with_two_ranks():
     d = json.loads(lines[0])
     _check(d, live_cpu=False)
     assert len(lines[0].encode()) <= LIMIT
+    # the transport probe ran AFTER the line: nothing of it on stdout, its times on stderr and in the side file
+    assert "transport_exchange_us" in out.stderr and "transport_exchange_us" not in out.stdout
+    full = json.loads(open(tmp_path / "full.json").read())
+    assert full["value"] == d["value"] and full["config"]["transport_exchange_us"]["velocity_space"]
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["config"]["parallelism"] == "mesh-partition x2" and d["config"]["transport"].startswith("p2p")
     assert d["cpu_baseline"] is None or "value" in d["cpu_baseline"]
@@ -211,8 +216,10 @@ def test_the_launcher_line_with_one_rank_is_the_plain_line():
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *tail], capture_output=True, text=True,
                            timeout=600, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-2000:]
+    # (the launched run WITH the counter child passes, as the driver's SCALE series runs it at N = 1: the rocprofv3
+    # children inherit the launcher's WORLD_SIZE = 1 / RANK / MASTER_* environment)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", *tail]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", *[t for t in tail if t != "--no-pmc"]]
     launched = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert launched.returncode == 0, launched.stderr[-3000:]
     a, b = (json.loads([ln for ln in o.stdout.strip().splitlines() if ln.strip().startswith("{")][-1]) for o in (plain, launched))
@@ -226,3 +233,5 @@ def test_the_launcher_line_with_one_rank_is_the_plain_line():
     assert a["krylov_iterations_series"] == b["krylov_iterations_series"]
     assert a["pressure_cg_iteration"]["kernels_per_iteration"] == b["pressure_cg_iteration"]["kernels_per_iteration"]
     assert a["roofline"]["kernel"] == b["roofline"]["kernel"] and a["roofline"]["stored_bytes_per_launch"] == b["roofline"]["stored_bytes_per_launch"]
+    assert a["roofline"]["traffic"] is None and "NO COUNTERS" in a["roofline"]["basis"]
+    assert b["roofline"]["traffic"] is not None and "rocprofv3" in b["roofline"]["basis"], b["roofline"].get("counters_error")
