@@ -312,3 +312,44 @@ def test_fold_setting_is_per_solver_not_per_process(hip):
     ra2 = a.solve_block(B, Xa)[0]  # after b ran: a is still the five-kernel form, bit for bit what it was
     assert ra == rb == ra2 == 2 and abs(a.iterations[0] - b.iterations[0]) <= 1
     assert np.abs(Xa.dev().cpu().numpy() - Xb.dev().cpu().numpy()).max() < 1e-8
+
+
+def test_nonzero_guess_with_a_tiny_right_hand_side_meets_divtol_at_iteration_zero(hip):
+    """every entry point applies PETSc's default ``divtol = 1e4`` against |D^-1 b|.  With a NONZERO initial
+    guess and a near-zero right-hand side (a near-steady pressure increment) the initial residual |D^-1 (b - A x0)| is
+    more than 1e4 |D^-1 b|: KSP_DIVERGED_DTOL at iteration 0, as PETSc's KSPConvergedDefault reports it.  A caller that
+    knows its guess may be far from a tiny right-hand side passes ``ksp_divtol``; the oracle's
+    stand-in for PETSc behaves the same."""
+    from oasisx_amd.fem import FieldStorage
+    from oasisx_amd.ksp import KSPSolver
+    from oracle import ipcs_oracle as O
+
+    mesh, V, F = _space_and_forms(2, 12, 2)
+    Acsr = (F.stiffness_v() + 3.0 * F.mass_v()).tocsr()
+    A = _matrix(V, Acsr, symmetric=True)
+    n = V.num_dofs
+    x = V.x.cpu().numpy()
+    b = 1e-12 * np.sin(3.0 * x[:, 0])
+    x0 = 1.0 + 0.5 * np.cos(2.0 * x[:, 1])
+    B, X = FieldStorage(n, 1, "cuda"), FieldStorage(n, 1, "cuda")
+    B.dev()[:, 0] = torch.from_numpy(b).cuda()
+    base = {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-8, "ksp_atol": 1e-50, "ksp_initial_guess_nonzero": True}
+    ksp = KSPSolver(None, base)
+    ksp.setOperators(A)
+    X.dev()[:, 0] = torch.from_numpy(x0).cuda()
+    assert ksp.solve_block(B, X)[0] == -4 and int(ksp.last_result.its[0]) == 0  # KSP_DIVERGED_DTOL before the first iteration
+    assert np.array_equal(X.dev()[:, 0].cpu().numpy(), x0)  # the guess is handed back untouched
+    _, reason_o, its_o, _ = O.jacobi_cg(Acsr, b, x0=x0.copy(), rtol=1e-8, atol=1e-50)
+    assert reason_o == -4 and its_o == 0
+    # with the bound raised the same solve converges to the tiny solution
+    ksp = KSPSolver(None, dict(base, ksp_divtol=1e30))
+    ksp.setOperators(A)
+    X.dev()[:, 0] = torch.from_numpy(x0).cuda()
+    assert ksp.solve_block(B, X)[0] == 2
+    sol, reason_o, its_o, _ = O.jacobi_cg(Acsr, b, x0=x0.copy(), rtol=1e-8, atol=1e-50, divtol=1e30)
+    assert reason_o == 2 and abs(int(ksp.last_result.its[0]) - its_o) <= 1
+    # (from an O(1) guess towards an O(1e-11) solution the TRUE residual ends at rounding level, eps |A| |x0| ~ 1e-3 |b|,
+    # on both sides; what is checked is that the iteration left the guess for the tiny solution, as the oracle's did)
+    xg = X.dev()[:, 0].cpu().numpy()
+    assert np.abs(xg).max() < 1e-9 and np.abs(sol).max() < 1e-9
+    assert _true_rel_residual(Acsr, b, xg) < 1e-2 and _true_rel_residual(Acsr, b, sol) < 1e-2

@@ -86,3 +86,43 @@ def test_eight_rank_threads_step_like_the_serial_run(hip, N, deg, p_deg, kind, l
         assert abs(max(res[0]["its"][k]) - max(int(i) for i in gi[k])) <= 2, (k, res[0]["its"], gi)
     # every rank went through the same number of collective points
     assert len(set(world.allreduces)) == 1 and world.allreduces[0] > 0 and min(world.exchanges) > 0
+
+
+def test_a_failed_pressure_solve_raises_on_every_rank(hip):
+    """``ksp_error_if_not_converged`` on a partitioned job.  The convergence test's operands are all-reduced, so
+    KSP_DIVERGED_ITS is reached at the same iteration on every rank and EVERY rank raises ``KSPConvergenceError`` -- no
+    rank is left waiting in a collective for one that has already unwound (8 rank threads; a rank stuck in an exchange
+    would run into the bounded waits of the harness and fail the test with a broken barrier instead)."""
+    import oasisx_amd as ox
+    from oasisx_amd import mesh as M
+    from oasisx_amd.ksp import KSPConvergenceError
+    from oracle import ipcs_oracle as O
+    from tests.helpers import KRYLOV, on_boundary3, run_rank_threads
+
+    nu, dt = 0.01, 0.005
+
+    def rank_job(comm):
+        mesh = M.create_box(comm, [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], [6, 6, 6])
+        clock = {"t": 0.0}
+        fns = [O.tg_u, O.tg_v, O.tg_w]
+        bcs = [[ox.DirichletBC(lambda x, f=f: f(x, clock["t"], nu), ox.LocatorMethod.GEOMETRICAL, on_boundary3)] for f in fns]
+        so = {k: dict(v) for k, v in KRYLOV.items()}
+        so["pressure"].update(ksp_max_it=3, ksp_rtol=1e-14)  # (no pressure conditions: the solver sets error_if_not_converged)
+        S = ox.FractionalStep_AB_CN(mesh, ("Lagrange", 2), ("Lagrange", 1), bcs_u=bcs, bcs_p=[], solver_options=so,
+                                    options={"sell_window": 128})
+        for i, f in enumerate(fns):
+            S._u2[i].interpolate(lambda x, f=f: f(x, -dt, nu))
+            S._u1[i].interpolate(lambda x, f=f: f(x, 0.0, nu))
+        S._p.interpolate(lambda x: O.tg_p(x, -dt / 2, nu))
+        clock["t"] = dt
+        try:
+            S.solve(dt, nu, max_iter=1)
+        except KSPConvergenceError as e:
+            torch.cuda.synchronize()
+            return {"reasons": list(e.reasons), "iterations": list(e.iterations)}
+        return None
+
+    res, world = run_rank_threads(8, rank_job)
+    assert all(r is not None for r in res), res
+    assert all(r == res[0] for r in res) and res[0]["reasons"][0] == -3 and res[0]["iterations"][0] == 3, res
+    assert len(set(world.allreduces)) == 1  # every rank left the solve at the same collective point
