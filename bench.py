@@ -226,14 +226,26 @@ def child_argv_of(args):
     return av
 
 
-def pick_kernel(passes, prefix, grid):
-    """The (kernel, grid) entry of a rocprof_passes() table whose demangled name starts with ``prefix``."""
+def pick_kernel(passes, prefix, grid, epi=None):
+    """The (kernel, grid) entry of a rocprof_passes() table whose demangled name starts with ``prefix``.  With ``epi``
+    (the pressure CG's epilogue id) and no exact match -- a matrix on the LDS-window stream launches ``k_spmv_win`` on a
+    grid the host does not know --: the MOST DISPATCHED one-column mat-vec with that epilogue (the pressure solve's: 200-1000
+    launches per step against a handful of narrowed mass products)."""
+    import re
+
     if not passes or "error" in passes:
         return None
     for (name, g), v in passes["kernels"].items():
         if g == grid and name.startswith(prefix) and "traffic" in v and "avg_us" in v:
             return dict(v, kernel=name, grid=g)
-    return None
+    if epi is None:
+        return None
+    pat = re.compile(r"^voidk_spmv(_ps|_win)?<1,%d[,>]" % int(epi))
+    best = None
+    for (name, g), v in passes["kernels"].items():
+        if pat.match(name) and "traffic" in v and "avg_us" in v and (best is None or v["dispatches"] > best["dispatches"]):
+            best = dict(v, kernel=name, grid=g)
+    return best
 
 
 def rocprof_kernel_table(passes, n=14):
@@ -919,10 +931,13 @@ def main():
     if cg:
         epi_name = "OX_EPI_CG_M2" if cg_merged else "OX_EPI_DOT"
         kid = spmv_kernel_id(S._Ap, 5 if cg_merged else 1)
+        on_windows = (S._Ap.ps_code is None and getattr(Pp, "wcode", None) is not None and S._Ap._struct.n_wblocks > 0)
         roofline = {"kernel": (f"k_spmv_ps<1,{epi_name}> (pressure-Poisson CG SpMV, SELL-64 pair-slot stream, f64)"
                                if S._Ap.ps_code is not None else
+                               f"k_spmv_win<1,{epi_name},*> (pressure-Poisson CG SpMV, SELL-64 LDS-window stream, f64)" if on_windows else
                                f"k_spmv<1,{epi_name},*> (pressure-Poisson CG SpMV, SELL-64, f64)")}
-        roofline.update(roofline_of(cg["bytes_moved"], b_p, cg["avg_us"], cg["launches"], pick_kernel(passes, *kid)))
+        roofline.update(roofline_of(cg["bytes_moved"], b_p, cg["avg_us"], cg["launches"],
+                                    pick_kernel(passes, *kid, epi=5 if cg_merged else 1)))
         if passes is not None and "error" in passes:
             roofline["counters_error"] = passes["error"]
         roofline.update({
