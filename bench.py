@@ -72,7 +72,8 @@ def parse():
                          "(default here: -ksp_initial_guess_nonzero, the previous field is the guess)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-cpu-one-core", action="store_true",
-                    help="skip the 1-core repetition of the cpu_baseline step (about a minute at 128^3)")
+                    help="(kept for old command lines; the 1-core repetition of the cpu_baseline step -- about a minute at "
+                         "128^3 -- runs only with --extras, and then unless this flag is given)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the cheap variant legs (steady state, zero guess, dictionaries off) and the 256^3 past-cache SpMV")
@@ -1175,7 +1176,7 @@ def main():
         def note(msg):
             print("[bench] extras: " + msg, file=sys.stderr, flush=True)
 
-        if not args.no_cpu and isinstance(out["cpu_baseline"], dict) and "value" in out["cpu_baseline"]:
+        if not args.no_cpu and not args.no_cpu_one_core and isinstance(out["cpu_baseline"], dict) and "value" in out["cpu_baseline"]:
             try:  # the same host step on ONE core (about a minute at 128^3)
                 from oracle.cpu_baseline import run_cpu_baseline
 
