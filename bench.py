@@ -24,7 +24,9 @@ repetition) run only with ``--extras``, after the line is out, and land in the s
                 `achieved` = traffic / that time, `frac` = achieved / 8 TB/s.  `frac_algorithmic` prices the same
                 launch at SURVEY.md 8d's CSR bytes (12 B per nonzero); `hip_event` = the stored bytes over the HIP-event
                 time measured inside the timed region; `past_cache` = the same kernel on the 256^3 pressure matrix
-                (0.9 GB stored: beyond the 256 MB Infinity Cache), with its own counters from the same child passes
+                (0.9 GB stored: beyond the 256 MB Infinity Cache), with its own counters from the same child passes;
+                `f64_values` = the same launch on the same matrix with the value dictionary off (plain f64 value stream,
+                HBM-resident), counters from a second set of child passes (--no-dictionary)
   headline_petsc_default  the same timed steps with PETSc's default zero initial guess, and with the value
                 dictionaries off (what a mesh without bit-identical cells gets)
   cpu_baseline  one step of the same workload on the host cores (oracle/ipcs_cpu.c), all cores (one core too with
@@ -351,6 +353,9 @@ def compact_line(full, limit=COMPACT_LIMIT):
         rr = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "basis", "avg_launch_us",
                        "algorithmic_bytes_per_launch", "achieved_algorithmic", "frac_algorithmic", "frac_algorithmic_note",
                        "stored_bytes_per_launch", "traffic_over_stored", "hip_event", "counters_error"))
+        if isinstance(r.get("f64_values"), dict):
+            rr["f64_values"] = _pick(r["f64_values"], ("what", "achieved", "frac", "traffic", "avg_launch_us", "stored_bytes_per_launch",
+                                                       "traffic_over_stored", "hip_event", "counters_error"))
         if isinstance(r.get("past_cache"), dict):
             rr["past_cache"] = _pick(r["past_cache"], ("workload", "achieved", "frac", "traffic", "basis", "avg_launch_us",
                                                        "stored_bytes_per_launch", "algorithmic_bytes_per_launch",
@@ -481,8 +486,12 @@ def main():
     passes = leg_passes = None
     DELAUNAY_LEG = (32, 2)  # --extras: the unstructured leg's mesh (jittered 33^3 lattice, refined twice: 14.0 M tets)
     extras_legs = (world == 1 and args.extras and not args.pmc_child and args.workload == "tg" and args.mesh == "box")
+    passes_f64 = None  # the same command with the value dictionaries off: the pressure SpMV on plain f64 values
     if world == 1 and not args.no_pmc and not args.pmc_child:
         passes = rocprof_passes(child_argv_of(args), log, "the headline workload")
+        if not args.no_extras and not args.no_dictionary and args.mesh == "box" and "error" not in passes:
+            passes_f64 = rocprof_passes([a for a in child_argv_of(args) if a != "--no-extras"] + ["--no-dictionary", "--no-extras"],
+                                        log, "the headline workload without value dictionaries")
         if extras_legs and args.udeg == 2 and args.N >= 96:
             leg_passes = rocprof_passes(["-N", str(DELAUNAY_LEG[0]), "--mesh", "delaunay", "--refine", str(DELAUNAY_LEG[1]),
                                          "--workload", "beltrami", "--udeg", str(args.udeg), "--pdeg", str(args.pdeg),
@@ -988,9 +997,21 @@ def main():
             if not args.matrix_free:
                 for A in (S._p_vdxi_Mat, S._grad_p_Mat, S._divu_Mat):
                     A.unfreeze()
-            leg("value_dictionary=False",
-                "f64 value streams everywhere: what a mesh without bit-identical cells (any unstructured mesh) gets; "
-                "same arithmetic, same results")
+            nd = leg("value_dictionary=False",
+                     "f64 value streams everywhere: what a mesh without bit-identical cells (any unstructured mesh) gets; "
+                     "same arithmetic, same results")
+            ev = nd.get("pressure_cg_spmv")
+            if roofline is not None and ev and ev.get("bytes_moved"):
+                # the SAME mat-vec on the SAME matrix with plain f64 values (16-bit column codes only): HBM-resident
+                # (0.47 GB > the 256 MB Infinity Cache), i.e. ON the HBM roofline -- counters from a second set of child
+                # passes (--no-dictionary).  The shipped value dictionary makes it ~2 x faster and takes it off that roofline.
+                kid_f64 = spmv_kernel_id(S._Ap, 5 if cg_merged else 1)  # (the codes are dropped: k_spmv<1, epi, 3>)
+                f64 = roofline_of(ev["bytes_moved"], b_p, ev["avg_us"], ev["launches"], pick_kernel(passes_f64, *kid_f64))
+                f64["what"] = ("the same launch with the value dictionary OFF (f64 value stream, 16-bit column codes): what a "
+                               "mesh without bit-identical cells gets, and the form that is bound by HBM bytes")
+                if passes_f64 is not None and "error" in passes_f64:
+                    f64["counters_error"] = passes_f64["error"]
+                roofline["f64_values"] = f64
 
     # ---- the metric's kernel past the Infinity Cache: 256^3 pressure matrix -----------------------
     # (also in the --pmc-child runs, so that the counter passes hold this launch too)

@@ -70,6 +70,9 @@ def test_the_compact_line_of_the_newest_committed_record_meets_the_contract():
     pc = r["past_cache"]  # the same kernel on the 256^3 matrix, its own counters from the same child passes
     assert 0.0 < pc["frac"] < 1.0 and pc["stored_bytes_per_launch"] > 256 * 2 ** 20 and pc["traffic"] > 256 * 2 ** 20
     assert "rocprofv3" in pc["basis"]
+    f64 = r["f64_values"]  # the same launch on plain f64 values (second set of child passes): HBM-resident, on the roofline
+    assert f64["traffic"] > 256 * 2 ** 20 and 0.9 < f64["traffic_over_stored"] < 1.1 and f64["frac"] >= 0.60 > r["frac"]
+    assert f64["avg_launch_us"] > 1.5 * r["avg_launch_us"]  # ... and the dictionary form is that much faster
     hp = d["headline_petsc_default"]
     assert hp["zero_initial_guess_steps_per_s"] < hp["headline_steps_per_s"] and hp["no_value_dictionary_steps_per_s"] > 0
     assert d["cpu_baseline"]["cpu_model"] and d["cpu_baseline"]["gpu_over_cpu"] > 1.0
@@ -128,6 +131,7 @@ def test_bench_runs_and_prints_one_json_line(tmp_path):
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
     assert d["roofline"]["traffic"] is not None, d["roofline"].get("counters_error")  # the child passes ran and found the kernel
     assert d["roofline"]["past_cache"]["traffic"] is not None and d["headline_petsc_default"]["zero_initial_guess_steps_per_s"] > 0
+    assert d["roofline"]["f64_values"]["traffic"] is not None, d["roofline"]["f64_values"].get("counters_error")
     full = json.loads(open(side).read())
     assert full["value"] == d["value"] and len(full["variants"]) >= 2 and full["kernels"] and full["kernels_rocprofv3"]
 
