@@ -211,3 +211,26 @@ def test_partitioned_merged_bicgstab_retests_the_stored_residual(hip, transport)
     mp.spawn(_retest_worker, args=(2, _free_port(), transport, out), nprocs=2, join=True)
     assert len(out) == 2 and out[0] == out[1], dict(out)  # the same re-openings, the same iteration counts on both ranks
     assert sum(out[0][0]) > 0, dict(out)  # at least one column was re-opened
+
+
+def test_first_link_check_script_rehearsal(hip):
+    """tools/first_link_check.py -- the procedure for the first node with a link (halo self-test, bit-exact all-reduce,
+    two steps against the serial run, 200 timed exchanges, for every device transport) -- stays runnable: its own
+    rehearsal mode, 2 ranks sharing this GPU over gloo, conservative and fast release protocol and the host transport."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OX_TRANSPORT", "OX_P2P_RELEASE")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tools", "first_link_check.py"), "--backend", "gloo", "-N", "6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert [x["transport"] for x in recs[:-1]] == ["p2p", "p2p-fast", "host"]
+    for x in recs[:-1]:
+        assert x["max_abs_du"] < 1e-8 and x["allreduce_bits_equal_on_all_ranks"] and x["allreduce_is_the_rank_order_sum"]
+        assert set(x["active"].values()) == {x["transport"].split("-")[0]}
+    assert recs[-1]["first_link_check"] == {"p2p": "passed", "p2p-fast": "passed", "host": "passed"}
+    assert "no link was crossed" in recs[-1]["note"]
