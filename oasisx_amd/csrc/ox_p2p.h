@@ -53,7 +53,7 @@ __device__ __forceinline__ void ox_p2p_allreduce_block(double *vals, int n, cons
     char *dst = a.r_slot[(live ? r : 0) * 2 + a.parity];
     if (live && i < n) __hip_atomic_store(reinterpret_cast<double *>(dst) + i, vals[i], __ATOMIC_RELAXED, OX_SYS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's payload stores are acknowledged ...
-    __threadfence_system();                            // ... ONE release for all of them, then the flags (relaxed)
+    __threadfence_system();                            // ... ONE fence for all of them, then the flags (relaxed, or -- conservative plans -- release stores)
     const char *src = a.my_slots + ((size_t)a.parity * a.nranks + (live ? r : 0)) * OX_P2P_SLOT;
     if (live && i == 15) {
       // conservative plans (the default until the windows have crossed a link): the flag itself is a system-scope
