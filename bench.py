@@ -142,7 +142,7 @@ def host_cores():
 
 
 # ---- HBM traffic and kernel durations: rocprofv3 child passes of this command ---------------------
-def rocprof_passes(child_argv, log, label):
+def rocprof_passes(child_argv, log, label, budget_s=240):
     """Run ``bench.py --pmc-child <child_argv>`` (1 warm-up + 1 timed step, then -- box meshes -- the 256^3 pressure
     SpMV) three times: under ``rocprofv3 --pmc FETCH_SIZE``, ``--pmc WRITE_SIZE`` (separate passes, as
     MI355X_MICROARCH.md's HBM section prescribes) and ``--kernel-trace``.  Returns the per-(kernel, grid) averages of all
@@ -171,11 +171,28 @@ def rocprof_passes(child_argv, log, label):
             mode = ["--kernel-trace"] if counter == "KERNEL_TRACE" else ["--pmc", counter]
             cmd = [exe, *mode, "--output-format", "csv", "-d", out, "--", py, os.path.join(ROOT, "bench.py"), "--pmc-child",
                    *child_argv]
-            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            if p.returncode != 0:
-                return {"error": f"rocprofv3 {counter} pass of {label} failed (rc {p.returncode}): "
-                                 + p.stderr.decode(errors="replace")[-300:]}
-            for line in p.stdout.decode(errors="replace").splitlines():
+            # bounded: a pass that hangs must not cost the run its line (the driver's limit is 600 s for everything).  The
+            # pass runs in its own process group, so a time-out takes rocprofv3 AND the python under it down (by pid group,
+            # never by pattern)
+            import signal
+
+            # (``budget_s`` covers the three passes together: the first may pay a cold start of the interpreter and its
+            # libraries, the others are then quick)
+            pass_timeout = max(10.0, budget_s - (time.perf_counter() - t0))
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=pass_timeout)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
+                return {"error": f"rocprofv3 {counter} pass of {label} did not finish within its share ({pass_timeout:.0f} s) of the {budget_s} s budget (killed)"}
+            if proc.returncode != 0:
+                return {"error": f"rocprofv3 {counter} pass of {label} failed (rc {proc.returncode}): "
+                                 + se.decode(errors="replace")[-300:]}
+            for line in so.decode(errors="replace").splitlines():
                 if line.startswith("{") and '"pmc_child"' in line:
                     child = json.loads(line)
             if child is None:
@@ -489,14 +506,16 @@ def main():
     passes_f64 = None  # the same command with the value dictionaries off: the pressure SpMV on plain f64 values
     if world == 1 and not args.no_pmc and not args.pmc_child:
         passes = rocprof_passes(child_argv_of(args), log, "the headline workload")
-        if not args.no_extras and not args.no_dictionary and args.mesh == "box" and "error" not in passes:
+        # (the second set only where the first one was quick: the line must be out long before the driver's limit)
+        if (not args.no_extras and not args.no_dictionary and args.mesh == "box" and "error" not in passes
+                and passes["seconds"] < 90.0):
             passes_f64 = rocprof_passes([a for a in child_argv_of(args) if a != "--no-extras"] + ["--no-dictionary", "--no-extras"],
-                                        log, "the headline workload without value dictionaries")
+                                        log, "the headline workload without value dictionaries", budget_s=120)
         if extras_legs and args.udeg == 2 and args.N >= 96:
             leg_passes = rocprof_passes(["-N", str(DELAUNAY_LEG[0]), "--mesh", "delaunay", "--refine", str(DELAUNAY_LEG[1]),
                                          "--workload", "beltrami", "--udeg", str(args.udeg), "--pdeg", str(args.pdeg),
                                          "--steps", "1", "--warmup", "1", "--rtol", str(args.rtol), "--no-extras"],
-                                        log, "the unstructured leg")
+                                        log, "the unstructured leg", budget_s=600)
     full_path = args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
 
     os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))  # cpu_baseline leg (oracle/ipcs_cpu.c)
